@@ -1,0 +1,10 @@
+"""CPU oracle for the set-point-control hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package, and only as
+the checker.  The product package never imports it.  See pime_oracle.c for the restatement and its
+reference citations, and oracle/ref_streams.py for the MT19937 stream emulation used by the parity tests.
+"""
+from .binding import (  # noqa: F401
+    OraclePH, OracleWT, build, critic_forward, gae, lib, modular_actor_mean, philox4x32_10, philox_uniform_pair,
+    ph_table, ph_zoh, plain_actor_mean, residual_action,
+)
