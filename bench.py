@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec (rollout + update), pH env, 16 384 parallel envs per MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+  rollout : 16 384 lanes x one 50-step episode of 'PH1DChangingParamUniformGoalIntegrator-SqaureDistance-v35'
+            (ensemble params resampled every episode, in-kernel Philox draws) under the residual modular PPO
+            policy (net_dim 128): fused f32-MFMA policy forward -> exploration noise -> fused residual env step
+  update  : value pass (fused f32-MFMA critic forward over 819 200 rows) -> GAE scan -> PPO minibatch updates,
+            batch 65 536, repeat_times 8 -> 100 optimizer steps (run_ph_changing.sh:5,9 scaled to N*T samples)
+  => 819 200 env-steps per step and per GPU.  Weak scaling: every rank owns 16 384 lanes; one flat-gradient
+  all-reduce per optimizer step.
+
+Usage:  python bench.py [--gpus N --steps K --warmup W]     (N > 1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+LANES = 16384
+T_EP = 50
+NET_DIM = 128
+BATCH = 65536
+REPEAT = 8
+LAMBDA = 0.99     # run_ph_changing.sh:10
+GAMMA = 0.99      # train.py never forwards --gamma
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+# algorithmic cost models (DESIGN.md "Kernels")
+PH_STEP_BYTES = 94            # mixed mode, fused-residual step: see DESIGN.md table
+MLP_FLOPS_PER_ROW = {"critic": 2 * (3 * 128 + 128 * 128 * 2 + 128),
+                     "modular_actor": 2 * (2 * 128 + 128 * 64 + 1 * 128 + 128 * 64 + 128 * 128 + 128)}
+
+
+class KernelTimer:
+    """HIP-event timing of named launches on torch's current stream (the stream libpime_hip launches on)."""
+
+    def __init__(self):
+        self.pairs = {}
+        self.enabled = False
+
+    def wrap(self, name, fn):
+        def timed(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*a, **k)
+            e.record()
+            self.pairs.setdefault(name, []).append((s, e))
+            return out
+        return timed
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.pairs.items()}
+
+
+def build_stack(device, rank, world, dp):
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from pime_amd.elegantrl.run import make_buffer
+    env = gym_control.make_vec(gym_control.PH_V35, LANES, device=device, state_mode="mixed", seed=0,
+                               env_offset=rank * LANES, draws="philox", resample_every=1)
+    torch.manual_seed(0)  # identical initial replicas on every rank
+    agent = AgentResidualIntegratorModularPPO(device=device)
+    agent.lambda_gae_adv = LAMBDA
+    agent.init(NET_DIM, env.state_dim, 1, env.n_integrator)
+    agent.init_residual({"init_K": env.K.reshape(-1, 1)})
+    agent.init_actor_zero()
+    agent.fix_K()
+    agent.dp = dp
+    if dp is not None:
+        dp.broadcast_module(agent.act, agent.cri)
+    torch.manual_seed(1000 + rank)  # exploration / minibatch streams differ per rank
+    buf = make_buffer(agent, env, LANES * T_EP)
+    return env, agent, buf
+
+
+def one_step(env, agent, buf):
+    steps = agent.explore_env(env, buf, LANES * T_EP, 1.0, GAMMA)
+    agent.update_net(buf, LANES * T_EP, BATCH, REPEAT)
+    return steps
+
+
+def cpu_baseline():
+    """The same hot path on the host: C oracle envs + torch-CPU nets with the product's own agent code, on a bounded
+    sample (2 048 lanes x one 50-step episode, batch 8 192, repeat 8 -> 100 optimizer steps, like the GPU schedule)."""
+    import oracle  # noqa: F401  (allowed here: bench.py's cpu_baseline leg)
+    from oracle.cpu_stack import OracleBackend, OracleVecEnv
+    from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from pime_amd.elegantrl.replay import TrajectoryBuffer
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = 2048
+    env = OracleVecEnv("ph", n, seed=0)
+    torch.manual_seed(0)
+    agent = AgentResidualIntegratorModularPPO(backend=OracleBackend(), device="cpu")
+    agent.lambda_gae_adv = LAMBDA
+    agent.init(NET_DIM, 3, 1, 1)
+    agent.init_residual({"init_K": env.K.reshape(-1, 1)})
+    buf = TrajectoryBuffer(T_EP, n, 3, 1, "cpu")
+    t0 = time.perf_counter()
+    steps = agent.explore_env(env, buf, n * T_EP, 1.0, GAMMA)
+    t1 = time.perf_counter()
+    agent.update_net(buf, n * T_EP, n * T_EP * BATCH // (LANES * T_EP), REPEAT)
+    t2 = time.perf_counter()
+    return {"value": steps / (t2 - t0), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} lanes x {T_EP} steps (= {steps} env-steps), batch {n * T_EP * BATCH // (LANES * T_EP)}, "
+                      f"repeat {REPEAT}: C oracle env (1 thread) {t1 - t0:.2f}s + torch-CPU PPO update ({cores} threads) {t2 - t1:.2f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from pime_amd import dist as pdist
+    rank, world, local = pdist.env_rank_world()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    device = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    dp = pdist.init_from_env(backend="nccl", device=device) if world > 1 else None
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    env, agent, buf = build_stack(device, rank, world, dp)
+    timer = KernelTimer()
+    # time the hand-written kernels where the agent calls them
+    import pime_amd.ops as ops
+    agent.state_value = timer.wrap("mlp_forward<critic> value pass", agent.state_value)
+    agent.policy_mean = timer.wrap("mlp_forward<modular_actor> rollout", agent.policy_mean)
+    env.step_residual = timer.wrap("ph_step_kernel (fused residual)", env.step_residual)
+    agent.backend.gae = timer.wrap("gae_scan_kernel", agent.backend.gae)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dp is not None:
+            dp.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(env, agent, buf)
+    sync()
+    timer.enabled = True
+    t_roll = t_upd = 0.0
+    t0 = time.perf_counter()
+    total = 0
+    for _ in range(args.steps):
+        total += one_step(env, agent, buf)
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if dp is not None:
+        dt = dp.max_over_ranks(dt)
+        total = dp.sum_over_ranks(total)
+
+    # rollout / update split (one extra untimed step, synchronised between the halves)
+    sync()
+    a = time.perf_counter()
+    agent.explore_env(env, buf, LANES * T_EP, 1.0, GAMMA)
+    torch.cuda.synchronize()
+    b = time.perf_counter()
+    agent.update_net(buf, LANES * T_EP, BATCH, REPEAT)
+    torch.cuda.synchronize()
+    c = time.perf_counter()
+    t_roll, t_upd = b - a, c - b
+
+    if rank != 0:
+        return
+    ks = timer.summary()
+    per_step = {k: n * ms / args.steps for k, (n, ms) in ks.items()}
+    dominant = max(per_step, key=per_step.get)
+    n_dom, ms_dom = ks[dominant]
+    if "critic" in dominant or "actor" in dominant:
+        kind = "critic" if "critic" in dominant else "modular_actor"
+        rows = LANES * T_EP if kind == "critic" else LANES
+        achieved = MLP_FLOPS_PER_ROW[kind] * rows / (ms_dom * 1e-3) / 1e12
+        roofline = {"kernel": dominant, "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "launches_per_step": n_dom / args.steps, "avg_launch_ms": ms_dom}
+    else:
+        achieved = PH_STEP_BYTES * LANES / (ms_dom * 1e-3) / 1e9
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches_per_step": n_dom / args.steps,
+                    "avg_launch_ms": ms_dom}
+    n_env, ms_env = ks["ph_step_kernel (fused residual)"]
+    env_gbs = PH_STEP_BYTES * LANES / (ms_env * 1e-3) / 1e9
+    out = {
+        "metric": "env-steps/sec (rollout+update), pH env, 16384 parallel envs",
+        "value": total / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "pH v35, 16384 lanes/GPU x 50-step episodes, ensemble resampled every episode, "
+                               "ResidualIntegratorModularPPO net_dim 128, batch 65536, repeat 8 (100 optimizer steps)",
+                   "lanes_per_gpu": LANES, "episode_len": T_EP, "batch": BATCH, "repeat_times": REPEAT,
+                   "state_mode": "mixed (f32 state, f64 x/A/B/C)", "parallelism": f"dp{world}"},
+        "roofline": roofline,
+        "roofline_env": {"kernel": "ph_step_kernel (fused residual)", "bound": "hbm", "achieved": env_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": env_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": ms_env, "note": "16384-lane launch moves 1.5 MB: launch-latency bound"},
+        "breakdown_ms": {"rollout": t_roll * 1e3, "update": t_upd * 1e3,
+                         "hand_written_kernels_per_step": per_step},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

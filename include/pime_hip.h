@@ -1,0 +1,193 @@
+/*
+ * pime_hip.h -- C ABI of libpime_hip.so, the MI355X (gfx950) implementation of the vectorised
+ * set-point-control hot path.
+ *
+ * The reference (ruoqizzz/PIME-..., 100 % Python) has no FFI: its boundary for this path is the Python duck
+ * type consumed by elegantrl/env.py:PreprocessEnv and the agents.  Each entry point below names the reference
+ * interface it replaces (paths relative to the reference root); INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add to bind them.
+ *
+ * Conventions
+ *  - plain C types only; every buffer is caller-owned.  Pointers marked [dev] are device pointers on the
+ *    handle's device (e.g. torch tensor .data_ptr()), [host] are host pointers.
+ *  - every launch goes to the caller-supplied HIP stream (pime_stream = hipStream_t; pass torch's current
+ *    stream) and returns without synchronising, so calls are hipGraph-capturable.  Functions documented as
+ *    "synchronous" (field I/O, create/destroy) synchronise that stream themselves.
+ *  - return value: 0 = PIME_OK, negative = error class; pime_last_error() returns a thread-local message.
+ *    No C++ exception crosses the ABI.
+ *  - a handle is single-writer: one host thread, one stream at a time.  Different handles are independent.
+ *  - there is NO CPU fallback: without a usable gfx950 device pime_env_create() fails with PIME_ERR_DEVICE.
+ */
+#ifndef PIME_HIP_H
+#define PIME_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+
+#define PIME_ABI_VERSION 3
+
+typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
+typedef void* pime_stream;        /* hipStream_t */
+
+enum pime_status {
+    PIME_OK = 0,
+    PIME_ERR_ARG = -1,    /* bad argument / shape / enum */
+    PIME_ERR_DEVICE = -2, /* no usable gfx950 device, or HIP runtime error */
+    PIME_ERR_ALLOC = -3,
+    PIME_ERR_STATE = -4   /* call sequence error (e.g. step before reset) */
+};
+
+enum pime_kind { PIME_ENV_PH = 0, PIME_ENV_WT = 1 };
+/* PIME_STATE_F64: every state word float64 (reference precision).  PIME_STATE_MIXED: float32 state; the pH
+ * reaction-invariant x and the discretised plant (A,B,C) stay float64 so the LUT index is the reference's. */
+enum pime_state_mode { PIME_STATE_F64 = 0, PIME_STATE_MIXED = 1 };
+enum pime_reward { PIME_REWARD_DISTANCE = 0, PIME_REWARD_SQUARE = 1, PIME_REWARD_SPARSE = 2 };
+enum pime_dtype { PIME_F32 = 0, PIME_F64 = 1 };
+
+/* state fields for pime_env_read_field / pime_env_write_field */
+enum pime_field {
+    /* pH  (gym_control/envs/ph.py attributes: state, integrator, r, y, dsys.A/B/C, qww_V, qc_V, _episode_steps) */
+    PIME_PH_X = 0, PIME_PH_I = 1, PIME_PH_R = 2, PIME_PH_Y = 3, PIME_PH_A = 4, PIME_PH_B = 5, PIME_PH_C = 6,
+    PIME_PH_QWW_V = 7, PIME_PH_QC_V = 8, PIME_PH_T = 9, PIME_PH_EPISODE = 10,
+    /* water tank (nonlinear_watertank.py attributes: h1, h2, r, integrator, a1, a2, Kp, _episode_steps) */
+    PIME_WT_H1 = 32, PIME_WT_H2 = 33, PIME_WT_R = 34, PIME_WT_I = 35, PIME_WT_A1 = 36, PIME_WT_A2 = 37,
+    PIME_WT_KP = 38, PIME_WT_T = 39, PIME_WT_EPISODE = 40
+};
+
+/* Titration chemistry, gym_control/envs/ph.py:32-37 */
+typedef struct pime_ph_chem {
+    double kw, kchem, ka, MNaOH, MHA, MNH3;
+} pime_ph_chem;
+
+typedef struct pime_env_cfg {
+    int32_t kind;            /* pime_kind */
+    int32_t n_envs;          /* instances advanced per launch (this rank's slice) */
+    int32_t device_id;       /* HIP device ordinal */
+    int32_t state_mode;      /* pime_state_mode */
+    int32_t max_steps;       /* pH: gym TimeLimit (gym_control/__init__.py:6) ; WT: max_step (:55) */
+    int32_t reward_type;     /* pime_reward */
+    int32_t integral_bound;  /* 1: clip I to +-integral_max (ph.py:341, nonlinear_watertank.py:825); 0: _NoBound (ph.py:470) */
+    int32_t num_stack;       /* WT only. 0: Integrator obs [h1,h2,r,I]; S>=1: Stacking obs, 3*S floats (:1056-1208) */
+    int32_t resample_every;  /* n: redraw the ensemble params on every n-th reset; 0 = never (if_reset_all False) */
+    uint32_t env_offset;     /* global id of lane 0 (rank * n_envs under data-parallel sharding); Philox counter word */
+    uint64_t seed;           /* Philox key */
+    double integral_max, integral_punish, action_punish, action_change_punish, distance_threshold;
+    double range_lo[3], range_hi[3]; /* ensemble ranges: pH (qww_V, qc_V, -) ; WT (a1, a2, Kp) */
+    double init_lo[2], init_hi[2];   /* [0]: initial state range (pH x0 / WT h1,h2) ; [1]: goal r range */
+    /* pH plant */
+    double ph_sample_t, ph_u_low, ph_u_high, ph_table_scale; /* T=20 s; action map [0,1.5]; 1e5 = 1/MHCl step */
+    const double* ph_table;  /* [host] ph_table_len float64 entries (pime_ph_table_build); copied at create */
+    int32_t ph_table_len;
+    /* water-tank plant */
+    int32_t wt_n_discrete;
+    double wt_A1, wt_A2, wt_G, wt_dt, wt_noise_scale, wt_z1, wt_pmax;
+} pime_env_cfg;
+
+/* -- library --------------------------------------------------------------------------------------------- */
+int pime_abi_version(void);
+const char* pime_last_error(void);
+/* number of visible gfx950 devices (0 on a CPU-only host); never throws */
+int pime_device_count(void);
+
+/* -- titration LUT ----------------------------------------------------------------------------------------
+ * replaces: PH1D.__init__ table loop, gym_control/envs/ph.py:72-84 (13 s of Python per gym.make).
+ * Sequential warm-started Newton => host code, fp64, ~10 ms.  out: [host] n entries, entry i for
+ * MHCl = i * mhcl_step.  chem == NULL selects ph.py:32-37. */
+int pime_ph_table_build(const pime_ph_chem* chem, double mhcl_step, int32_t n, double* out);
+
+/* -- env handle -------------------------------------------------------------------------------------------
+ * pime_env_cfg_default fills the registered configuration of
+ *   kind PH: 'PH1DChangingParamUniformGoalIntegrator-SqaureDistance-v35' (gym_control/__init__.py:3-14)
+ *   kind WT: 'NonLinearWaterTankChangingParamUniformGoalIntegrator-SquareDistance-v2' (:50-69)
+ * (ph_table left NULL: the caller supplies it). */
+int pime_env_cfg_default(int32_t kind, pime_env_cfg* cfg);
+/* replaces: gym.make(id) -> env constructor (ph.py:353-407, nonlinear_watertank.py:830-888). synchronous. */
+pime_env* pime_env_create(const pime_env_cfg* cfg);
+void pime_env_destroy(pime_env* env);
+int32_t pime_env_obs_dim(const pime_env* env);
+int32_t pime_env_num_envs(const pime_env* env);
+/* number of float64 draws one reset consumes per lane: pH 4 (qww_V, qc_V, x0, r), WT 6 (a1, a2, Kp, h1, h2, r) */
+int32_t pime_env_reset_draw_width(const pime_env* env);
+
+/* replaces: env.reset() -> reset_all()/reset_r(), ph.py:412-445 ; nonlinear_watertank.py:902-939,1166-1208.
+ *   mask  [dev] uint8[N] or NULL (= all lanes)
+ *   draws [dev] float64[N, width] final values in the reference's draw order (seed-for-seed replay of the
+ *         MT19937 streams, generated host side) or NULL (= in-kernel Philox4x32-10)
+ *   obs   [dev] float32[N, obs_dim] written for the reset lanes (float32 = PreprocessEnv cast, env.py:46) */
+int pime_env_reset(pime_env* env, const uint8_t* mask, const double* draws, float* obs, pime_stream stream);
+
+/* replaces: PreprocessEnv.step_type -> TimeLimit.step -> env.step(action), ph.py:320-348,448-478 ;
+ * nonlinear_watertank.py:800-826,1118-1147.
+ *   action       [dev] N env actions, float32 or float64 (action_dtype = pime_dtype)
+ *   noise        [dev] WT: float64[N,2] already-scaled normals added to h1,h2 (:810-811) or NULL (= Philox)
+ *   auto_reset   1: a lane that reports done is reset in the same launch and its obs row is the first
+ *                observation of the next episode (vector-env convention; the reference calls reset() itself)
+ *   reset_draws  [dev] as pime_env_reset's draws, consumed only by lanes that auto-reset; or NULL
+ *   obs [dev] float32[N, obs_dim]; reward [dev] float32[N]; done [dev] uint8[N] */
+int pime_env_step(pime_env* env, const void* action, int32_t action_dtype, const double* noise,
+                  int32_t auto_reset, const double* reset_draws, float* obs, float* reward, uint8_t* done,
+                  pime_stream stream);
+
+/* The same step with the residual-policy action composition fused into the kernel prologue.
+ * replaces: elegantrl/agent_residual.py:61  env.step(np.tanh(action) + state @ self.priorK)
+ *   a_pre   [dev] float32[N] pre-tanh residual action (mean + sigma*eps)
+ *   obs_in  [dev] float32[N, obs_dim] the observation the policy saw
+ *   priorK  [host] float64[obs_dim] (= -env.K); copied into the launch arguments */
+int pime_env_step_residual(pime_env* env, const float* a_pre, const float* obs_in, const double* priorK,
+                           const double* noise, int32_t auto_reset, const double* reset_draws, float* obs,
+                           float* reward, uint8_t* done, pime_stream stream);
+
+/* replaces: attribute reads/writes on the env object (set_state/set_r/set_params/get_changable_parameters/
+ * reset_changable_parameters: ph.py:233-270, nonlinear_watertank.py:205-212,896-900).  synchronous.
+ *   out/in [host] float64[N]; mask [host] uint8[N] or NULL.  Writing PIME_PH_QWW_V / PIME_PH_QC_V rebuilds the
+ *   lane's ZOH plant (A,B,C) as update_system does (ph.py:114-121).  PIME_PH_Y is read-only. */
+int pime_env_read_field(pime_env* env, int32_t field, double* out, pime_stream stream);
+int pime_env_write_field(pime_env* env, int32_t field, const double* in, const uint8_t* mask, pime_stream stream);
+/* run-time changes the evaluation harness makes on a live env (utils/test.py:1062-1064, utils/robust_test.py:17) */
+int pime_env_set_punish(pime_env* env, double integral_punish, double action_punish, double action_change_punish);
+int pime_env_set_max_steps(pime_env* env, int32_t max_steps);
+int pime_env_set_resample_every(pime_env* env, int32_t n);
+/* writes the current observation of every lane (what _get_observe() returns) */
+int pime_env_observe(pime_env* env, float* obs, pime_stream stream);
+
+/* -- trajectory post-processing ---------------------------------------------------------------------------
+ * replaces: AgentPPO.compute_reward_gae / compute_reward_adv, elegantrl/agent.py:666-708 (a Python loop over
+ * device scalars).  Time-major [T, N] float32 buffers, one thread per lane, reverse scan over T.
+ * Outputs are un-normalised; the buffer-global (adv-mean)/(std+1e-5) stays with the caller (agent.py:707). */
+int pime_gae_scan(const float* reward, const float* mask, const float* value, int32_t T, int32_t N, float lambda,
+                  int32_t use_gae, float* r_sum, float* adv, pime_stream stream);
+
+/* -- batched MLP forwards on the f32 matrix cores -----------------------------------------------------------
+ * (v_mfma_f32_32x32x2_f32: exact float32, the reference's precision.)  Two steps so that the weight permutation
+ * is paid once per weight version, not once per call: pime_mlp_pack re-lays the nn.Linear tensors into the image
+ * the kernel keeps in LDS; pime_mlp_forward runs the whole net per 32-row tile with activations in registers.
+ *
+ *   kind PIME_MLP_CRITIC         replaces CriticAdv.forward over the buffer, elegantrl/agent.py:619-620 with
+ *                                net.py:274-277 (D -> md ReLU -> md ReLU -> md ReLU -> 1)
+ *                                params[8]  = net.0 W,b ; net.2 W,b ; net.4 W,b ; net.6 W,b
+ *   kind PIME_MLP_PLAIN_ACTOR    replaces ActorResidualPPO / ActorPPO mean, net_residual.py:19-22,45-48
+ *                                (same shape, Tanh); params[8] as above
+ *   kind PIME_MLP_MODULAR_ACTOR  replaces ActorResidualIntegratorModularPPO mean, net_residual.py:153-160,172-176
+ *                                params[12] = other_net.0 W,b ; other_net.2 W,b ; integrator_net.0 W,b ;
+ *                                integrator_net.2 W,b ; net.0 W,b ; net.2 W,b ; Di = integrator_dim (trailing
+ *                                columns of x)
+ * All weights are [dev] float32 in nn.Linear layout ([out, in] row-major).  md must be 64 or 128 (the image must
+ * fit the 160 KB LDS), D <= 32.  out [dev] float32[M] is the scalar head (value, or pre-tanh action mean without
+ * noise and prior term). */
+enum pime_mlp_kind { PIME_MLP_CRITIC = 0, PIME_MLP_PLAIN_ACTOR = 1, PIME_MLP_MODULAR_ACTOR = 2 };
+/* floats in the packed image (0 and an error message if the shape is unsupported) */
+int64_t pime_mlp_packed_floats(int32_t kind, int32_t D, int32_t Di, int32_t md);
+int pime_mlp_pack(int32_t kind, int32_t D, int32_t Di, int32_t md, const float* const* params, float* packed,
+                  pime_stream stream);
+int pime_mlp_forward(int32_t kind, const float* x, int32_t M, int32_t D, int32_t Di, int32_t md, const float* packed,
+                     float* out, pime_stream stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIME_HIP_H */

@@ -107,8 +107,8 @@ class OraclePH:
                                                     env_offset))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().oracle_ph_destroy(self._h)
+        if getattr(self, "_h", None) and lib is not None and _lib is not None:
+            _lib.oracle_ph_destroy(self._h)
             self._h = None
 
     def set_punish(self, integral=0.0, action=0.0, action_change=0.0):
@@ -153,8 +153,8 @@ class OracleWT:
         self.obs_dim = lib().oracle_wt_obs_dim(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().oracle_wt_destroy(self._h)
+        if getattr(self, "_h", None) and lib is not None and _lib is not None:
+            _lib.oracle_wt_destroy(self._h)
             self._h = None
 
     def set_punish(self, integral=0.0):

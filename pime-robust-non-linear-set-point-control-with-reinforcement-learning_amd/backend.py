@@ -1,0 +1,33 @@
+"""Compute backend of the agents' non-autograd hot ops (value pass, policy mean for rollouts, GAE scan).
+
+The product ships exactly one backend, `HipBackend`, which drives libpime_hip.so and refuses CPU tensors.
+The agents take the backend as a constructor argument only so that the *tests* can inject the CPU oracle
+(tests/oracle_backend.py) to exercise the host-side update logic in a GPU-less container and under gloo;
+nothing in this package constructs any other backend, and there is no automatic selection or fallback.
+"""
+import torch
+
+from . import native, ops
+
+
+class HipBackend:
+    name = "hip"
+
+    def check_device(self, device):
+        if torch.device(device).type != "cuda":
+            raise native.PimeError("pime_amd agents run their rollout/GAE/value-pass on a gfx950 GPU; "
+                                   f"device '{device}' has no implementation (no CPU fallback)")
+
+    def gae(self, reward, mask, value, lam, use_gae):
+        return ops.gae_scan(reward, mask, value, lam, use_gae)
+
+    def packed(self, module):
+        """PackedMLP for `module` if the fused kernel supports its shape, else None (-> plain torch forward on
+        the GPU, i.e. rocBLAS; still not a CPU path)."""
+        kind = getattr(module, "packed_kind", None)
+        if kind is None or getattr(module, "action_dim", 1) != 1:
+            return None
+        md = module.net[0].out_features if kind != "modular_actor" else module.other_net[0].out_features
+        if not ops.PackedMLP.supported(kind, module.state_dim, getattr(module, "integrator_dim", 0), md):
+            return None
+        return ops.PackedMLP.from_module(module)

@@ -1,0 +1,528 @@
+// C ABI of libpime_hip.so (include/pime_hip.h): handle management, argument checks, field I/O, launch dispatch.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "env_state.hpp"
+
+namespace pime {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// launchers defined in env_kernels.hip / gae_scan.hip / mlp_mfma.hip
+template <typename S> int launch_ph_reset(const PhParams&, const PhPtrs<S>&, const uint8_t*, const double*, float*, hipStream_t);
+template <typename S> int launch_ph_step(const PhParams&, const PhPtrs<S>&, const void*, int, bool, const float*, const PriorK&,
+                                         const double*, float*, float*, uint8_t*, hipStream_t);
+template <typename S> int launch_ph_observe(const PhParams&, const PhPtrs<S>&, float*, hipStream_t);
+template <typename S> int launch_wt_reset(const WtParams&, const WtPtrs<S>&, const uint8_t*, const double*, float*, hipStream_t);
+template <typename S> int launch_wt_step(const WtParams&, const WtPtrs<S>&, const void*, int, bool, const float*, const PriorK&,
+                                         const double*, const double*, float*, float*, uint8_t*, hipStream_t);
+template <typename S> int launch_wt_observe(const WtParams&, const WtPtrs<S>&, float*, hipStream_t);
+int launch_gae_scan(const float*, const float*, const float*, int, int, float, int, float*, float*, hipStream_t);
+int64_t mlp_packed_floats(int, int, int, int);
+int mlp_check(int, int, int, int);
+int launch_mlp_pack(int, int, int, int, const float* const*, float*, hipStream_t);
+int launch_mlp_forward(int, const float*, int, int, int, int, const float*, float*, hipStream_t);
+
+}  // namespace pime
+
+using namespace pime;
+
+// One slab of HBM per handle; SoA arrays are carved from it at 256-B boundaries.
+struct pime_env {
+    pime_env_cfg cfg;
+    int obs_dim = 0;
+    bool was_reset = false;
+    void* slab = nullptr;
+    size_t slab_bytes = 0;
+    std::vector<double> table_host;  // pH: for PIME_PH_Y reads
+    PhParams ph{};
+    WtParams wt{};
+    PhPtrs<double> ph64{};
+    PhPtrs<float> ph32{};
+    WtPtrs<double> wt64{};
+    WtPtrs<float> wt32{};
+};
+
+namespace {
+
+struct Carver {
+    size_t off = 0;
+    char* base = nullptr;
+    template <typename T>
+    T* take(size_t count) {
+        off = (off + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+template <typename S>
+void carve_ph(Carver& c, PhPtrs<S>& p, int n, int table_len, S** table_out) {
+    p.x = c.take<double>(n); p.A = c.take<double>(n); p.B = c.take<double>(n); p.C = c.take<double>(n);
+    p.qww = c.take<double>(n); p.qc = c.take<double>(n);
+    p.I = c.take<S>(n); p.r = c.take<S>(n); p.last_a = c.take<S>(n);
+    p.t = c.take<int32_t>(n); p.episode = c.take<int32_t>(n);
+    *table_out = c.take<S>(table_len);
+    p.table = *table_out;
+}
+
+template <typename S>
+void carve_wt(Carver& c, WtPtrs<S>& p, int n, int obs_dim, int num_stack) {
+    p.h1 = c.take<S>(n); p.h2 = c.take<S>(n); p.r = c.take<S>(n); p.I = c.take<S>(n);
+    p.a1 = c.take<S>(n); p.a2 = c.take<S>(n); p.kp = c.take<S>(n);
+    p.frames = num_stack > 0 ? c.take<S>((size_t)n * obs_dim) : nullptr;
+    p.t = c.take<int32_t>(n); p.episode = c.take<int32_t>(n);
+}
+
+int check_cfg(const pime_env_cfg* c) {
+    PIME_REQUIRE(c != nullptr, "cfg is NULL");
+    PIME_REQUIRE(c->kind == PIME_ENV_PH || c->kind == PIME_ENV_WT, "unknown env kind %d", c->kind);
+    PIME_REQUIRE(c->n_envs >= 1, "n_envs = %d", c->n_envs);
+    PIME_REQUIRE(c->state_mode == PIME_STATE_F64 || c->state_mode == PIME_STATE_MIXED, "unknown state_mode %d", c->state_mode);
+    PIME_REQUIRE(c->reward_type >= PIME_REWARD_DISTANCE && c->reward_type <= PIME_REWARD_SPARSE, "unknown reward_type %d",
+                 c->reward_type);
+    PIME_REQUIRE(c->max_steps >= 1, "max_steps = %d", c->max_steps);
+    PIME_REQUIRE(c->resample_every >= 0, "resample_every = %d", c->resample_every);
+    if (c->kind == PIME_ENV_PH) {
+        PIME_REQUIRE(c->ph_table != nullptr && c->ph_table_len >= 2, "pH env needs the titration table (pime_ph_table_build)");
+        PIME_REQUIRE(c->num_stack == 0, "num_stack applies to the water-tank env only");
+    } else {
+        PIME_REQUIRE(c->num_stack >= 0 && 3 * c->num_stack <= kMaxObsDim, "num_stack = %d out of range", c->num_stack);
+        PIME_REQUIRE(c->wt_n_discrete >= 1, "wt_n_discrete = %d", c->wt_n_discrete);
+    }
+    return PIME_OK;
+}
+
+void fill_params(pime_env* e) {
+    const pime_env_cfg& c = e->cfg;
+    if (c.kind == PIME_ENV_PH) {
+        PhParams& p = e->ph;
+        p.n = c.n_envs; p.max_steps = c.max_steps; p.reward_type = c.reward_type; p.integral_bound = c.integral_bound;
+        p.resample_every = c.resample_every; p.table_len = c.ph_table_len; p.auto_reset = 0;
+        p.has_punish = (c.integral_punish != 0.0 || c.action_punish != 0.0 || c.action_change_punish != 0.0);
+        p.env_offset = c.env_offset; p.seed = c.seed;
+        p.integral_max = c.integral_max; p.integral_punish = c.integral_punish; p.action_punish = c.action_punish;
+        p.action_change_punish = c.action_change_punish; p.thr = c.distance_threshold;
+        p.sample_t = c.ph_sample_t; p.u_low = c.ph_u_low; p.u_high = c.ph_u_high; p.table_scale = c.ph_table_scale;
+        p.qww_lo = c.range_lo[0]; p.qww_hi = c.range_hi[0]; p.qc_lo = c.range_lo[1]; p.qc_hi = c.range_hi[1];
+        p.x0_lo = c.init_lo[0]; p.x0_hi = c.init_hi[0]; p.r_lo = c.init_lo[1]; p.r_hi = c.init_hi[1];
+    } else {
+        WtParams& p = e->wt;
+        p.n = c.n_envs; p.max_steps = c.max_steps; p.reward_type = c.reward_type; p.num_stack = c.num_stack;
+        p.resample_every = c.resample_every; p.n_discrete = c.wt_n_discrete; p.auto_reset = 0; p.obs_dim = e->obs_dim;
+        p.env_offset = c.env_offset; p.seed = c.seed;
+        p.integral_max = c.integral_max; p.integral_punish = c.integral_punish; p.thr = c.distance_threshold;
+        p.A1 = c.wt_A1; p.A2 = c.wt_A2; p.G = c.wt_G; p.dt = c.wt_dt; p.noise_scale = c.wt_noise_scale; p.z1 = c.wt_z1;
+        p.pmax = c.wt_pmax;
+        p.a1_lo = c.range_lo[0]; p.a1_hi = c.range_hi[0]; p.a2_lo = c.range_lo[1]; p.a2_hi = c.range_hi[1];
+        p.kp_lo = c.range_lo[2]; p.kp_hi = c.range_hi[2];
+        p.h_lo = c.init_lo[0]; p.h_hi = c.init_hi[0]; p.r_lo = c.init_lo[1]; p.r_hi = c.init_hi[1];
+    }
+}
+
+int use_device(const pime_env* e) {
+    PIME_HIP_TRY(hipSetDevice(e->cfg.device_id));
+    return PIME_OK;
+}
+
+// device array <-> host double conversions for field I/O
+struct FieldRef {
+    void* ptr = nullptr;
+    int type = 0;  // 0 double, 1 float, 2 int32
+    bool ph_params = false, read_only = false, is_y = false;
+};
+
+int resolve_field(pime_env* e, int field, FieldRef* out) {
+    const bool f64 = e->cfg.state_mode == PIME_STATE_F64;
+    FieldRef r;
+#define SPTR(member) (f64 ? (void*)e->ph64.member : (void*)e->ph32.member)
+#define WPTR(member) (f64 ? (void*)e->wt64.member : (void*)e->wt32.member)
+    const int st = f64 ? 0 : 1;
+    if (e->cfg.kind == PIME_ENV_PH) {
+        switch (field) {
+            case PIME_PH_X: r = {e->ph64.x, 0}; break;
+            case PIME_PH_I: r = {SPTR(I), st}; break;
+            case PIME_PH_R: r = {SPTR(r), st}; break;
+            case PIME_PH_Y: r = {nullptr, 0, false, true, true}; break;
+            case PIME_PH_A: r = {e->ph64.A, 0}; break;
+            case PIME_PH_B: r = {e->ph64.B, 0}; break;
+            case PIME_PH_C: r = {e->ph64.C, 0}; break;
+            case PIME_PH_QWW_V: r = {e->ph64.qww, 0, true}; break;
+            case PIME_PH_QC_V: r = {e->ph64.qc, 0, true}; break;
+            case PIME_PH_T: r = {e->ph64.t, 2}; break;
+            case PIME_PH_EPISODE: r = {e->ph64.episode, 2}; break;
+            default: set_error("field %d is not a pH field", field); return PIME_ERR_ARG;
+        }
+    } else {
+        switch (field) {
+            case PIME_WT_H1: r = {WPTR(h1), st}; break;
+            case PIME_WT_H2: r = {WPTR(h2), st}; break;
+            case PIME_WT_R: r = {WPTR(r), st}; break;
+            case PIME_WT_I:
+                if (e->cfg.num_stack > 0) { set_error("the Stacking variant has no integrator"); return PIME_ERR_ARG; }
+                r = {WPTR(I), st}; break;
+            case PIME_WT_A1: r = {WPTR(a1), st}; break;
+            case PIME_WT_A2: r = {WPTR(a2), st}; break;
+            case PIME_WT_KP: r = {WPTR(kp), st}; break;
+            case PIME_WT_T: r = {e->wt64.t, 2}; break;
+            case PIME_WT_EPISODE: r = {e->wt64.episode, 2}; break;
+            default: set_error("field %d is not a water-tank field", field); return PIME_ERR_ARG;
+        }
+    }
+#undef SPTR
+#undef WPTR
+    *out = r;
+    return PIME_OK;
+}
+
+int d2h_as_double(const FieldRef& f, int n, double* out, hipStream_t s) {
+    if (f.type == 0) {
+        PIME_HIP_TRY(hipMemcpyAsync(out, f.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        PIME_HIP_TRY(hipStreamSynchronize(s));
+    } else if (f.type == 1) {
+        std::vector<float> tmp(n);
+        PIME_HIP_TRY(hipMemcpyAsync(tmp.data(), f.ptr, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+        PIME_HIP_TRY(hipStreamSynchronize(s));
+        for (int i = 0; i < n; ++i) out[i] = tmp[i];
+    } else {
+        std::vector<int32_t> tmp(n);
+        PIME_HIP_TRY(hipMemcpyAsync(tmp.data(), f.ptr, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+        PIME_HIP_TRY(hipStreamSynchronize(s));
+        for (int i = 0; i < n; ++i) out[i] = tmp[i];
+    }
+    return PIME_OK;
+}
+
+int h2d_from_double(const FieldRef& f, int n, const double* in, hipStream_t s) {
+    if (f.type == 0) {
+        PIME_HIP_TRY(hipMemcpyAsync(f.ptr, in, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        PIME_HIP_TRY(hipStreamSynchronize(s));
+    } else if (f.type == 1) {
+        std::vector<float> tmp(n);
+        for (int i = 0; i < n; ++i) tmp[i] = (float)in[i];
+        PIME_HIP_TRY(hipMemcpyAsync(f.ptr, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice, s));
+        PIME_HIP_TRY(hipStreamSynchronize(s));
+    } else {
+        std::vector<int32_t> tmp(n);
+        for (int i = 0; i < n; ++i) tmp[i] = (int32_t)in[i];
+        PIME_HIP_TRY(hipMemcpyAsync(f.ptr, tmp.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+        PIME_HIP_TRY(hipStreamSynchronize(s));
+    }
+    return PIME_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pime_abi_version(void) { return PIME_ABI_VERSION; }
+const char* pime_last_error(void) { return g_err; }
+
+int pime_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int pime_env_cfg_default(int32_t kind, pime_env_cfg* c) {
+    PIME_REQUIRE(c != nullptr, "cfg is NULL");
+    std::memset(c, 0, sizeof(*c));
+    c->kind = kind;
+    c->n_envs = 1;
+    c->state_mode = PIME_STATE_F64;
+    c->integral_bound = 1;
+    c->resample_every = 1;       // the reference resamples on every reset (ph.py:413, nonlinear_watertank.py:903)
+    c->integral_max = 25.0;      // ph.py:299, nonlinear_watertank.py:732
+    c->distance_threshold = 0.05;
+    if (kind == PIME_ENV_PH) {   // gym_control/__init__.py:3-14
+        c->max_steps = 50;
+        c->reward_type = PIME_REWARD_SQUARE;
+        c->range_lo[0] = 0.005; c->range_hi[0] = 0.015;    // qww_V, ph.py:357
+        c->range_lo[1] = 0.0015; c->range_hi[1] = 0.0025;  // qc_V, ph.py:358
+        c->init_lo[0] = 0.0; c->init_hi[0] = 50.0;         // x0, ph.py:420
+        c->init_lo[1] = 3.0; c->init_hi[1] = 11.0;         // r, ph.py:424
+        c->ph_sample_t = 20.0; c->ph_u_low = 0.0; c->ph_u_high = 1.5; c->ph_table_scale = 1e5;
+    } else if (kind == PIME_ENV_WT) {  // gym_control/__init__.py:50-69
+        c->max_steps = 200;
+        c->reward_type = PIME_REWARD_SQUARE;
+        c->range_lo[0] = 0.0015; c->range_hi[0] = 0.0024;
+        c->range_lo[1] = 0.0015; c->range_hi[1] = 0.0024;
+        c->range_lo[2] = 0.07; c->range_hi[2] = 0.17;
+        c->init_lo[0] = 0.0; c->init_hi[0] = 10.0;         // h1,h2: nonlinear_watertank.py:912
+        c->init_lo[1] = 0.0; c->init_hi[1] = 10.0;         // r: :913
+        c->wt_A1 = 1; c->wt_A2 = 1; c->wt_G = 980; c->wt_n_discrete = 20; c->wt_dt = 2.0 / 20;
+        c->wt_noise_scale = 0.01; c->wt_z1 = 1; c->wt_pmax = 10.0;
+    } else {
+        set_error("unknown env kind %d", kind);
+        return PIME_ERR_ARG;
+    }
+    return PIME_OK;
+}
+
+pime_env* pime_env_create(const pime_env_cfg* cfg) {
+    if (check_cfg(cfg) != PIME_OK) return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible: libpime_hip has no CPU fallback");
+        return nullptr;
+    }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) {
+        set_error("device_id %d out of range [0,%d)", cfg->device_id, ndev);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is '%s'; libpime_hip is built for gfx950 only", cfg->device_id, prop.gcnArchName);
+        return nullptr;
+    }
+    pime_env* e = new (std::nothrow) pime_env();
+    if (!e) { set_error("out of host memory"); return nullptr; }
+    e->cfg = *cfg;
+    e->cfg.ph_table = nullptr;  // never keep the caller's pointer
+    const int n = cfg->n_envs;
+    const bool f64 = cfg->state_mode == PIME_STATE_F64;
+    e->obs_dim = cfg->kind == PIME_ENV_PH ? 3 : (cfg->num_stack > 0 ? 3 * cfg->num_stack : 4);
+    void* table_dev = nullptr;
+    for (int pass = 0; pass < 2; ++pass) {  // pass 0 sizes the slab, pass 1 carves it
+        Carver c;
+        c.base = pass ? static_cast<char*>(e->slab) : nullptr;
+        if (cfg->kind == PIME_ENV_PH) {
+            if (f64) { double* t; carve_ph(c, e->ph64, n, cfg->ph_table_len, &t); table_dev = t; }
+            else {
+                float* t; carve_ph(c, e->ph32, n, cfg->ph_table_len, &t); table_dev = t;
+                // shared float64 arrays are addressed through ph64 by the field accessors
+                e->ph64.x = e->ph32.x; e->ph64.A = e->ph32.A; e->ph64.B = e->ph32.B; e->ph64.C = e->ph32.C;
+                e->ph64.qww = e->ph32.qww; e->ph64.qc = e->ph32.qc; e->ph64.t = e->ph32.t; e->ph64.episode = e->ph32.episode;
+            }
+        } else {
+            if (f64) carve_wt(c, e->wt64, n, e->obs_dim, cfg->num_stack);
+            else { carve_wt(c, e->wt32, n, e->obs_dim, cfg->num_stack); e->wt64.t = e->wt32.t; e->wt64.episode = e->wt32.episode; }
+        }
+        if (pass == 0) {
+            e->slab_bytes = (c.off + 255) & ~size_t(255);
+            if (hipSetDevice(cfg->device_id) != hipSuccess || hipMalloc(&e->slab, e->slab_bytes) != hipSuccess) {
+                set_error("hipMalloc of %zu B env state failed: %s", e->slab_bytes, hipGetErrorString(hipGetLastError()));
+                delete e;
+                return nullptr;
+            }
+        }
+    }
+    bool ok = hipMemset(e->slab, 0, e->slab_bytes) == hipSuccess;
+    // episode counters start at -1 so that the first reset is episode 0 (and resamples)
+    std::vector<int32_t> minus1(n, -1);
+    int32_t* ep = cfg->kind == PIME_ENV_PH ? e->ph64.episode : e->wt64.episode;
+    ok = ok && hipMemcpy(ep, minus1.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice) == hipSuccess;
+    if (cfg->kind == PIME_ENV_PH) {
+        e->table_host.assign(cfg->ph_table, cfg->ph_table + cfg->ph_table_len);
+        if (f64) {
+            ok = ok && hipMemcpy(table_dev, e->table_host.data(), sizeof(double) * cfg->ph_table_len, hipMemcpyHostToDevice) == hipSuccess;
+        } else {
+            std::vector<float> t32(e->table_host.begin(), e->table_host.end());
+            ok = ok && hipMemcpy(table_dev, t32.data(), sizeof(float) * cfg->ph_table_len, hipMemcpyHostToDevice) == hipSuccess;
+        }
+    }
+    if (!ok) {
+        set_error("initialising env state failed: %s", hipGetErrorString(hipGetLastError()));
+        (void)hipFree(e->slab);
+        delete e;
+        return nullptr;
+    }
+    fill_params(e);
+    return e;
+}
+
+void pime_env_destroy(pime_env* e) {
+    if (!e) return;
+    if (e->slab) {
+        (void)hipSetDevice(e->cfg.device_id);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(e->slab);
+    }
+    delete e;
+}
+
+int32_t pime_env_obs_dim(const pime_env* e) { return e ? e->obs_dim : 0; }
+int32_t pime_env_num_envs(const pime_env* e) { return e ? e->cfg.n_envs : 0; }
+int32_t pime_env_reset_draw_width(const pime_env* e) { return e ? (e->cfg.kind == PIME_ENV_PH ? 4 : 6) : 0; }
+
+int pime_env_reset(pime_env* e, const uint8_t* mask, const double* draws, float* obs, pime_stream stream) {
+    PIME_REQUIRE(e != nullptr && obs != nullptr, "pime_env_reset: NULL handle or obs");
+    if (int rc = use_device(e)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    e->was_reset = true;
+    const bool f64 = e->cfg.state_mode == PIME_STATE_F64;
+    if (e->cfg.kind == PIME_ENV_PH)
+        return f64 ? launch_ph_reset(e->ph, e->ph64, mask, draws, obs, s) : launch_ph_reset(e->ph, e->ph32, mask, draws, obs, s);
+    return f64 ? launch_wt_reset(e->wt, e->wt64, mask, draws, obs, s) : launch_wt_reset(e->wt, e->wt32, mask, draws, obs, s);
+}
+
+static int step_common(pime_env* e, const void* act, int act_dtype, bool residual, const float* obs_in, const double* priorK,
+                       const double* noise, int auto_reset, const double* reset_draws, float* obs, float* reward, uint8_t* done,
+                       pime_stream stream) {
+    PIME_REQUIRE(e != nullptr, "NULL env handle");
+    PIME_REQUIRE(act && obs && reward && done, "pime_env_step: NULL action/obs/reward/done");
+    PIME_REQUIRE(act_dtype == PIME_F32 || act_dtype == PIME_F64, "action_dtype %d", act_dtype);
+    if (!e->was_reset) { set_error("pime_env_step before pime_env_reset"); return PIME_ERR_STATE; }
+    PriorK K{};
+    if (residual) {
+        PIME_REQUIRE(obs_in != nullptr && priorK != nullptr, "pime_env_step_residual: NULL obs_in/priorK");
+        for (int j = 0; j < e->obs_dim; ++j) K.k[j] = priorK[j];
+    }
+    if (int rc = use_device(e)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool f64 = e->cfg.state_mode == PIME_STATE_F64;
+    if (e->cfg.kind == PIME_ENV_PH) {
+        PIME_REQUIRE(noise == nullptr, "the pH env has no process noise input");
+        PhParams p = e->ph;
+        p.auto_reset = auto_reset ? 1 : 0;
+        return f64 ? launch_ph_step(p, e->ph64, act, act_dtype, residual, obs_in, K, reset_draws, obs, reward, done, s)
+                   : launch_ph_step(p, e->ph32, act, act_dtype, residual, obs_in, K, reset_draws, obs, reward, done, s);
+    }
+    WtParams p = e->wt;
+    p.auto_reset = auto_reset ? 1 : 0;
+    return f64 ? launch_wt_step(p, e->wt64, act, act_dtype, residual, obs_in, K, noise, reset_draws, obs, reward, done, s)
+               : launch_wt_step(p, e->wt32, act, act_dtype, residual, obs_in, K, noise, reset_draws, obs, reward, done, s);
+}
+
+int pime_env_step(pime_env* e, const void* action, int32_t action_dtype, const double* noise, int32_t auto_reset,
+                  const double* reset_draws, float* obs, float* reward, uint8_t* done, pime_stream stream) {
+    return step_common(e, action, action_dtype, false, nullptr, nullptr, noise, auto_reset, reset_draws, obs, reward, done, stream);
+}
+
+int pime_env_step_residual(pime_env* e, const float* a_pre, const float* obs_in, const double* priorK, const double* noise,
+                           int32_t auto_reset, const double* reset_draws, float* obs, float* reward, uint8_t* done,
+                           pime_stream stream) {
+    return step_common(e, a_pre, PIME_F32, true, obs_in, priorK, noise, auto_reset, reset_draws, obs, reward, done, stream);
+}
+
+int pime_env_observe(pime_env* e, float* obs, pime_stream stream) {
+    PIME_REQUIRE(e != nullptr && obs != nullptr, "pime_env_observe: NULL handle or obs");
+    if (int rc = use_device(e)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool f64 = e->cfg.state_mode == PIME_STATE_F64;
+    if (e->cfg.kind == PIME_ENV_PH) return f64 ? launch_ph_observe(e->ph, e->ph64, obs, s) : launch_ph_observe(e->ph, e->ph32, obs, s);
+    return f64 ? launch_wt_observe(e->wt, e->wt64, obs, s) : launch_wt_observe(e->wt, e->wt32, obs, s);
+}
+
+int pime_env_read_field(pime_env* e, int32_t field, double* out, pime_stream stream) {
+    PIME_REQUIRE(e != nullptr && out != nullptr, "pime_env_read_field: NULL handle or out");
+    if (int rc = use_device(e)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FieldRef f;
+    if (int rc = resolve_field(e, field, &f)) return rc;
+    const int n = e->cfg.n_envs;
+    if (f.is_y) {  // y = pH_table[rint(C*x*1e5)], ph.py:187-189, from the float64 host copy of the table
+        std::vector<double> x(n), C(n);
+        FieldRef fx{e->ph64.x, 0}, fc{e->ph64.C, 0};
+        if (int rc = d2h_as_double(fx, n, x.data(), s)) return rc;
+        if (int rc = d2h_as_double(fc, n, C.data(), s)) return rc;
+        for (int i = 0; i < n; ++i) {
+            long long k = std::llrint(C[i] * x[i] * e->cfg.ph_table_scale);
+            k = k < 0 ? 0 : (k >= e->cfg.ph_table_len ? e->cfg.ph_table_len - 1 : k);
+            out[i] = e->table_host[(size_t)k];
+        }
+        return PIME_OK;
+    }
+    return d2h_as_double(f, n, out, s);
+}
+
+int pime_env_write_field(pime_env* e, int32_t field, const double* in, const uint8_t* mask, pime_stream stream) {
+    PIME_REQUIRE(e != nullptr && in != nullptr, "pime_env_write_field: NULL handle or in");
+    if (int rc = use_device(e)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FieldRef f;
+    if (int rc = resolve_field(e, field, &f)) return rc;
+    PIME_REQUIRE(!f.read_only, "field %d is read-only", field);
+    const int n = e->cfg.n_envs;
+    std::vector<double> v(n);
+    if (mask) {
+        if (int rc = d2h_as_double(f, n, v.data(), s)) return rc;
+        for (int i = 0; i < n; ++i) if (mask[i]) v[i] = in[i];
+    } else {
+        std::memcpy(v.data(), in, sizeof(double) * n);
+    }
+    if (int rc = h2d_from_double(f, n, v.data(), s)) return rc;
+    if (f.ph_params) {  // update_system (ph.py:114-121): rebuild the ZOH plant of every lane from (qww_V, qc_V)
+        std::vector<double> qww(n), qc(n), A(n), B(n);
+        FieldRef fq{e->ph64.qww, 0}, fc{e->ph64.qc, 0}, fA{e->ph64.A, 0}, fB{e->ph64.B, 0}, fC{e->ph64.C, 0};
+        if (int rc = d2h_as_double(fq, n, qww.data(), s)) return rc;
+        if (int rc = d2h_as_double(fc, n, qc.data(), s)) return rc;
+        for (int i = 0; i < n; ++i) {
+            const double ex = -qww[i] * e->cfg.ph_sample_t;
+            A[i] = std::exp(ex);
+            B[i] = qww[i] != 0.0 ? -std::expm1(ex) / qww[i] : e->cfg.ph_sample_t;
+        }
+        if (int rc = h2d_from_double(fA, n, A.data(), s)) return rc;
+        if (int rc = h2d_from_double(fB, n, B.data(), s)) return rc;
+        if (int rc = h2d_from_double(fC, n, qc.data(), s)) return rc;
+    }
+    return PIME_OK;
+}
+
+int pime_env_set_punish(pime_env* e, double integral_punish, double action_punish, double action_change_punish) {
+    PIME_REQUIRE(e != nullptr, "NULL env handle");
+    e->cfg.integral_punish = integral_punish;
+    e->cfg.action_punish = action_punish;
+    e->cfg.action_change_punish = action_change_punish;
+    fill_params(e);
+    return PIME_OK;
+}
+
+int pime_env_set_max_steps(pime_env* e, int32_t max_steps) {
+    PIME_REQUIRE(e != nullptr && max_steps >= 1, "pime_env_set_max_steps: bad arguments");
+    e->cfg.max_steps = max_steps;
+    fill_params(e);
+    return PIME_OK;
+}
+
+int pime_env_set_resample_every(pime_env* e, int32_t n) {
+    PIME_REQUIRE(e != nullptr && n >= 0, "pime_env_set_resample_every: bad arguments");
+    e->cfg.resample_every = n;
+    fill_params(e);
+    return PIME_OK;
+}
+
+int pime_gae_scan(const float* reward, const float* mask, const float* value, int32_t T, int32_t N, float lambda,
+                  int32_t use_gae, float* r_sum, float* adv, pime_stream stream) {
+    PIME_REQUIRE(reward && mask && value && r_sum && adv, "pime_gae_scan: NULL buffer");
+    PIME_REQUIRE(T >= 1 && N >= 1, "pime_gae_scan: T=%d N=%d", T, N);
+    return launch_gae_scan(reward, mask, value, T, N, lambda, use_gae, r_sum, adv, static_cast<hipStream_t>(stream));
+}
+
+int64_t pime_mlp_packed_floats(int32_t kind, int32_t D, int32_t Di, int32_t md) {
+    if (mlp_check(kind, D, Di, md) != PIME_OK) return 0;
+    return mlp_packed_floats(kind, D, Di, md);
+}
+
+int pime_mlp_pack(int32_t kind, int32_t D, int32_t Di, int32_t md, const float* const* params, float* packed,
+                  pime_stream stream) {
+    PIME_REQUIRE(params != nullptr && packed != nullptr, "pime_mlp_pack: NULL params/packed");
+    return launch_mlp_pack(kind, D, Di, md, params, packed, static_cast<hipStream_t>(stream));
+}
+
+int pime_mlp_forward(int32_t kind, const float* x, int32_t M, int32_t D, int32_t Di, int32_t md, const float* packed,
+                     float* out, pime_stream stream) {
+    PIME_REQUIRE(x != nullptr && packed != nullptr && out != nullptr, "pime_mlp_forward: NULL x/packed/out");
+    return launch_mlp_forward(kind, x, M, D, Di, md, packed, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,384 @@
+// HIP kernels for the vectorised pH-neutralisation and two-tank water-level envs (gfx950).
+//
+// One thread advances one env instance; state is SoA in HBM so every load/store of a wave is one
+// contiguous 256-B (f32) or 512-B (f64) segment.  Both kernels are HBM/latency bound (76 B and
+// 84-112 B of algorithmic traffic per env-step); the only non-streaming access is the 4/8-B titration-LUT
+// gather, which is served by the XCD L2 (the reachable part of the table is 300-600 KB).
+//
+// Reference semantics (file:line under /root/reference):
+//   pH step   gym_control/envs/ph.py:320-348 (+ :155-159 action map, :187-189 LUT, :202-225 reward), NoBound :448-478,
+//             TimeLimit from gym_control/__init__.py:6
+//   pH reset  ph.py:409-445, ZOH :114-121
+//   WT step   gym_control/envs/nonlinear_watertank.py:800-826 (+ :258-260, :271-272, :484-514), Stacking :1118-1147
+//   WT reset  :890-939, :1166-1208
+//   residual  elegantrl/agent_residual.py:61
+#include "env_state.hpp"
+
+namespace pime {
+
+template <typename T>
+__device__ __forceinline__ T clip(T v, T lo, T hi) {  // np.clip = minimum(maximum(v, lo), hi)
+    const T m = v > lo ? v : lo;
+    return m < hi ? m : hi;
+}
+
+template <typename S>
+__device__ __forceinline__ S reward_of(int reward_type, S achieved, S goal, S thr) {
+    const S d = fabs(achieved - goal);
+    if (reward_type == PIME_REWARD_DISTANCE) return -d;
+    if (reward_type == PIME_REWARD_SQUARE) return -(d * d);
+    return d > thr ? S(-1) : S(-0.0);
+}
+
+// ============================================================================================ pH
+template <typename S>
+__device__ __forceinline__ S ph_lookup(const PhParams& p, const S* __restrict__ table, double C, double x) {
+    // observe_state (ph.py:187-189): first i with MHCl[i] >= around(C*x, 5)  ==  rint(C*x*1e5)  
+    long long k = __double2ll_rn(C * x * p.table_scale);  // round-half-even like np.around
+    k = k < 0 ? 0 : (k >= p.table_len ? p.table_len - 1 : k);  // reference: IndexError (unreachable in range)
+    return table[k];
+}
+
+template <typename S>
+__device__ __forceinline__ void ph_reset_lane(const PhParams& p, const PhPtrs<S>& st, int i,
+                                              const double* __restrict__ draws, float* __restrict__ obs) {
+    const int ep = st.episode[i] + 1;
+    st.episode[i] = ep;
+    const bool resample = p.resample_every > 0 && (ep % p.resample_every) == 0;
+    double qww, qc, x0, r;
+    if (draws) {  // seed-for-seed replay of the reference's MT19937 draws (host generated)
+        qww = draws[4 * (size_t)i + 0]; qc = draws[4 * (size_t)i + 1];
+        x0 = draws[4 * (size_t)i + 2]; r = draws[4 * (size_t)i + 3];
+    } else {
+        double u0, u1, u2, u3;
+        philox_pair(p.seed, p.env_offset + (uint32_t)i, (uint32_t)ep, 0, STREAM_RESET, u0, u1);
+        philox_pair(p.seed, p.env_offset + (uint32_t)i, (uint32_t)ep, 1, STREAM_RESET, u2, u3);
+        qww = p.qww_lo + (p.qww_hi - p.qww_lo) * u0;  // np.random.uniform(lo, hi), ph.py:410
+        qc = p.qc_lo + (p.qc_hi - p.qc_lo) * u1;
+        x0 = p.x0_lo + (p.x0_hi - p.x0_lo) * u2;      // ph.py:420
+        r = p.r_lo + (p.r_hi - p.r_lo) * u3;          // ph.py:424
+    }
+    double C;
+    if (resample) {  // update_system (ph.py:114-121): ZOH of qc_V/(s+qww_V) at T -> closed form
+        st.qww[i] = qww;
+        st.qc[i] = qc;
+        const double e = -qww * p.sample_t;
+        st.A[i] = exp(e);
+        st.B[i] = -expm1(e) / qww;
+        st.C[i] = C = qc;
+    } else {
+        C = st.C[i];
+    }
+    st.x[i] = x0;
+    const S y = ph_lookup<S>(p, st.table, C, x0);
+    st.t[i] = 0;
+    st.r[i] = (S)r;
+    st.I[i] = S(0);
+    obs[3 * (size_t)i + 0] = (float)y;
+    obs[3 * (size_t)i + 1] = (float)r;
+    obs[3 * (size_t)i + 2] = 0.0f;
+}
+
+template <typename S>
+__global__ void ph_reset_kernel(PhParams p, PhPtrs<S> st, const uint8_t* __restrict__ mask,
+                                const double* __restrict__ draws, float* __restrict__ obs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    if (mask && !mask[i]) return;
+    ph_reset_lane<S>(p, st, i, draws, obs);
+}
+
+template <typename S, typename ActT, bool RESIDUAL>
+__global__ void ph_step_kernel(PhParams p, PhPtrs<S> st, const ActT* __restrict__ act,
+                               const float* __restrict__ obs_in, PriorK K, const double* __restrict__ reset_draws,
+                               float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    double a;
+    if constexpr (RESIDUAL) {  // agent_residual.py:61: np.tanh(action_f32) + state_f32 @ priorK_f64
+        double dot = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dot += (double)obs_in[3 * (size_t)i + j] * K.k[j];
+        a = (double)tanhf((float)act[i]) + dot;
+    } else {
+        a = (double)act[i];
+    }
+    a = clip(a, -1.0, 1.0);                                   // ph.py:321
+    int t = st.t[i];
+    S delta_u = S(0);
+    if (p.has_punish) {
+        delta_u = t != 0 ? (S)a - st.last_a[i] : S(0);        // :322
+        st.last_a[i] = (S)a;
+    }
+    t += 1;                                                   // :325
+    const double u = p.u_low + (p.u_high - p.u_low) * ((a - -1.0) / (1.0 - -1.0));  // action(): :155-159
+    const double C = st.C[i];
+    const double x = st.A[i] * st.x[i] + st.B[i] * u;         // :330
+    const S y = ph_lookup<S>(p, st.table, C, x);              // :332
+    const S r = st.r[i];
+    S rew = reward_of<S>(p.reward_type, y, r, (S)p.thr);      // :334
+    const S I_raw = st.I[i] + (r - y);                        // :339-340
+    const S I = p.integral_bound ? clip(I_raw, (S)-p.integral_max, (S)p.integral_max) : I_raw;  // :341 / :470
+    if (p.has_punish) {
+        rew -= (S)p.action_punish * fabs((S)u);               // :336
+        rew -= (S)p.action_change_punish * fabs(delta_u);     // :337
+        rew += -(S)p.integral_punish * fabs(p.integral_bound ? I_raw : I);  // :343 / :473
+    }
+    const bool d = t >= p.max_steps;  // gym TimeLimit; the env itself returns False (:348)
+    reward[i] = (float)rew;
+    done[i] = (uint8_t)d;
+    if (d && p.auto_reset) {
+        ph_reset_lane<S>(p, st, i, reset_draws, obs);
+    } else {
+        st.x[i] = x;
+        st.I[i] = I;
+        st.t[i] = t;
+        obs[3 * (size_t)i + 0] = (float)y;
+        obs[3 * (size_t)i + 1] = (float)r;
+        obs[3 * (size_t)i + 2] = (float)I;
+    }
+}
+
+template <typename S>
+__global__ void ph_observe_kernel(PhParams p, PhPtrs<S> st, float* __restrict__ obs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    obs[3 * (size_t)i + 0] = (float)ph_lookup<S>(p, st.table, st.C[i], st.x[i]);
+    obs[3 * (size_t)i + 1] = (float)st.r[i];
+    obs[3 * (size_t)i + 2] = (float)st.I[i];
+}
+
+// ============================================================================================ water tank
+template <typename S>
+__device__ __forceinline__ void wt_write_obs(const WtParams& p, const WtPtrs<S>& st, int i, S h1, S h2, S r, S I,
+                                             float* __restrict__ obs) {
+    if (p.num_stack > 0) {  // Stacking: np.array(frames).reshape(1,-1)[0], oldest first (:1162-1164)
+        const S* f = st.frames + (size_t)i * p.obs_dim;
+        for (int j = 0; j < p.obs_dim; ++j) obs[(size_t)i * p.obs_dim + j] = (float)f[j];
+    } else {                // Integrator: [h1, h2, r, I] (:789-793)
+        float4 o = make_float4((float)h1, (float)h2, (float)r, (float)I);
+        *reinterpret_cast<float4*>(obs + 4 * (size_t)i) = o;
+    }
+}
+
+template <typename S>
+__device__ __forceinline__ void wt_reset_lane(const WtParams& p, const WtPtrs<S>& st, int i,
+                                              const double* __restrict__ draws, float* __restrict__ obs) {
+    const int ep = st.episode[i] + 1;
+    st.episode[i] = ep;
+    const bool resample = p.resample_every > 0 && (ep % p.resample_every) == 0;
+    double v[6];
+    if (draws) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = draws[6 * (size_t)i + j];
+    } else {
+        double u[6];
+#pragma unroll
+        for (uint32_t s = 0; s < 3; ++s)
+            philox_pair(p.seed, p.env_offset + (uint32_t)i, (uint32_t)ep, s, STREAM_RESET, u[2 * s], u[2 * s + 1]);
+        v[0] = p.a1_lo + (p.a1_hi - p.a1_lo) * u[0];  // sample_parameters :890-894
+        v[1] = p.a2_lo + (p.a2_hi - p.a2_lo) * u[1];
+        v[2] = p.kp_lo + (p.kp_hi - p.kp_lo) * u[2];
+        v[3] = p.h_lo + (p.h_hi - p.h_lo) * u[3];     // :912
+        v[4] = p.h_lo + (p.h_hi - p.h_lo) * u[4];
+        v[5] = p.r_lo + (p.r_hi - p.r_lo) * u[5];     // :913
+    }
+    if (resample) {
+        st.a1[i] = (S)v[0]; st.a2[i] = (S)v[1]; st.kp[i] = (S)v[2];
+    }
+    const S h1 = (S)v[3], h2 = (S)v[4], r = (S)v[5];
+    st.h1[i] = h1; st.h2[i] = h2; st.r[i] = r;
+    st.t[i] = 0;
+    if (p.num_stack > 0) {  // every frame = first frame (:1181-1183)
+        S* f = st.frames + (size_t)i * p.obs_dim;
+        for (int s = 0; s < p.num_stack; ++s) { f[3 * s] = h1; f[3 * s + 1] = h2; f[3 * s + 2] = r; }
+    } else {
+        st.I[i] = S(0);
+    }
+    wt_write_obs<S>(p, st, i, h1, h2, r, S(0), obs);
+}
+
+template <typename S>
+__global__ void wt_reset_kernel(WtParams p, WtPtrs<S> st, const uint8_t* __restrict__ mask,
+                                const double* __restrict__ draws, float* __restrict__ obs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    if (mask && !mask[i]) return;
+    wt_reset_lane<S>(p, st, i, draws, obs);
+}
+
+template <typename S, typename ActT, bool RESIDUAL>
+__global__ void wt_step_kernel(WtParams p, WtPtrs<S> st, const ActT* __restrict__ act,
+                               const float* __restrict__ obs_in, PriorK K, const double* __restrict__ noise,
+                               const double* __restrict__ reset_draws, float* __restrict__ obs,
+                               float* __restrict__ reward, uint8_t* __restrict__ done) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    double a;
+    if constexpr (RESIDUAL) {
+        double dot = 0.0;
+        for (int j = 0; j < p.obs_dim; ++j) dot += (double)obs_in[(size_t)i * p.obs_dim + j] * K.k[j];
+        a = (double)tanhf((float)act[i]) + dot;
+    } else {
+        a = (double)act[i];
+    }
+    const int t = st.t[i] + 1;                                          // :801
+    const S u = (S)(a * p.pmax / 2. + p.pmax / 2.);                     // action_P :258-260 (a is NOT clipped)
+    S h1 = st.h1[i], h2 = st.h2[i];
+    const S a1 = st.a1[i], a2 = st.a2[i], kp = st.kp[i], r = st.r[i];
+    const S A1 = (S)p.A1, A2 = (S)p.A2, G = (S)p.G, dt = (S)p.dt;
+    const S lo = S(-0.0), hi = (S)INFINITY;                            // Box(low=-0, high=inf) :252-257
+    for (int s = 0; s < p.n_discrete; ++s) {                            // :805-809, both roots from the OLD h1,h2
+        const S s1 = sqrt(2 * G * h1), s2 = sqrt(2 * G * h2);
+        const S n1 = h1 + (-a1 / A1 * s1 + kp / A1 * u) * dt;
+        const S n2 = h2 + (a1 / A2 * s1 - a2 / A2 * s2) * dt;
+        h1 = clip(n1, lo, hi);
+        h2 = clip(n2, lo, hi);
+    }
+    double z1n, z2n;
+    if (noise) {
+        z1n = noise[2 * (size_t)i]; z2n = noise[2 * (size_t)i + 1];
+    } else {  // Philox Box-Muller; the reference draws np.random.normal twice (:271-272,:810-811)
+        double ua, ub;
+        philox_pair(p.seed, p.env_offset + (uint32_t)i, (uint32_t)st.episode[i], (uint32_t)t, STREAM_NOISE, ua, ub);
+        const double rad = sqrt(-2.0 * log(1.0 - ua)), ang = 6.283185307179586476925286766559 * ub;
+        double sn, cs;
+        sincos(ang, &sn, &cs);
+        z1n = p.noise_scale * (rad * cs);
+        z2n = p.noise_scale * (rad * sn);
+    }
+    h1 = clip(h1 + (S)z1n, lo, hi);                                     // :810-813
+    h2 = clip(h2 + (S)z2n, lo, hi);
+    S rew = reward_of<S>(p.reward_type, h2, r, (S)p.thr);
+    if (p.reward_type != PIME_REWARD_SPARSE) rew = rew * (S)p.z1;       // :506,508
+    const bool d = !(t < p.max_steps);                                  // :816-821
+    S I = S(0);
+    if (p.num_stack == 0) {
+        const S I_raw = st.I[i] + (r - h2);                             // :822-823
+        rew += -(S)p.integral_punish * fabs(I_raw);                     // :824
+        I = clip(I_raw, (S)-p.integral_max, (S)p.integral_max);         // :825
+    }
+    reward[i] = (float)rew;
+    done[i] = (uint8_t)d;
+    if (d && p.auto_reset) {
+        wt_reset_lane<S>(p, st, i, reset_draws, obs);
+        return;
+    }
+    st.h1[i] = h1; st.h2[i] = h2; st.t[i] = t;
+    if (p.num_stack > 0) {  // deque(maxlen=S).append([h1,h2,r]) (:1143-1144)
+        S* f = st.frames + (size_t)i * p.obs_dim;
+        for (int j = 0; j < p.obs_dim - 3; ++j) f[j] = f[j + 3];
+        f[p.obs_dim - 3] = h1; f[p.obs_dim - 2] = h2; f[p.obs_dim - 1] = r;
+    } else {
+        st.I[i] = I;
+    }
+    wt_write_obs<S>(p, st, i, h1, h2, r, I, obs);
+}
+
+template <typename S>
+__global__ void wt_observe_kernel(WtParams p, WtPtrs<S> st, float* __restrict__ obs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    wt_write_obs<S>(p, st, i, st.h1[i], st.h2[i], st.r[i], p.num_stack > 0 ? S(0) : st.I[i], obs);
+}
+
+// ============================================================================================ launchers
+static inline dim3 lane_grid(int n, int& block) {
+    // one wave per workgroup while the launch is small, so a 16 384-env launch still spreads over all 256 CUs
+    block = n <= 65536 ? 64 : 256;
+    return dim3((unsigned)((n + block - 1) / block));
+}
+
+template <typename S>
+int launch_ph_reset(const PhParams& p, const PhPtrs<S>& st, const uint8_t* mask, const double* draws, float* obs,
+                    hipStream_t s) {
+    int block;
+    const dim3 grid = lane_grid(p.n, block);
+    hipLaunchKernelGGL(ph_reset_kernel<S>, grid, dim3(block), 0, s, p, st, mask, draws, obs);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+template <typename S>
+int launch_ph_step(const PhParams& p, const PhPtrs<S>& st, const void* act, int act_dtype, bool residual,
+                   const float* obs_in, const PriorK& K, const double* reset_draws, float* obs, float* reward,
+                   uint8_t* done, hipStream_t s) {
+    int block;
+    const dim3 grid = lane_grid(p.n, block);
+    if (residual)
+        hipLaunchKernelGGL((ph_step_kernel<S, float, true>), grid, dim3(block), 0, s, p, st, (const float*)act, obs_in,
+                           K, reset_draws, obs, reward, done);
+    else if (act_dtype == PIME_F32)
+        hipLaunchKernelGGL((ph_step_kernel<S, float, false>), grid, dim3(block), 0, s, p, st, (const float*)act,
+                           obs_in, K, reset_draws, obs, reward, done);
+    else
+        hipLaunchKernelGGL((ph_step_kernel<S, double, false>), grid, dim3(block), 0, s, p, st, (const double*)act,
+                           obs_in, K, reset_draws, obs, reward, done);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+template <typename S>
+int launch_ph_observe(const PhParams& p, const PhPtrs<S>& st, float* obs, hipStream_t s) {
+    int block;
+    const dim3 grid = lane_grid(p.n, block);
+    hipLaunchKernelGGL(ph_observe_kernel<S>, grid, dim3(block), 0, s, p, st, obs);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+template <typename S>
+int launch_wt_reset(const WtParams& p, const WtPtrs<S>& st, const uint8_t* mask, const double* draws, float* obs,
+                    hipStream_t s) {
+    int block;
+    const dim3 grid = lane_grid(p.n, block);
+    hipLaunchKernelGGL(wt_reset_kernel<S>, grid, dim3(block), 0, s, p, st, mask, draws, obs);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+template <typename S>
+int launch_wt_step(const WtParams& p, const WtPtrs<S>& st, const void* act, int act_dtype, bool residual,
+                   const float* obs_in, const PriorK& K, const double* noise, const double* reset_draws, float* obs,
+                   float* reward, uint8_t* done, hipStream_t s) {
+    int block;
+    const dim3 grid = lane_grid(p.n, block);
+    if (residual)
+        hipLaunchKernelGGL((wt_step_kernel<S, float, true>), grid, dim3(block), 0, s, p, st, (const float*)act, obs_in,
+                           K, noise, reset_draws, obs, reward, done);
+    else if (act_dtype == PIME_F32)
+        hipLaunchKernelGGL((wt_step_kernel<S, float, false>), grid, dim3(block), 0, s, p, st, (const float*)act,
+                           obs_in, K, noise, reset_draws, obs, reward, done);
+    else
+        hipLaunchKernelGGL((wt_step_kernel<S, double, false>), grid, dim3(block), 0, s, p, st, (const double*)act,
+                           obs_in, K, noise, reset_draws, obs, reward, done);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+template <typename S>
+int launch_wt_observe(const WtParams& p, const WtPtrs<S>& st, float* obs, hipStream_t s) {
+    int block;
+    const dim3 grid = lane_grid(p.n, block);
+    hipLaunchKernelGGL(wt_observe_kernel<S>, grid, dim3(block), 0, s, p, st, obs);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+// explicit instantiations used by abi.hip
+#define PIME_INST(S)                                                                                               \
+    template int launch_ph_reset<S>(const PhParams&, const PhPtrs<S>&, const uint8_t*, const double*, float*,     \
+                                    hipStream_t);                                                                  \
+    template int launch_ph_step<S>(const PhParams&, const PhPtrs<S>&, const void*, int, bool, const float*,       \
+                                   const PriorK&, const double*, float*, float*, uint8_t*, hipStream_t);           \
+    template int launch_ph_observe<S>(const PhParams&, const PhPtrs<S>&, float*, hipStream_t);                     \
+    template int launch_wt_reset<S>(const WtParams&, const WtPtrs<S>&, const uint8_t*, const double*, float*,     \
+                                    hipStream_t);                                                                  \
+    template int launch_wt_step<S>(const WtParams&, const WtPtrs<S>&, const void*, int, bool, const float*,       \
+                                   const PriorK&, const double*, const double*, float*, float*, uint8_t*,          \
+                                   hipStream_t);                                                                   \
+    template int launch_wt_observe<S>(const WtParams&, const WtPtrs<S>&, float*, hipStream_t);
+PIME_INST(double)
+PIME_INST(float)
+
+}  // namespace pime

@@ -1,0 +1,362 @@
+// Fused small-MLP forwards on the gfx950 f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, 64 FLOP/clk/SIMD).
+//
+// replaces (reference, /root/reference):
+//   CriticAdv value pass over the whole buffer      elegantrl/agent.py:619-620 with elegantrl/net.py:274-277
+//   ActorResidualIntegratorModularPPO mean          elegantrl/net_residual.py:153-160,172-176
+//   ActorResidualPPO / ActorPPO mean                elegantrl/net_residual.py:19-22,45-48
+//
+// Design (DESIGN.md "mlp_forward"):
+//  * One wave owns a tile of 32 samples for the WHOLE network.  Activations never leave registers: with the
+//    weights as the MFMA A operand (rows = output features) and the activations as B (columns = samples), the
+//    32x32 accumulator of layer l has its sample on the lane and its features in the 16 registers, which is
+//    exactly the B-operand shape of layer l+1's k-steps (k = lane>>5 picks the feature pair {f, f+4}).  So
+//    layer chaining needs no LDS round trip and no cross-lane traffic; only the head's 2-way lane-half sum
+//    uses one permute.
+//  * All weights of the net (<= 132 KB at width 128) sit in LDS for the lifetime of a persistent workgroup,
+//    pre-permuted by mlp_pack_kernel into the order the k-steps consume them, so the per-k-step A operands of
+//    all output tiles are ONE conflict-free ds_read_b128 (or b64) per lane.
+//  * First layer (K = state_dim <= 32) and head (N = 1) are VALU work in the same register layout.
+#include "pime_common.hpp"
+
+namespace pime {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum { MLP_CRITIC = 0, MLP_PLAIN_ACTOR = 1, MLP_MODULAR_ACTOR = 2 };
+
+// feature index inside a 32-wide tile held by accumulator register s of lane-half h (C/D map of 32x32 MFMA)
+__host__ __device__ __forceinline__ constexpr int feat32(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+// ---- packed image layout (identical in HBM and LDS) -------------------------------------------------------
+// FIRST  layer (D_in -> 32*OT):   [D_in+1][OT][16][2]        column j of W for feature feat(ot,r,h); row D_in = bias
+//                                 (j outermost so every LDS read of the unrolled (ot,r) loop is base + immediate)
+// MFMA   layer (32*KT -> 32*OT):  [KT*16][64][OT]            W[ot*32 + (lane&31)][kt*32 + feat32(s, lane>>5)]
+// VEC    (bias / head weights):   [OT][16][2]                v[ot*32 + feat32(r,h)]
+struct MlpLayout {
+    int T;          // md / 32
+    int off[12];    // float offsets of the segments
+    int total;      // floats (multiple of 4)
+};
+
+__host__ __device__ inline int align4(int v) { return (v + 3) & ~3; }
+
+__host__ __device__ inline MlpLayout mlp_layout(int kind, int D, int Di, int md) {
+    MlpLayout L{};
+    const int T = md / 32;
+    L.T = T;
+    int o = 0;
+    auto seg = [&](int idx, int floats) { L.off[idx] = o; o = align4(o + floats); };
+    if (kind == MLP_MODULAR_ACTOR) {
+        const int Do = D - Di, H = T / 2;
+        seg(0, T * 32 * (Do + 1));     // other_net.0 (FIRST)
+        seg(1, T * 16 * 64 * H);       // other_net.2 (MFMA md -> md/2)
+        seg(2, H * 32);                // other_net.2 bias
+        seg(3, T * 32 * (Di + 1));     // integrator_net.0 (FIRST)
+        seg(4, T * 16 * 64 * H);       // integrator_net.2
+        seg(5, H * 32);
+        seg(6, T * 16 * 64 * T);       // net.0 (MFMA md -> md)
+        seg(7, T * 32);                // net.0 bias
+        seg(8, T * 32);                // net.2 weights (HEAD)
+        seg(9, 4);                     // net.2 bias
+    } else {
+        seg(0, T * 32 * (D + 1));      // net.0 (FIRST)
+        seg(1, T * 16 * 64 * T);       // net.2
+        seg(2, T * 32);
+        seg(3, T * 16 * 64 * T);       // net.4
+        seg(4, T * 32);
+        seg(5, T * 32);                // net.6 weights (HEAD)
+        seg(6, 4);                     // net.6 bias
+    }
+    L.total = o;
+    return L;
+}
+
+// ---- pack: nn.Linear layout -> packed image -------------------------------------------------------------------
+struct PackArgs {
+    const float* p[12];
+    int kind, D, Di, md;
+};
+
+__device__ inline void pack_first(float* dst, const float* W, const float* b, int Din, int ldw, int col0, int OT,
+                                  int tid, int nthr) {
+    const int per = OT * 32, n = per * (Din + 1);
+    for (int idx = tid; idx < n; idx += nthr) {
+        const int j = idx / per, q = idx % per;
+        const int h = q & 1, r = (q >> 1) & 15, ot = q >> 5;
+        const int f = ot * 32 + feat32(r, h);
+        dst[idx] = j < Din ? W[(size_t)f * ldw + col0 + j] : b[f];
+    }
+}
+
+__device__ inline void pack_mfma(float* dst, const float* W, int KT, int OT, int tid, int nthr) {
+    const int K = KT * 32, n = KT * 16 * 64 * OT;
+    for (int idx = tid; idx < n; idx += nthr) {
+        const int ot = idx % OT, lane = (idx / OT) & 63, ks = idx / (OT * 64);
+        const int kt = ks >> 4, s = ks & 15;
+        dst[idx] = W[(size_t)(ot * 32 + (lane & 31)) * K + kt * 32 + feat32(s, lane >> 5)];
+    }
+}
+
+__device__ inline void pack_vec(float* dst, const float* v, int OT, int tid, int nthr) {
+    for (int idx = tid; idx < OT * 32; idx += nthr) {
+        const int h = idx & 1, r = (idx >> 1) & 15, ot = idx >> 5;
+        dst[idx] = v[ot * 32 + feat32(r, h)];
+    }
+}
+
+__global__ void mlp_pack_kernel(PackArgs a, float* __restrict__ out) {
+    const MlpLayout L = mlp_layout(a.kind, a.D, a.Di, a.md);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x, T = L.T;
+    if (a.kind == MLP_MODULAR_ACTOR) {
+        const int Do = a.D - a.Di, H = T / 2;
+        pack_first(out + L.off[0], a.p[0], a.p[1], Do, Do, 0, T, tid, nthr);
+        pack_mfma(out + L.off[1], a.p[2], T, H, tid, nthr);
+        pack_vec(out + L.off[2], a.p[3], H, tid, nthr);
+        pack_first(out + L.off[3], a.p[4], a.p[5], a.Di, a.Di, 0, T, tid, nthr);
+        pack_mfma(out + L.off[4], a.p[6], T, H, tid, nthr);
+        pack_vec(out + L.off[5], a.p[7], H, tid, nthr);
+        pack_mfma(out + L.off[6], a.p[8], T, T, tid, nthr);
+        pack_vec(out + L.off[7], a.p[9], T, tid, nthr);
+        pack_vec(out + L.off[8], a.p[10], T, tid, nthr);
+        if (tid == 0) out[L.off[9]] = a.p[11][0];
+    } else {
+        pack_first(out + L.off[0], a.p[0], a.p[1], a.D, a.D, 0, T, tid, nthr);
+        pack_mfma(out + L.off[1], a.p[2], T, T, tid, nthr);
+        pack_vec(out + L.off[2], a.p[3], T, tid, nthr);
+        pack_mfma(out + L.off[3], a.p[4], T, T, tid, nthr);
+        pack_vec(out + L.off[4], a.p[5], T, tid, nthr);
+        pack_vec(out + L.off[5], a.p[6], T, tid, nthr);
+        if (tid == 0) out[L.off[6]] = a.p[7][0];
+    }
+}
+
+// hipcc treats the (read-only after staging) LDS image as loop invariant and hoists bias/head/first-layer reads
+// out of the persistent tile loop, then spills them (1.2 KB/lane of scratch).  A compiler-only memory barrier per
+// tile and per layer keeps each read next to its use.
+#define PIME_NO_HOIST() asm volatile("" ::: "memory")
+
+// ---- forward --------------------------------------------------------------------------------------------------
+// tanh in ~12 VALU ops with few live temporaries (ocml's tanhf inlined 64x per layer drove the kernel to the
+// 256-VGPR cap).  |x| >= 0.25: 1 - 2/(e^{2|x|}+1) via v_exp_f32/v_rcp_f32 (abs err < 1.5e-7); below that the
+// cancellation is avoided with the odd Taylor polynomial to x^9 (rel err < 1e-7 at 0.25).
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);  // e^{2|x|}
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    const float x2 = x * x;
+    const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.021869488536155203f, -0.053968253968253971f),
+                                                   0.13333333333333333f), -0.33333333333333331f), 1.0f);
+    const float t = ax < 0.25f ? small : big;
+    return copysignf(t, x);
+}
+
+template <int ACT>
+__device__ __forceinline__ float activate(float v) {
+    if constexpr (ACT == 0) return v > 0.f ? v : 0.f;  // nn.ReLU
+    else return fast_tanh(v);                           // nn.Tanh
+}
+
+// y[ot][r] = act( b[f] + sum_j x[m][col0 + j] * W[f][j] ),  f = ot*32 + feat32(r, h)
+template <int OT, int ACT>
+__device__ __forceinline__ void layer_first(const float* __restrict__ w0, const float* __restrict__ xrow, int Din,
+                                            int h, f32x16 (&out)[OT]) {
+    const float* wb = w0 + Din * (OT * 32) + h;  // bias row
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = wb[(ot * 16 + r) * 2];
+    for (int j = 0; j < Din; ++j) {
+        const float xj = xrow[j];
+        const float* wj = w0 + j * (OT * 32) + h;
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[ot][r] = fmaf(xj, wj[(ot * 16 + r) * 2], out[ot][r]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = activate<ACT>(out[ot][r]);
+}
+
+template <int OT>
+struct WFrag;
+template <>
+struct WFrag<4> { using type = float4; };
+template <>
+struct WFrag<2> { using type = float2; };
+template <>
+struct WFrag<1> { using type = float; };
+
+__device__ __forceinline__ float wfrag_get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ float wfrag_get(const float2& v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ float wfrag_get(const float& v, int) { return v; }
+
+// out = act( W * in + b ) on the matrix cores.  in: KT tiles of 32 features, out: OT tiles.
+template <int KT, int OT, int ACT>
+__device__ __forceinline__ void layer_mfma(const float* __restrict__ wp, const float* __restrict__ bp, int lane,
+                                           const f32x16 (&in)[KT], f32x16 (&out)[OT]) {
+    using Frag = typename WFrag<OT>::type;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = bp[(ot * 16 + r) * 2 + h];
+    const Frag* wl = reinterpret_cast<const Frag*>(wp) + lane;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if ((s & 3) == 0) PIME_NO_HOIST();  // bound the W-fragment prefetch depth to 4 k-steps (<= 16 VGPRs)
+            const Frag w = wl[(kt * 16 + s) * 64];
+            const float b = in[kt][s];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+                out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfrag_get(w, ot), b, out[ot], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = activate<ACT>(out[ot][r]);
+}
+
+template <int KT>
+__device__ __forceinline__ float layer_head(const float* __restrict__ w, float bias, int lane, const f32x16 (&in)[KT]) {
+    const int h = lane >> 5;
+    float acc = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc = fmaf(in[kt][r], w[(kt * 16 + r) * 2 + h], acc);
+    acc += __shfl_xor(acc, 32);  // the other lane half holds the other 16 features of every tile
+    return acc + bias;
+}
+
+constexpr int kMlpThreads = 512;  // 8 waves: two per SIMD so one wave's tanh/VALU overlaps the other's MFMAs
+
+template <int T, int KIND>
+__global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const float* __restrict__ x, int M, int D, int Di,
+                                                                  const float* __restrict__ packed,
+                                                                  float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MlpLayout L = mlp_layout(KIND, D, Di, T * 32);
+    {  // stage the packed image: straight 16-B copies, coalesced in HBM and conflict-free in LDS
+        const float4* src = reinterpret_cast<const float4*>(packed);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < L.total / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6, h = lane >> 5;
+    const int ntiles = (M + 31) / 32;
+    for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
+        PIME_NO_HOIST();
+        const int m = tile * 32 + (lane & 31);
+        const float* xrow = x + (size_t)(m < M ? m : M - 1) * D;
+        float y;
+        if constexpr (KIND == MLP_MODULAR_ACTOR) {
+            constexpr int H = T / 2;
+            const int Do = D - Di;
+            f32x16 cat[T];  // torch.cat([other_net(..), integrator_net(..)], -1): tiles [0,H) and [H,T)
+            {
+                f32x16 a0[T];
+                layer_first<T, 1>(lds + L.off[0], xrow, Do, h, a0);
+                PIME_NO_HOIST();
+                layer_mfma<T, H, 1>(lds + L.off[1], lds + L.off[2], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
+            }
+            {
+                f32x16 a0[T];
+                PIME_NO_HOIST();
+                layer_first<T, 1>(lds + L.off[3], xrow + Do, Di, h, a0);
+                PIME_NO_HOIST();
+                layer_mfma<T, H, 1>(lds + L.off[4], lds + L.off[5], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
+            }
+            f32x16 n0[T];
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 1>(lds + L.off[6], lds + L.off[7], lane, cat, n0);
+            PIME_NO_HOIST();
+            y = layer_head<T>(lds + L.off[8], lds[L.off[9]], lane, n0);
+        } else {
+            constexpr int ACT = KIND == MLP_CRITIC ? 0 : 1;
+            f32x16 a0[T], a1[T];
+            layer_first<T, ACT>(lds + L.off[0], xrow, D, h, a0);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, ACT>(lds + L.off[1], lds + L.off[2], lane, a0, a1);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, ACT>(lds + L.off[3], lds + L.off[4], lane, a1, a0);
+            PIME_NO_HOIST();
+            y = layer_head<T>(lds + L.off[5], lds[L.off[6]], lane, a0);
+        }
+        if (h == 0 && m < M) out[m] = y;
+    }
+}
+
+// ---- host launchers ---------------------------------------------------------------------------------------------
+int64_t mlp_packed_floats(int kind, int D, int Di, int md) { return mlp_layout(kind, D, Di, md).total; }
+
+int mlp_check(int kind, int D, int Di, int md) {
+    PIME_REQUIRE(kind >= MLP_CRITIC && kind <= MLP_MODULAR_ACTOR, "mlp kind %d unknown", kind);
+    PIME_REQUIRE(D >= 1 && D <= kMaxObsDim, "state_dim %d out of range [1,%d]", D, kMaxObsDim);
+    if (kind == MLP_MODULAR_ACTOR) {
+        PIME_REQUIRE(Di >= 1 && Di < D, "integrator_dim %d must be in [1, state_dim)", Di);
+        PIME_REQUIRE(md == 64 || md == 128, "fused modular-actor forward supports width 64 or 128, got %d", md);
+    } else {
+        PIME_REQUIRE(md == 64 || md == 128, "fused MLP forward supports width 64 or 128, got %d "
+                     "(width 256 does not fit the 160 KB LDS-resident design)", md);
+    }
+    return PIME_OK;
+}
+
+int launch_mlp_pack(int kind, int D, int Di, int md, const float* const* params, float* packed, hipStream_t s) {
+    if (int rc = mlp_check(kind, D, Di, md)) return rc;
+    PackArgs a{};
+    const int np = kind == MLP_MODULAR_ACTOR ? 12 : 8;
+    for (int i = 0; i < np; ++i) {
+        PIME_REQUIRE(params[i] != nullptr, "mlp params[%d] is NULL", i);
+        a.p[i] = params[i];
+    }
+    a.kind = kind; a.D = D; a.Di = Di; a.md = md;
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(64), dim3(256), 0, s, a, packed);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+template <int T, int KIND>
+static int launch_fwd(const float* x, int M, int D, int Di, const float* packed, float* out, hipStream_t s) {
+    const MlpLayout L = mlp_layout(KIND, D, Di, T * 32);
+    const size_t lds_bytes = (size_t)L.total * sizeof(float);
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_forward_kernel<T, KIND>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    PIME_REQUIRE(lds_bytes <= 160 * 1024, "packed MLP image (%zu B) exceeds the 160 KB LDS", lds_bytes);
+    const int ntiles = (M + 31) / 32, waves = kMlpThreads / 64;
+    int grid = (ntiles + waves - 1) / waves;
+    // small launches: spread the tiles over more CUs (one tile per wave costs ~3 x 16k cycles of MFMA issue)
+    if (ntiles <= 256 * 2) grid = ntiles < 256 ? ntiles : 256;
+    if (grid > 256) grid = 256;  // persistent: one workgroup per CU, weights stay in its LDS
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((mlp_forward_kernel<T, KIND>), dim3(grid), dim3(kMlpThreads), lds_bytes, s, x, M, D, Di, packed,
+                       out);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+int launch_mlp_forward(int kind, const float* x, int M, int D, int Di, int md, const float* packed, float* out,
+                       hipStream_t s) {
+    if (int rc = mlp_check(kind, D, Di, md)) return rc;
+    PIME_REQUIRE(M >= 1, "M = %d rows", M);
+    const int T = md / 32;
+#define PIME_FWD(TT, KK) \
+    if (T == TT && kind == KK) return launch_fwd<TT, KK>(x, M, D, Di, packed, out, s);
+    PIME_FWD(2, MLP_CRITIC) PIME_FWD(4, MLP_CRITIC)
+    PIME_FWD(2, MLP_PLAIN_ACTOR) PIME_FWD(4, MLP_PLAIN_ACTOR)
+    PIME_FWD(2, MLP_MODULAR_ACTOR) PIME_FWD(4, MLP_MODULAR_ACTOR)
+#undef PIME_FWD
+    set_error("no fused MLP instantiation for kind %d width %d", kind, md);
+    return PIME_ERR_ARG;
+}
+
+}  // namespace pime

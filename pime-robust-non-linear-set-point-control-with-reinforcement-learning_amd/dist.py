@@ -1,0 +1,83 @@
+"""Data-parallel sharding over the GPUs of one node: one process per GPU, env lanes split into contiguous
+slices (rank g owns global lanes [g*N, (g+1)*N)), no communication during rollout, and per optimizer step ONE
+all-reduce of a flat gradient buffer over RCCL/xGMI (backend "nccl" on ROCm) -- or gloo in the CPU tests.
+
+The reference has no distributed path at all (SURVEY.md §2 "Native / CUDA / collective inventory: empty");
+this is new.  Messages are tiny (67 459 floats = 270 KB for the pH nets at width 128), i.e. latency-bound, so
+everything is flattened into one buffer and reduced in one call.
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_from_env(backend=None, device=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns a DataParallel or None when
+    WORLD_SIZE == 1."""
+    rank, world, local = env_rank_world()
+    if world <= 1:
+        return None
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC
+        torch.cuda.set_device(local)
+    if not td.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group(backend=backend, rank=rank, world_size=world)
+    return DataParallel(rank, world, local, device)
+
+
+class DataParallel:
+    def __init__(self, rank, world, local_rank=0, device=None):
+        self.rank, self.world, self.local_rank = rank, world, local_rank
+        self.device = device
+        self._flat = None
+
+    def lane_offset(self, lanes_per_rank):
+        """Global id of this rank's lane 0 (the env kernels' Philox counter word / Mt19937 seed offset)."""
+        return self.rank * lanes_per_rank
+
+    def broadcast_module(self, *modules):
+        """Make every replica start from rank 0's weights."""
+        for m in modules:
+            for t in list(m.parameters()) + list(m.buffers()):
+                td.broadcast(t.data, src=0)
+
+    def all_reduce_sum(self, t):
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return t
+
+    def average_gradients(self, params):
+        """Flatten every gradient into ONE buffer, all-reduce it once, scatter the mean back."""
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return
+        n = sum(g.numel() for g in grads)
+        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
+            self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        torch.cat([g.reshape(-1) for g in grads], out=self._flat)
+        td.all_reduce(self._flat, op=td.ReduceOp.SUM)
+        self._flat.div_(self.world)
+        off = 0
+        for g in grads:
+            g.copy_(self._flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def barrier(self):
+        td.barrier()
+
+    def max_over_ranks(self, value):
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value):
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return float(t.item())

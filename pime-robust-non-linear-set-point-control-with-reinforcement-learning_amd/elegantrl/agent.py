@@ -1,0 +1,392 @@
+"""Base agents: AgentBase, AgentPPO (on-policy, the residual agents' parent) and AgentTD3
+(interface of /root/reference/elegantrl/agent.py: AgentBase :15-124, AgentTD3 :276-394, AgentPPO :543-712).
+
+What differs from the reference, by design:
+  * `explore_env` understands vectorised envs (`env.num_envs`): all N lanes advance in lock-step, the policy
+    runs once per step on [N, D], and transitions go straight into a time-major `TrajectoryBuffer` in HBM.
+    A one-instance env (the gym-style facade) still takes the reference's per-step loop.
+  * the value pass and the rollout policy mean run on the fused f32-MFMA forward, GAE on the scan kernel
+    (via the injected backend; the product backend is HIP-only).
+  * loss scalars are accumulated on the device and read back once per `update_net`, not four `.item()` syncs
+    per minibatch (agent.py:644-653).
+  * under torch.distributed every optimizer step all-reduces ONE flat gradient buffer, and the buffer-global
+    advantage normalisation (agent.py:707) all-reduces three moments.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import logger
+from .. import dist as pdist
+from ..backend import HipBackend
+from .net import Actor, ActorPPO, CriticAdv, CriticTwin
+from .replay import TrajectoryBuffer
+
+
+class AgentBase:
+    def __init__(self, backend=None, device=None):
+        self.learning_rate = 1e-4
+        self.soft_update_tau = 2 ** -8
+        self.state = None
+        self.device = torch.device(device) if device is not None else None
+        self.backend = backend if backend is not None else HipBackend()
+        self.act = self.act_target = None
+        self.cri = self.cri_target = None
+        self.act_optimizer = self.cri_optimizer = None
+        self.criterion = None
+        self.get_obj_critic = None
+        self.if_on_policy = False
+        self._n_updates = 0
+        self.dp = None          # pime_amd.dist.DataParallel when training sharded
+        self.index_hook = None  # tests: callable(step, buf_len, batch_size) -> LongTensor of minibatch indices
+
+    def _pick_device(self):
+        if self.device is None:
+            self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.backend.check_device(self.device)
+        return self.device
+
+    def select_action(self, state):
+        states = torch.as_tensor(np.asarray(state)[None], dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            return self.act(states)[0].cpu().numpy()
+
+    def explore_env(self, env, buffer, target_step, reward_scale, gamma):
+        """Off-policy default: `target_step` transitions continuing from self.state (agent.py:54-70)."""
+        for _ in range(target_step):
+            action = self.select_action(self.state)
+            next_s, reward, done, _ = env.step(action)
+            buffer.append_buffer(self.state, (reward * reward_scale, 0.0 if done else gamma, *action))
+            self.state = env.reset() if done else next_s
+        return target_step
+
+    def update_net(self, buffer, target_step, batch_size, repeat_times):
+        raise NotImplementedError
+
+    def save_load_model(self, cwd, if_save):
+        """actor.pth / critic.pth state_dicts, the reference's checkpoint layout (agent.py:86-114).  Loading uses
+        weights_only=True: nothing in the file is executed."""
+        paths = {"act": os.path.join(cwd, "actor.pth"), "cri": os.path.join(cwd, "critic.pth")}
+        for name, path in paths.items():
+            net = getattr(self, name)
+            if net is None:
+                continue
+            if if_save:
+                torch.save(net.state_dict(), path)
+            elif os.path.exists(path):
+                net.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+                print(f"Loaded {name}:", cwd)
+            else:
+                print(f"FileNotFound when load {name}: {cwd}")
+        if not if_save:
+            self.weights_changed()
+
+    def weights_changed(self):
+        """Invalidate packed (kernel-layout) copies of the weights."""
+        self._packed = {}
+
+    @staticmethod
+    def soft_update(target_net, current_net, tau):
+        with torch.no_grad():
+            for tar, cur in zip(target_net.parameters(), current_net.parameters()):
+                tar.mul_(1 - tau).add_(cur, alpha=tau)
+
+
+# ================================================================================================= PPO
+class AgentPPO(AgentBase):
+    def __init__(self, backend=None, device=None):
+        super().__init__(backend, device)
+        self.ratio_clip = 0.2
+        self.lambda_entropy = 0.02
+        self.lambda_gae_adv = 0.97
+        self.if_use_gae = True
+        self.if_on_policy = True
+        self.if_use_dn = False
+        self.noise = None
+        self.optimizer = None
+        self.compute_reward = None
+        self._packed = {}
+        self.noise_hook = None  # tests: callable(t, shape) -> exploration noise tensor (else torch.randn)
+
+    # ---- construction ------------------------------------------------------------------------------------
+    def _build_nets(self, net_dim, state_dim, action_dim):
+        self.cri = CriticAdv(state_dim, net_dim, self.if_use_dn).to(self.device)
+        self.act = ActorPPO(net_dim, state_dim, action_dim, self.if_use_dn).to(self.device)
+
+    def init(self, net_dim, state_dim, action_dim, if_per=False):
+        assert if_per is False, "on-policy agents do not use prioritised replay"
+        self._pick_device()
+        self.compute_reward = self.compute_reward_gae if self.if_use_gae else self.compute_reward_adv
+        self._build_nets(net_dim, state_dim, action_dim)
+        self._make_optimizer()
+        self.criterion = torch.nn.SmoothL1Loss()
+
+    def _make_optimizer(self):
+        # ONE Adam over both nets (agent.py:565-566); rebuilt whenever the reference rebuilds it
+        groups = [{"params": self.act.parameters(), "lr": self.learning_rate},
+                  {"params": self.cri.parameters(), "lr": self.learning_rate}]
+        self.optimizer = torch.optim.Adam(groups)
+        self.weights_changed()
+
+    def init_actor_zero(self):
+        """Zero the policy's output layer so the initial policy is the prior controller alone (agent.py:569-574)."""
+        with torch.no_grad():
+            self.act.net[-1].bias.fill_(0.)
+            self.act.net[-1].weight.fill_(0.)
+        self._make_optimizer()
+
+    def frozen_transfer(self):
+        self.cri.frozen_transfer()
+        self.act.frozen_transfer()
+
+    # ---- acting ------------------------------------------------------------------------------------------
+    def select_action(self, state, if_deterministic=False):
+        states = torch.as_tensor(np.asarray(state)[None], dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            if if_deterministic:
+                return self.act(states)[0].cpu().numpy(), None
+            actions, noises = self.act.get_action_noise(states)
+        return actions[0].cpu().numpy(), noises[0].cpu().numpy()
+
+    def _env_action(self, state, action):
+        """What is sent to a one-instance env for the sampled pre-tanh `action` (agent.py:599)."""
+        return np.tanh(action)
+
+    def _packed_for(self, name):
+        if name not in self._packed:
+            self._packed[name] = self.backend.packed(getattr(self, name))
+        return self._packed[name]
+
+    def policy_mean(self, states):
+        """a_avg for a [M, D] batch without autograd: fused MFMA forward when the shape is supported."""
+        pk = self._packed_for("act")
+        if pk is not None:
+            return pk(states).unsqueeze(1)
+        with torch.no_grad():
+            return self.act.mean(states)
+
+    def state_value(self, states):
+        pk = self._packed_for("cri")
+        if pk is not None:
+            return pk(states)
+        with torch.no_grad():
+            out = [self.cri(states[i:i + 2 ** 16])[:, 0] for i in range(0, states.shape[0], 2 ** 16)]
+        return torch.cat(out)
+
+    def explore_env(self, env, buffer, target_step, reward_scale, gamma):
+        if hasattr(env, "num_envs"):
+            return self.explore_vec_env(env, buffer, target_step, reward_scale, gamma)
+        # one-instance env: whole episodes until >= target_step transitions (agent.py:591-609)
+        buffer.empty_buffer_before_explore()
+        actual_step = 0
+        while actual_step < target_step:
+            state = env.reset()
+            for _ in range(env.max_step):
+                action, noise = self.select_action(state)
+                next_state, reward, done, _ = env.step(self._env_action(state, action))
+                actual_step += 1
+                buffer.append_buffer(state, (reward * reward_scale, 0.0 if done else gamma, *action, *noise))
+                if done:
+                    break
+                state = next_state
+        return actual_step
+
+    def _vec_env_step(self, env, a_pre, obs, out_obs, out_reward, out_done):
+        """Plain PPO: the env sees tanh(a_pre) (agent.py:599)."""
+        return env.step(torch.tanh(a_pre), auto_reset=True, out_obs=out_obs, out_reward=out_reward, out_done=out_done)
+
+    def explore_vec_env(self, env, buffer, target_step, reward_scale, gamma):
+        """Lock-step rollout of all lanes for whole episodes until >= target_step transitions are stored.
+        Every tensor stays in HBM; per step: policy mean (fused forward) + noise + ONE env launch that also
+        applies tanh + prior and writes obs/reward/done into the trajectory slots."""
+        assert isinstance(buffer, TrajectoryBuffer) and buffer.num_envs == env.num_envs
+        buffer.empty_buffer_before_explore()
+        N, T_max = env.num_envs, buffer.horizon
+        episodes = max(1, -(-target_step // (N * env.max_step)))
+        assert episodes * env.max_step <= T_max, "TrajectoryBuffer horizon too short for target_step"
+        std = None
+        t = 0
+        # Every lane sits at the start of an episode either because nothing ran yet (-> reset) or because the last
+        # step of the previous rollout auto-reset it inside the kernel (-> just read the observation back).
+        if env.fresh:
+            env.observe(out=buffer.state[0])
+        else:
+            env.reset(out=buffer.state[0])
+        for ep in range(episodes):
+            for _ in range(env.max_step):
+                obs = buffer.state[t]
+                with torch.no_grad():
+                    if std is None:
+                        std = self.act.a_std_log.detach().exp()
+                    a_avg = self.policy_mean(obs)
+                    noise = torch.randn_like(a_avg) if self.noise_hook is None else self.noise_hook(t, a_avg.shape)
+                    a_pre = a_avg + noise * std
+                    buffer.action[t] = a_pre
+                    buffer.noise[t] = noise
+                self._vec_env_step(env, a_pre, obs, buffer.state[t + 1], buffer.reward[t], buffer.done[t])
+                t += 1
+        with torch.no_grad():
+            if reward_scale != 1.0:
+                buffer.reward[:t] *= reward_scale
+            buffer.mask[:t] = (1.0 - buffer.done[:t].to(torch.float32)) * gamma  # 0.0 if done else gamma
+        buffer.length = t
+        return t * N
+
+    # ---- learning ----------------------------------------------------------------------------------------
+    def _trajectory_views(self, buffer):
+        """(reward, mask, action, noise, state) flattened in storage order plus the [T, N] shape for the scan."""
+        buffer.update_now_len_before_sample()
+        if isinstance(buffer, TrajectoryBuffer):
+            T, N = buffer.length, buffer.num_envs
+        else:
+            T, N = buffer.now_len, 1  # flat time-ordered ring: one lane
+        rew, mask, action, noise, state = buffer.sample_all()
+        return T, N, rew, mask, action, noise, state
+
+    def update_net(self, buffer, _target_step, batch_size, repeat_times=4):
+        T, N, buf_reward, buf_mask, buf_action, buf_noise, buf_state = self._trajectory_views(buffer)
+        buf_len = T * N
+        dev = buf_state.device
+        with torch.no_grad():
+            buf_value = self.state_value(buf_state)                                # agent.py:619-620
+            buf_logprob = self.act.old_logprob(buf_noise)                          # :621
+            buf_r_sum, buf_advantage = self.compute_reward(buf_len, buf_reward, buf_mask, buf_value, shape=(T, N))
+
+        n_steps = int(repeat_times * buf_len / batch_size)                         # :629
+        sums = torch.zeros(4, device=dev)  # united, actor, critic, entropy
+        obj_actor = obj_critic = torch.zeros((), device=dev)
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        for step in range(n_steps):
+            if self.index_hook is not None:
+                indices = self.index_hook(step, buf_len, batch_size).to(dev)
+            else:
+                indices = torch.randint(buf_len, size=(batch_size,), device=dev)   # :630
+            state = buf_state[indices]
+            action = buf_action[indices]
+            r_sum = buf_r_sum[indices]
+            logprob = buf_logprob[indices]
+            advantage = buf_advantage[indices]
+
+            new_logprob = self.act.compute_logprob(state, action)
+            ratio = (new_logprob - logprob).exp()
+            surrogate = torch.min(advantage * ratio,
+                                  advantage * ratio.clamp(1 - self.ratio_clip, 1 + self.ratio_clip))
+            obj_entropy = (new_logprob.exp() * new_logprob).mean()                 # ElegantRL's entropy proxy (:643)
+            obj_actor = -surrogate.mean() + obj_entropy * self.lambda_entropy
+            value = self.cri(state).squeeze(1)
+            obj_critic = self.criterion(value, r_sum)
+            obj_united = obj_actor + obj_critic / (r_sum.std() + 1e-5)             # :652
+            self.optimizer.zero_grad(set_to_none=False)
+            obj_united.backward()
+            if self.dp is not None:
+                self.dp.average_gradients(params)                                  # one flat all-reduce per step
+            self.optimizer.step()
+            sums += torch.stack([obj_united.detach(), obj_actor.detach(), obj_critic.detach(), obj_entropy.detach()])
+        self.weights_changed()
+        self._n_updates += int(repeat_times)
+        if n_steps:
+            mean = (sums / n_steps).tolist()                                       # the only host sync of the update
+            logger.record("train/united_loss", mean[0])
+            logger.record("train/actor_loss", mean[1])
+            logger.record("train/critic_loss", mean[2])
+            logger.record("train/entropy_losses", mean[3])
+        return float(obj_actor.detach()), float(obj_critic.detach())
+
+    def _normalise_advantage(self, adv):
+        """(adv - mean) / (std + 1e-5) over the WHOLE buffer with torch's unbiased std (agent.py:707); under data
+        parallelism the buffer is the union of all ranks' slices -> all-reduce (count, sum, sum of squares)."""
+        if self.dp is None:
+            return (adv - adv.mean()) / (adv.std() + 1e-5)
+        a64 = adv.double()
+        m = torch.stack([torch.tensor(float(adv.numel()), dtype=torch.float64, device=adv.device), a64.sum(),
+                         (a64 * a64).sum()])
+        self.dp.all_reduce_sum(m)
+        n, s, ss = m[0], m[1], m[2]
+        mean = s / n
+        var = (ss - n * mean * mean) / (n - 1)
+        return ((a64 - mean) / (var.clamp_min(0).sqrt() + 1e-5)).float()
+
+    def compute_reward_gae(self, buf_len, buf_reward, buf_mask, buf_value, shape=None):
+        """r_sum and GAE advantage, ElegantRL's recursion (agent.py:685-708), as one reverse scan per env lane."""
+        T, N = shape if shape is not None else (buf_len, 1)
+        value = buf_value.reshape(-1)
+        r_sum, adv = self.backend.gae(buf_reward.reshape(T, N), buf_mask.reshape(T, N), value.reshape(T, N),
+                                      self.lambda_gae_adv, True)
+        return r_sum.reshape(-1), self._normalise_advantage(adv.reshape(-1))
+
+    def compute_reward_adv(self, buf_len, buf_reward, buf_mask, buf_value, shape=None):
+        T, N = shape if shape is not None else (buf_len, 1)
+        value = buf_value.reshape(-1)
+        r_sum, adv = self.backend.gae(buf_reward.reshape(T, N), buf_mask.reshape(T, N), value.reshape(T, N), 0.0, False)
+        return r_sum.reshape(-1), self._normalise_advantage(adv.reshape(-1))
+
+
+# ================================================================================================= TD3
+class AgentTD3(AgentBase):
+    """Twin-delayed DDPG on the flat ring buffer (agent.py:276-394).  Pure PyTorch-ROCm; kept for the
+    reference's `--algo TD3` entry (which only runs there with the residual flags patched off)."""
+
+    def __init__(self, backend=None, device=None):
+        super().__init__(backend, device)
+        self.explore_noise = 0.1
+        self.policy_noise = 0.2
+        self.update_freq = 2
+
+    def init(self, net_dim, state_dim, action_dim, if_per=False):
+        assert not if_per, "prioritised replay is not on the residual-control path"
+        self._pick_device()
+        from copy import deepcopy
+        self.cri = CriticTwin(net_dim, state_dim, action_dim).to(self.device)
+        self.cri_target = deepcopy(self.cri)
+        self.cri_optimizer = torch.optim.Adam(self.cri.parameters(), lr=self.learning_rate)
+        self.act = Actor(net_dim, state_dim, action_dim).to(self.device)
+        self.act_target = deepcopy(self.act)
+        self.act_optimizer = torch.optim.Adam(self.act.parameters(), lr=self.learning_rate)
+        self.criterion = torch.nn.SmoothL1Loss()
+        self.get_obj_critic = self.get_obj_critic_raw
+
+    def select_action(self, state, if_deterministic=False):
+        states = torch.as_tensor(np.asarray(state)[None], dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            action = self.act(states)[0]
+            if not if_deterministic:
+                action = (action + torch.randn_like(action) * self.explore_noise).clamp(-1, 1)
+        return action.cpu().numpy()
+
+    def get_obj_critic_raw(self, buffer, batch_size):
+        with torch.no_grad():
+            reward, mask, action, state, next_s = buffer.sample_batch(batch_size)
+            next_a = self.act_target.get_action(next_s, self.policy_noise)
+            next_q = torch.min(*self.cri_target.get_q1_q2(next_s, next_a))
+            q_label = reward + mask * next_q
+        q1, q2 = self.cri.get_q1_q2(state, action)
+        return self.criterion(q1, q_label) + self.criterion(q2, q_label), state
+
+    def update_net(self, buffer, target_step, batch_size, repeat_times):
+        buffer.update_now_len_before_sample()
+        dev = self.device
+        sums = torch.zeros(2, device=dev)
+        obj_actor = obj_critic = torch.zeros((), device=dev)
+        n_steps = int(target_step * repeat_times)
+        for i in range(n_steps):
+            obj_critic, state = self.get_obj_critic(buffer, batch_size)
+            self.cri_optimizer.zero_grad()
+            obj_critic.backward()
+            self.cri_optimizer.step()
+            if i % self.update_freq == 0:
+                self.soft_update(self.cri_target, self.cri, self.soft_update_tau)
+            obj_actor = -self.cri_target(state, self.act(state)).mean()
+            self.act_optimizer.zero_grad()
+            obj_actor.backward()
+            self.act_optimizer.step()
+            if i % self.update_freq == 0:
+                self.soft_update(self.act_target, self.act, self.soft_update_tau)
+            sums += torch.stack([obj_actor.detach(), obj_critic.detach()])
+        self._n_updates += int(target_step)
+        if n_steps:
+            mean = (sums / n_steps).tolist()
+            logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
+            logger.record("train/actor_loss", mean[0])
+            logger.record("train/critic_loss", mean[1])
+        return float(obj_actor.detach()), float(obj_critic.detach()) / 2

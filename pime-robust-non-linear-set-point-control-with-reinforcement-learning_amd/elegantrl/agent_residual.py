@@ -1,0 +1,58 @@
+"""Residual agents: the policy output is a correction on top of a fixed prior P/PI controller
+(interface of /root/reference/elegantrl/agent_residual.py: Residual :15-24, AgentResidualPPO :31-73,
+AgentResidualIntegratorModularPPO :76-95)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .agent import AgentPPO
+from .net import CriticAdv
+from .net_residual import ActorResidualIntegratorModularPPO, ActorResidualPPO
+
+
+class Residual:
+    def init_residual(self, residual_kwarg):
+        """priorK = -K as a frozen parameter of the actor (checkpointed with it), zero the output layer, and keep a
+        float64 host copy for the rollout-side composition (agent_residual.py:16-21)."""
+        K = np.asarray(residual_kwarg["init_K"], dtype=np.float64)
+        self.act.priorK = nn.Parameter(-torch.as_tensor(K, dtype=torch.float32, device=self.device),
+                                       requires_grad=False)
+        self.init_actor_zero()
+        self.priorK = -K
+
+    def fix_K(self):
+        self.act.priorK.requires_grad = False
+
+
+class AgentResidualPPO(AgentPPO, Residual):
+    def _build_nets(self, net_dim, state_dim, action_dim):
+        self.cri = CriticAdv(state_dim, net_dim, self.if_use_dn).to(self.device)
+        self.act = ActorResidualPPO(net_dim, state_dim, action_dim, self.if_use_dn).to(self.device)
+
+    def _env_action(self, state, action):
+        # float32 tanh + float32 state @ float64 priorK, summed in float64 (agent_residual.py:61)
+        return np.tanh(action) + state @ self.priorK
+
+    def _vec_env_step(self, env, a_pre, obs, out_obs, out_reward, out_done):
+        # the composition above is fused into the env kernel's prologue
+        return env.step_residual(a_pre, obs, self.priorK.reshape(-1), auto_reset=True, out_obs=out_obs,
+                                 out_reward=out_reward, out_done=out_done)
+
+    def frozen_transfer(self):
+        self.act.frozen_transfer()
+        self.cri.frozen_transfer()
+
+
+class AgentResidualIntegratorModularPPO(AgentResidualPPO):
+    def init(self, net_dim, state_dim, action_dim, integrator_dim, if_per=False):
+        self._integrator_dim = integrator_dim
+        super().init(net_dim, state_dim, action_dim, if_per)
+
+    def _build_nets(self, net_dim, state_dim, action_dim):
+        self.cri = CriticAdv(state_dim, net_dim, self.if_use_dn).to(self.device)
+        self.act = ActorResidualIntegratorModularPPO(net_dim, state_dim, action_dim, self._integrator_dim,
+                                                     self.if_use_dn).to(self.device)
+
+    def frozen_integrator(self):
+        self.act.frozen_integrator()
+        self.cri.frozen_transfer()

@@ -1,0 +1,112 @@
+"""Experience storage.
+
+`ReplayBuffer` keeps the reference's flat ring interface (/root/reference/elegantrl/replay.py:238-433) for the
+one-instance env path and the off-policy agents: rows are transitions in time order, `buf_other` = (reward*scale,
+mask, action[, noise]) and `sample_batch` relies on row i+1 being the successor of row i.  Unlike the reference it
+stays on the agent's device also for on-policy use (the reference forces host NumPy there and re-uploads the whole
+buffer every update, replay.py:265-266,353-367).
+
+`TrajectoryBuffer` is the vectorised-rollout store: time-major [T, N, .] tensors resident in HBM that the env
+step kernel and the policy write into directly; lane n of slot t is the transition env n made at its step t.
+"""
+import numpy as np
+import torch
+
+
+class ReplayBuffer:
+    def __init__(self, max_len, state_dim, action_dim, if_on_policy, if_per=False, if_gpu=True, device=None):
+        if if_per:
+            raise NotImplementedError("prioritised replay is not on the residual-control path (run.py:37 if_per=False)")
+        self.device = torch.device(device) if device is not None else \
+            torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.max_len = int(max_len)
+        self.now_len = 0
+        self.next_idx = 0
+        self.if_full = False
+        self.action_dim = action_dim
+        self.if_on_policy = if_on_policy
+        self.if_gpu = True
+        self.if_per = False
+        other_dim = 2 + action_dim * (2 if if_on_policy else 1)
+        self.buf_other = torch.empty((self.max_len, other_dim), dtype=torch.float32, device=self.device)
+        self.buf_state = torch.empty((self.max_len, state_dim), dtype=torch.float32, device=self.device)
+
+    def append_buffer(self, state, other):
+        self.buf_state[self.next_idx] = torch.as_tensor(state, dtype=torch.float32, device=self.device)
+        self.buf_other[self.next_idx] = torch.as_tensor(np.asarray(other, dtype=np.float32), device=self.device)
+        self.next_idx += 1
+        if self.next_idx >= self.max_len:
+            self.if_full = True
+            self.next_idx = 0
+
+    def extend_buffer(self, state, other):
+        state = torch.as_tensor(state, dtype=torch.float32, device=self.device)
+        other = torch.as_tensor(other, dtype=torch.float32, device=self.device)
+        size = len(other)
+        end = self.next_idx + size
+        if end > self.max_len:  # wrap: head of the batch fills the tail of the ring, the rest restarts at row 0
+            head = self.max_len - self.next_idx
+            self.buf_state[self.next_idx:] = state[:head]
+            self.buf_other[self.next_idx:] = other[:head]
+            self.if_full = True
+            end -= self.max_len
+            self.buf_state[:end] = state[-end:] if end else state[:0]
+            self.buf_other[:end] = other[-end:] if end else other[:0]
+        else:
+            self.buf_state[self.next_idx:end] = state
+            self.buf_other[self.next_idx:end] = other
+        self.next_idx = end
+
+    def sample_batch(self, batch_size, indices=None):
+        """(reward, mask, action, state, next_state): next_state is row i+1 (time adjacency)."""
+        if indices is None:
+            indices = torch.randint(self.now_len - 1, size=(batch_size,), device=self.device)
+        r_m_a = self.buf_other[indices]
+        return r_m_a[:, 0:1], r_m_a[:, 1:2], r_m_a[:, 2:], self.buf_state[indices], self.buf_state[indices + 1]
+
+    def sample_all(self):
+        """(reward, mask, action, noise, state) of every stored on-policy transition, in storage order."""
+        other = self.buf_other[:self.now_len]
+        a = self.action_dim
+        return other[:, 0], other[:, 1], other[:, 2:2 + a], other[:, 2 + a:], self.buf_state[:self.now_len]
+
+    def update_now_len_before_sample(self):
+        self.now_len = self.max_len if self.if_full else self.next_idx
+
+    def empty_buffer_before_explore(self):
+        self.next_idx = 0
+        self.now_len = 0
+        self.if_full = False
+
+
+class TrajectoryBuffer:
+    """Time-major on-policy store for N lock-stepped env lanes: state [T,N,D], reward/mask [T,N], action/noise [T,N,A]."""
+
+    def __init__(self, horizon, num_envs, state_dim, action_dim, device):
+        self.device = torch.device(device)
+        self.horizon, self.num_envs, self.state_dim, self.action_dim = horizon, num_envs, state_dim, action_dim
+        f = dict(dtype=torch.float32, device=self.device)
+        # one extra state slot: the step kernel writes the successor observation of slot t straight into slot t+1
+        self.state = torch.zeros((horizon + 1, num_envs, state_dim), **f)
+        self.reward = torch.zeros((horizon, num_envs), **f)
+        self.mask = torch.zeros((horizon, num_envs), **f)
+        self.action = torch.zeros((horizon, num_envs, action_dim), **f)
+        self.noise = torch.zeros((horizon, num_envs, action_dim), **f)
+        self.done = torch.zeros((horizon, num_envs), dtype=torch.uint8, device=self.device)
+        self.length = 0  # filled time slots
+        self.if_on_policy = True
+
+    @property
+    def now_len(self):
+        return self.length * self.num_envs
+
+    def update_now_len_before_sample(self):
+        pass
+
+    def empty_buffer_before_explore(self):
+        self.length = 0
+
+    def sample_all(self):
+        T = self.length
+        flat = lambda x: x[:T].reshape(T * self.num_envs, *x.shape[2:])  # noqa: E731
+        return flat(self.reward), flat(self.mask), flat(self.action), flat(self.noise), flat(self.state)

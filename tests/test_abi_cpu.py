@@ -1,0 +1,74 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every function include/pime_hip.h declares,
+the binding covers them all, and the product path refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "pime_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pime_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_library_binding_agree():
+    import pime_amd.native as nt
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    lib = C.CDLL(nt.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in pime_hip.h but not exported by libpime_hip.so"
+    assert sorted(nt.EXPORTS) == declared, "ctypes binding and header disagree"
+    assert nt.lib().pime_abi_version() == 3
+
+
+def test_cfg_struct_layout_matches_c():
+    """pime_env_cfg_default round-trips through the ctypes struct: catches field-order/padding drift."""
+    import pime_amd.native as nt
+    cfg = nt.EnvCfg()
+    nt.check(nt.lib().pime_env_cfg_default(nt.ENV_PH, C.byref(cfg)))
+    assert (cfg.kind, cfg.max_steps, cfg.reward_type, cfg.integral_bound, cfg.resample_every) == (0, 50, 1, 1, 1)
+    assert (cfg.range_lo[0], cfg.range_hi[0], cfg.range_lo[1], cfg.range_hi[1]) == (0.005, 0.015, 0.0015, 0.0025)
+    assert (cfg.init_lo[0], cfg.init_hi[0], cfg.init_lo[1], cfg.init_hi[1]) == (0.0, 50.0, 3.0, 11.0)
+    assert (cfg.ph_sample_t, cfg.ph_u_high, cfg.ph_table_scale, cfg.integral_max) == (20.0, 1.5, 1e5, 25.0)
+    nt.check(nt.lib().pime_env_cfg_default(nt.ENV_WT, C.byref(cfg)))
+    assert (cfg.max_steps, cfg.wt_n_discrete, cfg.wt_G, cfg.wt_dt, cfg.wt_noise_scale, cfg.wt_pmax) == \
+        (200, 20, 980.0, 0.1, 0.01, 10.0)
+    assert (cfg.range_lo[2], cfg.range_hi[2]) == (0.07, 0.17)
+    assert nt.lib().pime_env_cfg_default(7, C.byref(cfg)) != 0 and "kind" in nt.last_error()
+
+
+def test_native_table_matches_oracle_bitwise(ph_table_oracle):
+    import pime_amd.native as nt
+    np.testing.assert_array_equal(nt.ph_table_build(), ph_table_oracle)
+
+
+def test_mlp_pack_size_and_argument_errors():
+    import pime_amd.native as nt
+    L = nt.lib()
+    # critic md 128, D 3: 128*4 + 2*(16384 + 128) + 128 + 4
+    assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 128) == 128 * 4 + 2 * (128 * 128 + 128) + 128 + 4
+    assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 3, 1, 128) * 4 < 160 * 1024
+    assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 256) == 0 and "256" in nt.last_error()
+    assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 3, 3, 128) == 0
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must fail loudly, not compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import pime_amd.native as nt
+    from pime_amd.vec_env import VecPH
+    assert nt.device_count() == 0
+    with pytest.raises(nt.PimeError):
+        VecPH(4, device="cpu")
+    cfg = nt.EnvCfg()
+    nt.check(nt.lib().pime_env_cfg_default(nt.ENV_WT, C.byref(cfg)))
+    assert not nt.lib().pime_env_create(C.byref(cfg))
+    assert "no HIP device" in nt.last_error() or "fallback" in nt.last_error()
