@@ -67,6 +67,13 @@ class KernelTimer:
         return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.pairs.items()}
 
 
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def build_stack(device, rank, world, dp):
     from pime_amd import gym_control
     from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
@@ -101,7 +108,8 @@ def cpu_baseline():
     from oracle.cpu_stack import OracleBackend, OracleVecEnv
     from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
     from pime_amd.elegantrl.replay import TrajectoryBuffer
-    cores = os.cpu_count() or 1
+    # the box's CPU share, not the host's core count (oversubscribing torch's intra-op pool stalls for minutes)
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     n = 2048
     env = OracleVecEnv("ph", n, seed=0)
@@ -153,8 +161,11 @@ def main():
             dp.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    log("stack built; warmup")
+    for i in range(args.warmup):
         one_step(env, agent, buf)
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
     sync()
     timer.enabled = True
     t_roll = t_upd = 0.0
@@ -165,6 +176,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    log(f"timed region: {dt:.3f}s for {args.steps} steps")
     if dp is not None:
         dt = dp.max_over_ranks(dt)
         total = dp.sum_over_ranks(total)
@@ -217,7 +229,9 @@ def main():
                          "hand_written_kernels_per_step": per_step},
     }
     if not args.no_cpu_baseline and world == 1:
+        log("cpu baseline (oracle env + torch CPU update) ...")
         out["cpu_baseline"] = cpu_baseline()
+        log("cpu baseline done")
     print(json.dumps(out))
 
 
