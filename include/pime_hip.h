@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 3
+#define PIME_ABI_VERSION 4
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -185,6 +185,48 @@ int pime_mlp_pack(int32_t kind, int32_t D, int32_t Di, int32_t md, const float* 
                   pime_stream stream);
 int pime_mlp_forward(int32_t kind, const float* x, int32_t M, int32_t D, int32_t Di, int32_t md, const float* packed,
                      float* out, pime_stream stream);
+
+/* -- fused PPO minibatch gradients ------------------------------------------------------------------------------
+ * replaces, per optimizer step of AgentPPO.update_net (elegantrl/agent.py:629-657): the minibatch gather (:632-636),
+ * compute_logprob of the residual actors (net_residual.py:48-54,182-190), the clipped surrogate + entropy proxy
+ * (:637-645), CriticAdv forward + SmoothL1 (:648-649), the united loss (:652) and `obj_united.backward()` (:654-655)
+ * -- i.e. everything between drawing the indices and `optimizer.step()`, which stays in PyTorch.
+ * Three launches: critic fwd+bwd, actor fwd+bwd, one weight-gradient kernel (csrc/ppo_train.hip).
+ *
+ * pime_ppo_net describes one net: the same (kind, D, Di, md, params) as pime_mlp_pack; `grads` are the .grad tensors in
+ * the same order and are ACCUMULATED into with float atomics (zero them first); img_fwd = pime_mlp_pack image,
+ * img_bwd = pime_ppo_pack_bwd image (both must be re-packed after the weights change); workspace =
+ * pime_ppo_workspace_floats(kind, B, md) floats.  action_dim must be 1. */
+typedef struct pime_ppo_net {
+    int32_t kind, D, Di, md;
+    const float* const* params;   /* [host] array of [dev] pointers, W,b pairs */
+    float* const* grads;          /* [host] array of [dev] pointers, same order */
+    const float* a_std_log;       /* [dev] actor only: the [1,1] log-std parameter */
+    float* g_a_std_log;           /* [dev] actor only: its gradient (accumulated) */
+    const float* img_fwd;         /* [dev] */
+    const float* img_bwd;         /* [dev] */
+    float* workspace;             /* [dev] */
+} pime_ppo_net;
+
+typedef struct pime_ppo_batch {
+    const float* state;           /* [dev] float32[L, D] trajectory observations */
+    const float* action;          /* [dev] float32[L] pre-tanh actions that were taken */
+    const float* logprob;         /* [dev] float32[L] their log-probabilities under the old policy */
+    const float* adv;             /* [dev] float32[L] normalised advantages */
+    const float* r_sum;           /* [dev] float32[L] reward sums (critic targets) */
+    const int64_t* indices;       /* [dev] int64[B] minibatch rows (torch.randint) */
+    int32_t B;
+} pime_ppo_batch;
+
+int64_t pime_ppo_bwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t md);
+int64_t pime_ppo_workspace_floats(int32_t kind, int32_t B, int32_t md);
+int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const float* const* params, float* image,
+                      pime_stream stream);
+/* critic_scale: [dev] float32[1] = 1 / (r_sum[indices].std() + 1e-5)  (agent.py:652)
+ * loss_sums:    [dev] float32[4], ACCUMULATED: sum(-min(surr1,surr2)), sum(exp(logp)*logp), sum(smooth_l1), unused */
+int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* batch,
+                            float ratio_clip, float lambda_entropy, const float* critic_scale, float* loss_sums,
+                            pime_stream stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -31,3 +31,9 @@ class HipBackend:
         if not ops.PackedMLP.supported(kind, module.state_dim, getattr(module, "integrator_dim", 0), md):
             return None
         return ops.PackedMLP.from_module(module)
+
+    def fused_ppo(self, act, cri, max_batch):
+        """ops.FusedPPOGrad for these nets, or False when their shape has no fused kernel."""
+        if not ops.FusedPPOGrad.supported(act, cri):
+            return False
+        return ops.FusedPPOGrad(act, cri, max_batch)

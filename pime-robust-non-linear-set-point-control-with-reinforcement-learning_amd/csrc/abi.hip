@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "env_state.hpp"
+#include "ppo_train.hpp"
 
 namespace pime {
 
@@ -31,6 +32,14 @@ int64_t mlp_packed_floats(int, int, int, int);
 int mlp_check(int, int, int, int);
 int launch_mlp_pack(int, int, int, int, const float* const*, float*, hipStream_t);
 int launch_mlp_forward(int, const float*, int, int, int, int, const float*, float*, hipStream_t);
+
+// ppo_train.hip
+int64_t ppo_bwd_image_floats(int, int, int, int);
+int64_t ppo_workspace_floats(int, int, int);
+int launch_pack_bwd(int, int, int, int, const float* const*, float*, hipStream_t);
+int launch_ppo_net(int, int, const PpoArgs&, hipStream_t);
+int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
+int launch_dw(const DwArgs&, int, hipStream_t);
 
 }  // namespace pime
 
@@ -523,6 +532,63 @@ int pime_mlp_forward(int32_t kind, const float* x, int32_t M, int32_t D, int32_t
                      float* out, pime_stream stream) {
     PIME_REQUIRE(x != nullptr && packed != nullptr && out != nullptr, "pime_mlp_forward: NULL x/packed/out");
     return launch_mlp_forward(kind, x, M, D, Di, md, packed, out, static_cast<hipStream_t>(stream));
+}
+
+int64_t pime_ppo_bwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t md) {
+    if (mlp_check(kind, D, Di, md) != PIME_OK) return 0;
+    return ppo_bwd_image_floats(kind, D, Di, md);
+}
+
+int64_t pime_ppo_workspace_floats(int32_t kind, int32_t B, int32_t md) {
+    if (B < 1 || (md != 64 && md != 128)) { set_error("pime_ppo_workspace_floats: B=%d md=%d", B, md); return 0; }
+    return ppo_workspace_floats(kind, B, md);
+}
+
+int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const float* const* params, float* image,
+                      pime_stream stream) {
+    PIME_REQUIRE(params != nullptr && image != nullptr, "pime_ppo_pack_bwd: NULL params/image");
+    return launch_pack_bwd(kind, D, Di, md, params, image, static_cast<hipStream_t>(stream));
+}
+
+static int check_net(const pime_ppo_net* n, bool actor) {
+    PIME_REQUIRE(n != nullptr, "pime_ppo_minibatch_grad: NULL net");
+    if (int rc = mlp_check(n->kind, n->D, n->Di, n->md)) return rc;
+    PIME_REQUIRE(n->params && n->grads && n->img_fwd && n->img_bwd && n->workspace, "pime_ppo_net: NULL member");
+    PIME_REQUIRE(actor == (n->kind != PIME_MLP_CRITIC), "pime_ppo_minibatch_grad: actor/critic kinds swapped");
+    if (actor) PIME_REQUIRE(n->a_std_log && n->g_a_std_log, "pime_ppo_net (actor): NULL a_std_log / gradient");
+    const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
+    for (int i = 0; i < np; ++i) PIME_REQUIRE(n->params[i] && n->grads[i], "pime_ppo_net: params/grads[%d] NULL", i);
+    return PIME_OK;
+}
+
+int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b,
+                            float ratio_clip, float lambda_entropy, const float* critic_scale, float* loss_sums,
+                            pime_stream stream) {
+    if (int rc = check_net(actor, true)) return rc;
+    if (int rc = check_net(critic, false)) return rc;
+    PIME_REQUIRE(b && b->state && b->action && b->logprob && b->adv && b->r_sum && b->indices && b->B >= 1,
+                 "pime_ppo_minibatch_grad: bad batch");
+    PIME_REQUIRE(critic_scale && loss_sums, "pime_ppo_minibatch_grad: NULL critic_scale / loss_sums");
+    PIME_REQUIRE(actor->D == critic->D, "actor and critic state_dim differ");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DwArgs dw{};
+    const pime_ppo_net* nets[2] = {critic, actor};
+    for (int k = 0; k < 2; ++k) {
+        const pime_ppo_net* n = nets[k];
+        PpoArgs a{};
+        a.state = b->state; a.action = b->action; a.logprob = b->logprob; a.adv = b->adv; a.r_sum = b->r_sum;
+        a.indices = b->indices; a.B = b->B; a.D = n->D; a.Di = n->Di;
+        a.a_std_log = n->a_std_log; a.critic_scale = critic_scale; a.ratio_clip = ratio_clip; a.lambda_entropy = lambda_entropy;
+        a.img_fwd = n->img_fwd; a.img_bwd = n->img_bwd;
+        const int64_t ntiles = (b->B + 31) / 32;
+        a.stash = n->workspace;
+        a.dout = n->workspace + (ppo_workspace_floats(n->kind, b->B, n->md) - ntiles * 32);
+        a.loss_sums = loss_sums; a.g_std = n->g_a_std_log;
+        if (int rc = launch_ppo_net(n->kind, n->md, a, s)) return rc;
+        dw.njobs += build_dw_jobs(n->kind, n->md, a, n->params, n->grads, dw.job + dw.njobs);
+    }
+    dw.tiles_per_wg = 4;
+    return launch_dw(dw, b->B, s);
 }
 
 }  // extern "C"

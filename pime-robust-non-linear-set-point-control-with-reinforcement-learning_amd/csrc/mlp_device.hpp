@@ -1,0 +1,202 @@
+// Device-side building blocks shared by the fused MLP forward (mlp_mfma.hip) and the fused PPO minibatch
+// gradient kernels (ppo_train.hip): packed-image layout, MFMA layer chain, first layer / head, tanh.
+#pragma once
+#include "pime_common.hpp"
+
+namespace pime {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum { MLP_CRITIC = 0, MLP_PLAIN_ACTOR = 1, MLP_MODULAR_ACTOR = 2 };
+
+// feature index inside a 32-wide tile held by accumulator register s of lane-half h (C/D map of 32x32 MFMA)
+__host__ __device__ __forceinline__ constexpr int feat32(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+// ---- packed image layout (identical in HBM and LDS) -------------------------------------------------------
+// FIRST  layer (D_in -> 32*OT):   [D_in+1][OT][16][2]        column j of W for feature feat(ot,r,h); row D_in = bias
+//                                 (j outermost so every LDS read of the unrolled (ot,r) loop is base + immediate)
+// MFMA   layer (32*KT -> 32*OT):  [KT*16][64][OT]            W[ot*32 + (lane&31)][kt*32 + feat32(s, lane>>5)]
+// VEC    (bias / head weights):   [OT][16][2]                v[ot*32 + feat32(r,h)]
+struct MlpLayout {
+    int T;          // md / 32
+    int off[12];    // float offsets of the segments
+    int total;      // floats (multiple of 4)
+};
+
+__host__ __device__ inline int align4(int v) { return (v + 3) & ~3; }
+
+__host__ __device__ inline MlpLayout mlp_layout(int kind, int D, int Di, int md) {
+    MlpLayout L{};
+    const int T = md / 32;
+    L.T = T;
+    int o = 0;
+    auto seg = [&](int idx, int floats) { L.off[idx] = o; o = align4(o + floats); };
+    if (kind == MLP_MODULAR_ACTOR) {
+        const int Do = D - Di, H = T / 2;
+        seg(0, T * 32 * (Do + 1));     // other_net.0 (FIRST)
+        seg(1, T * 16 * 64 * H);       // other_net.2 (MFMA md -> md/2)
+        seg(2, H * 32);                // other_net.2 bias
+        seg(3, T * 32 * (Di + 1));     // integrator_net.0 (FIRST)
+        seg(4, T * 16 * 64 * H);       // integrator_net.2
+        seg(5, H * 32);
+        seg(6, T * 16 * 64 * T);       // net.0 (MFMA md -> md)
+        seg(7, T * 32);                // net.0 bias
+        seg(8, T * 32);                // net.2 weights (HEAD)
+        seg(9, 4);                     // net.2 bias
+    } else {
+        seg(0, T * 32 * (D + 1));      // net.0 (FIRST)
+        seg(1, T * 16 * 64 * T);       // net.2
+        seg(2, T * 32);
+        seg(3, T * 16 * 64 * T);       // net.4
+        seg(4, T * 32);
+        seg(5, T * 32);                // net.6 weights (HEAD)
+        seg(6, 4);                     // net.6 bias
+    }
+    L.total = o;
+    return L;
+}
+
+__device__ inline void pack_first(float* dst, const float* W, const float* b, int Din, int ldw, int col0, int OT,
+                                  int tid, int nthr) {
+    const int per = OT * 32, n = per * (Din + 1);
+    for (int idx = tid; idx < n; idx += nthr) {
+        const int j = idx / per, q = idx % per;
+        const int h = q & 1, r = (q >> 1) & 15, ot = q >> 5;
+        const int f = ot * 32 + feat32(r, h);
+        dst[idx] = j < Din ? W[(size_t)f * ldw + col0 + j] : b[f];
+    }
+}
+
+__device__ inline void pack_mfma(float* dst, const float* W, int KT, int OT, int tid, int nthr) {
+    const int K = KT * 32, n = KT * 16 * 64 * OT;
+    for (int idx = tid; idx < n; idx += nthr) {
+        const int ot = idx % OT, lane = (idx / OT) & 63, ks = idx / (OT * 64);
+        const int kt = ks >> 4, s = ks & 15;
+        dst[idx] = W[(size_t)(ot * 32 + (lane & 31)) * K + kt * 32 + feat32(s, lane >> 5)];
+    }
+}
+
+// The same image for the TRANSPOSED matrix: the backward chain dH_in = W^T dZ is a forward layer whose weight is
+// V = W^T ([K_in x O] seen as out x in).  W is nn.Linear [O][K]; KT = O/32 input tiles, OT = K/32 output tiles.
+__device__ inline void pack_mfma_t(float* dst, const float* W, int KT, int OT, int tid, int nthr) {
+    const int Kin = OT * 32, n = KT * 16 * 64 * OT;  // W row length = K_in of the forward layer
+    for (int idx = tid; idx < n; idx += nthr) {
+        const int ot = idx % OT, lane = (idx / OT) & 63, ks = idx / (OT * 64);
+        const int kt = ks >> 4, s = ks & 15;
+        // V[ot*32 + i][kt*32 + feat] = W[kt*32 + feat][ot*32 + i]
+        dst[idx] = W[(size_t)(kt * 32 + feat32(s, lane >> 5)) * Kin + ot * 32 + (lane & 31)];
+    }
+}
+
+__device__ inline void pack_vec(float* dst, const float* v, int OT, int tid, int nthr) {
+    for (int idx = tid; idx < OT * 32; idx += nthr) {
+        const int h = idx & 1, r = (idx >> 1) & 15, ot = idx >> 5;
+        dst[idx] = v[ot * 32 + feat32(r, h)];
+    }
+}
+
+// hipcc treats the (read-only after staging) LDS image as loop invariant and hoists bias/head/first-layer reads
+// out of the persistent tile loop, then spills them (1.2 KB/lane of scratch).  A compiler-only memory barrier per
+// tile and per layer keeps each read next to its use.
+#define PIME_NO_HOIST() asm volatile("" ::: "memory")
+
+// ---- forward --------------------------------------------------------------------------------------------------
+// tanh in ~12 VALU ops with few live temporaries (ocml's tanhf inlined 64x per layer drove the kernel to the
+// 256-VGPR cap).  |x| >= 0.25: 1 - 2/(e^{2|x|}+1) via v_exp_f32/v_rcp_f32 (abs err < 1.5e-7); below that the
+// cancellation is avoided with the odd Taylor polynomial to x^9 (rel err < 1e-7 at 0.25).
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);  // e^{2|x|}
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    const float x2 = x * x;
+    const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.021869488536155203f, -0.053968253968253971f),
+                                                   0.13333333333333333f), -0.33333333333333331f), 1.0f);
+    const float t = ax < 0.25f ? small : big;
+    return copysignf(t, x);
+}
+
+template <int ACT>
+__device__ __forceinline__ float activate(float v) {
+    if constexpr (ACT == 0) return v > 0.f ? v : 0.f;  // nn.ReLU
+    else if constexpr (ACT == 1) return fast_tanh(v);   // nn.Tanh
+    else return v;                                      // identity (backward chains)
+}
+
+// y[ot][r] = act( b[f] + sum_j x[m][col0 + j] * W[f][j] ),  f = ot*32 + feat32(r, h)
+template <int OT, int ACT>
+__device__ __forceinline__ void layer_first(const float* __restrict__ w0, const float* __restrict__ xrow, int Din,
+                                            int h, f32x16 (&out)[OT]) {
+    const float* wb = w0 + Din * (OT * 32) + h;  // bias row
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = wb[(ot * 16 + r) * 2];
+    for (int j = 0; j < Din; ++j) {
+        const float xj = xrow[j];
+        const float* wj = w0 + j * (OT * 32) + h;
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[ot][r] = fmaf(xj, wj[(ot * 16 + r) * 2], out[ot][r]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = activate<ACT>(out[ot][r]);
+}
+
+template <int OT>
+struct WFrag;
+template <>
+struct WFrag<4> { using type = float4; };
+template <>
+struct WFrag<2> { using type = float2; };
+template <>
+struct WFrag<1> { using type = float; };
+
+__device__ __forceinline__ float wfrag_get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ float wfrag_get(const float2& v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ float wfrag_get(const float& v, int) { return v; }
+
+// out = act( W * in + b ) on the matrix cores.  in: KT tiles of 32 features, out: OT tiles.
+template <int KT, int OT, int ACT, bool HAS_BIAS = true>
+__device__ __forceinline__ void layer_mfma(const float* __restrict__ wp, const float* __restrict__ bp, int lane,
+                                           const f32x16 (&in)[KT], f32x16 (&out)[OT]) {
+    using Frag = typename WFrag<OT>::type;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = HAS_BIAS ? bp[(ot * 16 + r) * 2 + h] : 0.f;
+    const Frag* wl = reinterpret_cast<const Frag*>(wp) + lane;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if ((s & 3) == 0) PIME_NO_HOIST();  // bound the W-fragment prefetch depth to 4 k-steps (<= 16 VGPRs)
+            const Frag w = wl[(kt * 16 + s) * 64];
+            const float b = in[kt][s];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+                out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfrag_get(w, ot), b, out[ot], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = activate<ACT>(out[ot][r]);
+}
+
+template <int KT>
+__device__ __forceinline__ float layer_head(const float* __restrict__ w, float bias, int lane, const f32x16 (&in)[KT]) {
+    const int h = lane >> 5;
+    float acc = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc = fmaf(in[kt][r], w[(kt * 16 + r) * 2 + h], acc);
+    acc += __shfl_xor(acc, 32);  // the other lane half holds the other 16 features of every tile
+    return acc + bias;
+}
+
+}  // namespace pime

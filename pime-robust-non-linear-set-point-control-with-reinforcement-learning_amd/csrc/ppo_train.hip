@@ -1,0 +1,535 @@
+// Fused PPO minibatch gradients on the gfx950 f32 matrix cores: the loss gradient and the whole fwd+bwd of the small
+// actor / critic MLPs for one minibatch in three launches (critic net, actor net, weight gradients), replacing
+// ~150 PyTorch/rocBLAS launches per optimizer step (profiles/r01_a_*: the skinny K=65536 rocBLAS GEMMs run at
+// 200-250 us each and made the update 99 % of the headline metric's time).
+//
+// replaces (reference, /root/reference/elegantrl/agent.py:629-657): minibatch gather, ActorResidual*.compute_logprob
+// (net_residual.py:48-54,182-190), clipped surrogate + entropy proxy (:637-645), CriticAdv forward + SmoothL1 (:648-649),
+// `obj_united.backward()` (:654-655).  The optimizer step itself stays in PyTorch (torch.optim.Adam).
+//
+// Structure (DESIGN.md "ppo_minibatch_grad"):
+//  net kernel, phase A (forward image in LDS):  per 32-sample tile, one wave: gather the rows by index, run the net with
+//     activations in registers (mlp_device.hpp), stash the hidden activations the backward needs in HBM in fragment
+//     order (every store is one contiguous 256-B segment), evaluate the loss and its gradient w.r.t. the net output.
+//  net kernel, phase B (transposed image in LDS): the same wave re-reads its stash and chains dZ_l -> dH_{l-1} through
+//     the matrix cores exactly like a forward (the weight operand is W^T), stashing every dZ_l.
+//  dW kernel: for every layer the TN GEMM dW_l = dZ_l^T H_{l-1} over the sample axis.  The stashes are sample-on-lane;
+//     the MFMA operands need feature-on-lane, so each 32x32 tile is transposed through a 33-float-pitch LDS image
+//     (conflict-free both ways).  First-layer activations are recomputed from the 3-float state instead of stashed.
+//     Partial products are combined with float atomics into the (zeroed) gradient tensors.
+#include "mlp_device.hpp"
+#include "ppo_train.hpp"
+
+namespace pime {
+
+constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
+
+// ---- backward image ------------------------------------------------------------------------------------------------
+struct BwdLayout {
+    int T, off[8], total;
+};
+
+__host__ __device__ inline BwdLayout bwd_layout(int kind, int D, int Di, int md) {
+    BwdLayout L{};
+    const int T = md / 32;
+    L.T = T;
+    int o = 0;
+    auto seg = [&](int idx, int floats) { L.off[idx] = o; o = align4(o + floats); };
+    if (kind == MLP_MODULAR_ACTOR) {
+        const int Do = D - Di, H = T / 2;
+        seg(0, T * 32 * (Do + 1));   // other_net.0 (FIRST, recomputed for act')
+        seg(1, T * 32 * (Di + 1));   // integrator_net.0 (FIRST)
+        seg(2, T * 32);              // net.2 weights (head, VEC)
+        seg(3, T * 16 * 64 * T);     // net.0 transposed: dZn0 (T tiles) -> dcat (T tiles)
+        seg(4, H * 16 * 64 * T);     // other_net.2 transposed: dZo2 (H tiles) -> dh_o1 (T tiles)
+        seg(5, H * 16 * 64 * T);     // integrator_net.2 transposed
+    } else {
+        seg(0, T * 32 * (D + 1));    // net.0 (FIRST)
+        seg(1, T * 32);              // net.6 weights (head, VEC)
+        seg(2, T * 16 * 64 * T);     // net.4 transposed: dZ3 -> dH2
+        seg(3, T * 16 * 64 * T);     // net.2 transposed: dZ2 -> dH1
+    }
+    L.total = o;
+    return L;
+}
+
+struct PackBwdArgs {
+    const float* p[12];
+    int kind, D, Di, md;
+};
+
+__global__ void mlp_pack_bwd_kernel(PackBwdArgs a, float* __restrict__ out) {
+    const BwdLayout L = bwd_layout(a.kind, a.D, a.Di, a.md);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x, T = L.T;
+    if (a.kind == MLP_MODULAR_ACTOR) {
+        const int Do = a.D - a.Di, H = T / 2;
+        pack_first(out + L.off[0], a.p[0], a.p[1], Do, Do, 0, T, tid, nthr);
+        pack_first(out + L.off[1], a.p[4], a.p[5], a.Di, a.Di, 0, T, tid, nthr);
+        pack_vec(out + L.off[2], a.p[10], T, tid, nthr);
+        pack_mfma_t(out + L.off[3], a.p[8], T, T, tid, nthr);
+        pack_mfma_t(out + L.off[4], a.p[2], H, T, tid, nthr);
+        pack_mfma_t(out + L.off[5], a.p[6], H, T, tid, nthr);
+    } else {
+        pack_first(out + L.off[0], a.p[0], a.p[1], a.D, a.D, 0, T, tid, nthr);
+        pack_vec(out + L.off[1], a.p[6], T, tid, nthr);
+        pack_mfma_t(out + L.off[2], a.p[4], T, T, tid, nthr);
+        pack_mfma_t(out + L.off[3], a.p[2], T, T, tid, nthr);
+    }
+}
+
+// ---- workspace ------------------------------------------------------------------------------------------------------
+// stash[(tile * NT + t) * 1024 + r * 64 + lane]: register r of lane `lane` of stashed tile t of sample-tile `tile`.
+// critic / plain actor, NT = 5T:  H2 [0,T)  H3 [T,2T)  dZ3 [2T,3T)  dZ2 [3T,4T)  dZ1 [4T,5T)
+// modular actor,        NT = 6T:  cat [0,T) n0 [T,2T)  dZn0 [2T,3T) dZcat [3T,4T) dZo1 [4T,5T) dZi1 [5T,6T)
+__host__ __device__ inline int stash_tiles(int kind, int T) { return kind == MLP_MODULAR_ACTOR ? 6 * T : 5 * T; }
+
+template <int NTL>
+__device__ __forceinline__ void stash_store(float* __restrict__ base, int lane, const f32x16 (&a)[NTL]) {
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) base[(t * 16 + r) * 64 + lane] = a[t][r];
+}
+template <int NTL>
+__device__ __forceinline__ void stash_load(const float* __restrict__ base, int lane, f32x16 (&a)[NTL]) {
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[t][r] = base[(t * 16 + r) * 64 + lane];
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_grad_from_output(float h) {
+    if constexpr (ACT == 0) return h > 0.f ? 1.f : 0.f;  // ReLU'
+    else return 1.f - h * h;                              // tanh'
+}
+
+template <int NTL, int ACT>
+__device__ __forceinline__ void times_act_grad(f32x16 (&d)[NTL], const f32x16 (&h)[NTL]) {
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[t][r] *= act_grad_from_output<ACT>(h[t][r]);
+}
+
+// dH_L = w_head (x) dOut in accumulator layout
+template <int NTL>
+__device__ __forceinline__ void head_backward(const float* __restrict__ w, int lane, float dout, f32x16 (&d)[NTL]) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[t][r] = w[(t * 16 + r) * 2 + h] * dout;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+constexpr int kTrainThreads = 512;
+
+template <int T, int KIND>
+__global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool MODULAR = KIND == MLP_MODULAR_ACTOR;
+    constexpr bool CRITIC = KIND == MLP_CRITIC;
+    constexpr int ACT = CRITIC ? 0 : 1;
+    constexpr int NT = MODULAR ? 6 * T : 5 * T;
+    constexpr int H = T / 2 > 0 ? T / 2 : 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6, h = lane >> 5;
+    const int ntiles = (a.B + 31) / 32;
+    const float invB = 1.0f / (float)a.B;
+
+    // ------------------------------------------------------------------ phase A: forward + loss gradient
+    const MlpLayout L = mlp_layout(KIND, a.D, a.Di, T * 32);
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.img_fwd);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < L.total / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f, gstd = 0.f;
+    for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
+        PIME_NO_HOIST();
+        const int pos = tile * 32 + (lane & 31);
+        const bool valid = pos < a.B;
+        const long long row = a.indices[valid ? pos : a.B - 1];
+        const float* xrow = a.state + (size_t)row * a.D;
+        float* st = a.stash + (size_t)tile * NT * 1024;
+        float y;
+        if constexpr (MODULAR) {
+            const int Do = a.D - a.Di;
+            f32x16 cat[T];
+            {
+                f32x16 a0[T];
+                layer_first<T, 1>(lds + L.off[0], xrow, Do, h, a0);
+                PIME_NO_HOIST();
+                layer_mfma<T, H, 1>(lds + L.off[1], lds + L.off[2], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
+            }
+            {
+                f32x16 a0[T];
+                PIME_NO_HOIST();
+                layer_first<T, 1>(lds + L.off[3], xrow + Do, a.Di, h, a0);
+                PIME_NO_HOIST();
+                layer_mfma<T, H, 1>(lds + L.off[4], lds + L.off[5], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
+            }
+            stash_store<T>(st, lane, cat);
+            f32x16 n0[T];
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 1>(lds + L.off[6], lds + L.off[7], lane, cat, n0);
+            stash_store<T>(st + T * 1024, lane, n0);
+            PIME_NO_HOIST();
+            y = layer_head<T>(lds + L.off[8], lds[L.off[9]], lane, n0);
+        } else {
+            f32x16 a0[T], a1[T];
+            layer_first<T, ACT>(lds + L.off[0], xrow, a.D, h, a0);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, ACT>(lds + L.off[1], lds + L.off[2], lane, a0, a1);
+            stash_store<T>(st, lane, a1);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, ACT>(lds + L.off[3], lds + L.off[4], lane, a1, a0);
+            stash_store<T>(st + T * 1024, lane, a0);
+            PIME_NO_HOIST();
+            y = layer_head<T>(lds + L.off[5], lds[L.off[6]], lane, a0);
+        }
+        // loss and d(loss)/d(net output) for this sample
+        float dout = 0.f;
+        if (valid) {
+            if constexpr (CRITIC) {
+                const float d = y - a.r_sum[row], ad = fabsf(d);         // SmoothL1, beta = 1 (agent.py:567,649)
+                const float l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+                const float g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+                dout = g * a.critic_scale[0] * invB;
+                if (h == 0) s0 += l;
+            } else {
+                const float asl = a.a_std_log[0], inv_sigma = __expf(-asl);
+                const float z = (y - a.action[row]) * inv_sigma;
+                const float logp = -(asl + kLogSqrt2Pi + 0.5f * z * z);           // compute_logprob
+                const float ratio = __expf(logp - a.logprob[row]);
+                const float lo = 1.f - a.ratio_clip, hi = 1.f + a.ratio_clip;
+                const float clamped = fminf(fmaxf(ratio, lo), hi);
+                const float adv = a.adv[row];
+                const float u = adv * ratio, c = adv * clamped;                   // agent.py:639-641
+                // torch.min backward: the smaller operand gets the gradient, ties split it; clamp passes it inside [lo,hi]
+                const float w_u = u < c ? 1.f : (u == c ? 0.5f : 0.f);
+                const float w_c = c < u ? 1.f : (u == c ? 0.5f : 0.f);
+                const bool in_range = ratio >= lo && ratio <= hi;
+                const float g_sur = w_u * u + (in_range ? w_c * u : 0.f);         // d min / d logp  (d ratio/d logp = ratio)
+                const float p = __expf(logp);
+                const float ent = p * logp;                                       // entropy proxy (:643)
+                const float g_logp = (-g_sur + a.lambda_entropy * p * (logp + 1.f)) * invB;
+                dout = g_logp * (-z * inv_sigma);                                 // d logp / d a_avg
+                if (h == 0) {
+                    gstd += g_logp * (z * z - 1.f);                               // d logp / d a_std_log
+                    s0 += -fminf(u, c);
+                    s1 += ent;
+                }
+            }
+        }
+        if (h == 0 && pos < ntiles * 32) a.dout[pos] = dout;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); gstd = wave_sum(gstd);
+    if (lane == 0) {
+        if constexpr (CRITIC) atomicAdd(&a.loss_sums[2], s0);
+        else { atomicAdd(&a.loss_sums[0], s0); atomicAdd(&a.loss_sums[1], s1); atomicAdd(a.g_std, gstd); }
+    }
+
+    // ------------------------------------------------------------------ phase B: backward chain
+    __syncthreads();  // every wave is done reading the forward image
+    const BwdLayout Lb = bwd_layout(KIND, a.D, a.Di, T * 32);
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.img_bwd);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < Lb.total / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
+        PIME_NO_HOIST();
+        const int pos = tile * 32 + (lane & 31);
+        const long long row = a.indices[pos < a.B ? pos : a.B - 1];
+        const float* xrow = a.state + (size_t)row * a.D;
+        float* st = a.stash + (size_t)tile * NT * 1024;
+        const float dout = a.dout[pos];  // written by this very wave in phase A
+        if constexpr (MODULAR) {
+            const int Do = a.D - a.Di;
+            f32x16 dcat[T];
+            {
+                f32x16 dn0[T], n0[T];
+                head_backward<T>(lds + Lb.off[2], lane, dout, dn0);
+                stash_load<T>(st + T * 1024, lane, n0);
+                times_act_grad<T, 1>(dn0, n0);
+                stash_store<T>(st + 2 * T * 1024, lane, dn0);                    // dZn0
+                PIME_NO_HOIST();
+                layer_mfma<T, T, 2, false>(lds + Lb.off[3], nullptr, lane, dn0, dcat);
+            }
+            {
+                f32x16 cat[T];
+                stash_load<T>(st, lane, cat);
+                times_act_grad<T, 1>(dcat, cat);
+                stash_store<T>(st + 3 * T * 1024, lane, dcat);                   // dZcat = [dZo2 | dZi2]
+            }
+            {
+                f32x16 d1[T], h1[T];
+                PIME_NO_HOIST();
+                layer_mfma<H, T, 2, false>(lds + Lb.off[4], nullptr, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[0]), d1);
+                PIME_NO_HOIST();
+                layer_first<T, 1>(lds + Lb.off[0], xrow, Do, h, h1);             // recompute h_o1
+                times_act_grad<T, 1>(d1, h1);
+                stash_store<T>(st + 4 * T * 1024, lane, d1);                     // dZo1
+            }
+            {
+                f32x16 d1[T], h1[T];
+                PIME_NO_HOIST();
+                layer_mfma<H, T, 2, false>(lds + Lb.off[5], nullptr, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[H]), d1);
+                PIME_NO_HOIST();
+                layer_first<T, 1>(lds + Lb.off[1], xrow + Do, a.Di, h, h1);      // recompute h_i1
+                times_act_grad<T, 1>(d1, h1);
+                stash_store<T>(st + 5 * T * 1024, lane, d1);                     // dZi1
+            }
+        } else {
+            f32x16 d[T], hh[T], d2[T];
+            head_backward<T>(lds + Lb.off[1], lane, dout, d);
+            stash_load<T>(st + T * 1024, lane, hh);                              // H3
+            times_act_grad<T, ACT>(d, hh);
+            stash_store<T>(st + 2 * T * 1024, lane, d);                          // dZ3
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 2, false>(lds + Lb.off[2], nullptr, lane, d, d2);   // dH2 = W(net.4)^T dZ3
+            stash_load<T>(st, lane, hh);                                         // H2
+            times_act_grad<T, ACT>(d2, hh);
+            stash_store<T>(st + 3 * T * 1024, lane, d2);                         // dZ2
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 2, false>(lds + Lb.off[3], nullptr, lane, d2, d);   // dH1 = W(net.2)^T dZ2
+            PIME_NO_HOIST();
+            layer_first<T, ACT>(lds + Lb.off[0], xrow, a.D, h, hh);              // recompute H1
+            times_act_grad<T, ACT>(d, hh);
+            stash_store<T>(st + 4 * T * 1024, lane, d);                          // dZ1
+        }
+    }
+}
+
+// ==================================================================================================== dW kernel
+constexpr int kDwThreads = 256;
+constexpr int kDwPitch = 33;                 // 32 samples + 1: conflict-free for row writes and column reads
+constexpr int kDwTile = 32 * kDwPitch;
+template <int AT, int BT>
+__device__ void dw_job(const DwJob& j, int tiles_per_wg, float* lds) {
+    constexpr int NQ = AT * BT;
+    constexpr int PER_WAVE = (NQ + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
+    float* A = lds;                    // [AT][32 feature rows][33]
+    float* Bm = lds + AT * kDwTile;    // [BT][32 feature rows][33]
+    const int ntiles = (j.B + 31) / 32;
+    const int tile0 = blockIdx.x * tiles_per_wg;
+    f32x16 acc[PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    float dbsum = 0.f;  // thread t < 32*AT owns feature t's bias gradient
+    for (int tt = 0; tt < tiles_per_wg; ++tt) {
+        const int tile = tile0 + tt;
+        if (tile >= ntiles) break;
+        __syncthreads();  // previous tile's operands fully consumed
+        // ---- stage A: dZ tiles (fragment order in HBM -> feature-major rows in LDS)
+        if (j.a_stash) {
+            const float* src = j.a_stash + ((size_t)tile * j.a_nt + j.a_t0) * 1024;
+            for (int e = tid; e < AT * 1024; e += kDwThreads) {
+                const int t = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+                A[t * kDwTile + feat32(r, ln >> 5) * kDwPitch + (ln & 31)] = src[e];
+            }
+        } else {
+            for (int e = tid; e < 1024; e += kDwThreads) {
+                const int f = e >> 5, m = e & 31;
+                A[f * kDwPitch + m] = f == 0 ? j.dout[tile * 32 + m] : 0.f;
+            }
+        }
+        // ---- stage B
+        if (j.b_kind == 0) {
+            const float* src = j.b_stash + ((size_t)tile * j.b_nt + j.b_t0) * 1024;
+            for (int e = tid; e < BT * 1024; e += kDwThreads) {
+                const int t = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+                Bm[t * kDwTile + feat32(r, ln >> 5) * kDwPitch + (ln & 31)] = src[e];
+            }
+        } else {
+            for (int e = tid; e < BT * 1024; e += kDwThreads) {
+                const int f = e >> 5, m = e & 31;  // feature f (0..32*BT), sample m
+                const int pos = tile * 32 + m;
+                const long long row = j.indices[pos < j.B ? pos : j.B - 1];
+                const float* x = j.state + (size_t)row * j.D + j.col0;
+                float v;
+                if (j.b_kind == 2) {
+                    v = f < j.Din ? x[f] : 0.f;
+                } else {
+                    float s = j.bias[f];
+                    for (int c = 0; c < j.Din; ++c) s = fmaf(x[c], j.W[(size_t)f * j.Din + c], s);
+                    v = j.act == 0 ? (s > 0.f ? s : 0.f) : fast_tanh(s);
+                }
+                Bm[(f >> 5) * kDwTile + (f & 31) * kDwPitch + m] = v;
+            }
+        }
+        __syncthreads();
+        if (j.db && tid < 32 * AT) {
+            const float* rowp = A + (tid >> 5) * kDwTile + (tid & 31) * kDwPitch;
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < 32; ++m) s += rowp[m];
+            dbsum += s;
+        }
+        // ---- 16 k-steps of two samples each
+#pragma unroll
+        for (int q = 0; q < PER_WAVE; ++q) {
+            const int tq = wave + 4 * q;
+            if (tq < NQ) {
+                const int ot = tq / BT, kt = tq % BT;
+                const float* ap = A + ot * kDwTile + li * kDwPitch + h;
+                const float* bp = Bm + kt * kDwTile + li * kDwPitch + h;
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc[q], 0, 0, 0);
+            }
+        }
+    }
+    // ---- combine: D[i = a feature][j = b feature], col on the lane, rows in the registers
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+        const int tq = wave + 4 * q;
+        if (tq < NQ) {
+            const int ot = tq / BT, kt = tq % BT;
+            const int col = kt * 32 + li;
+            if (col < j.out_cols) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowi = ot * 32 + feat32(r, h);
+                    if (rowi < j.out_rows) atomicAdd(&j.dW[(size_t)rowi * j.ldw + col], acc[q][r]);
+                }
+            }
+        }
+    }
+    if (j.db && tid < 32 * AT && tid < j.out_rows) atomicAdd(&j.db[tid], dbsum);
+}
+
+__global__ __launch_bounds__(kDwThreads) void ppo_dw_kernel(DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const DwJob& j = a.job[blockIdx.y];
+    const int key = j.a_tiles * 8 + j.b_tiles;
+    switch (key) {
+        case 4 * 8 + 4: dw_job<4, 4>(j, a.tiles_per_wg, lds); break;
+        case 2 * 8 + 4: dw_job<2, 4>(j, a.tiles_per_wg, lds); break;
+        case 4 * 8 + 1: dw_job<4, 1>(j, a.tiles_per_wg, lds); break;
+        case 1 * 8 + 4: dw_job<1, 4>(j, a.tiles_per_wg, lds); break;
+        case 2 * 8 + 2: dw_job<2, 2>(j, a.tiles_per_wg, lds); break;
+        case 1 * 8 + 2: dw_job<1, 2>(j, a.tiles_per_wg, lds); break;
+        case 2 * 8 + 1: dw_job<2, 1>(j, a.tiles_per_wg, lds); break;
+        default: break;
+    }
+}
+
+// ==================================================================================================== host side
+int mlp_check(int kind, int D, int Di, int md);
+
+int64_t ppo_bwd_image_floats(int kind, int D, int Di, int md) { return bwd_layout(kind, D, Di, md).total; }
+
+int64_t ppo_workspace_floats(int kind, int B, int md) {
+    const int64_t ntiles = (B + 31) / 32;
+    return ntiles * stash_tiles(kind, md / 32) * 1024 + ntiles * 32;
+}
+
+int launch_pack_bwd(int kind, int D, int Di, int md, const float* const* params, float* out, hipStream_t s) {
+    if (int rc = mlp_check(kind, D, Di, md)) return rc;
+    PackBwdArgs a{};
+    const int np = kind == MLP_MODULAR_ACTOR ? 12 : 8;
+    for (int i = 0; i < np; ++i) {
+        PIME_REQUIRE(params[i] != nullptr, "ppo pack: params[%d] is NULL", i);
+        a.p[i] = params[i];
+    }
+    a.kind = kind; a.D = D; a.Di = Di; a.md = md;
+    hipLaunchKernelGGL(mlp_pack_bwd_kernel, dim3(64), dim3(256), 0, s, a, out);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+template <int T, int KIND>
+static int launch_net(const PpoArgs& a, hipStream_t s) {
+    const MlpLayout L = mlp_layout(KIND, a.D, a.Di, T * 32);
+    const BwdLayout Lb = bwd_layout(KIND, a.D, a.Di, T * 32);
+    const size_t lds_bytes = sizeof(float) * (size_t)(L.total > Lb.total ? L.total : Lb.total);
+    PIME_REQUIRE(lds_bytes <= 160 * 1024, "PPO net image (%zu B) exceeds the 160 KB LDS", lds_bytes);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_fwd_bwd_kernel<T, KIND>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int ntiles = (a.B + 31) / 32, waves = kTrainThreads / 64;
+    int grid = (ntiles + waves - 1) / waves;
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL((ppo_fwd_bwd_kernel<T, KIND>), dim3(grid), dim3(kTrainThreads), lds_bytes, s, a);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+int launch_ppo_net(int kind, int md, const PpoArgs& a, hipStream_t s) {
+    const int T = md / 32;
+#define PIME_NET(TT, KK) \
+    if (T == TT && kind == KK) return launch_net<TT, KK>(a, s);
+    PIME_NET(2, MLP_CRITIC) PIME_NET(4, MLP_CRITIC)
+    PIME_NET(2, MLP_PLAIN_ACTOR) PIME_NET(4, MLP_PLAIN_ACTOR)
+    PIME_NET(2, MLP_MODULAR_ACTOR) PIME_NET(4, MLP_MODULAR_ACTOR)
+#undef PIME_NET
+    set_error("no fused PPO instantiation for kind %d width %d", kind, md);
+    return PIME_ERR_ARG;
+}
+
+// Fills the dW jobs of one net.  params/grads: nn.Linear order as in pime_mlp_pack (W,b pairs).
+int build_dw_jobs(int kind, int md, const PpoArgs& a, const float* const* params, float* const* grads, DwJob* jobs) {
+    const int T = md / 32, NT = stash_tiles(kind, T);
+    int n = 0;
+    auto base = [&]() {
+        DwJob j{};
+        j.state = a.state; j.indices = a.indices; j.D = a.D; j.B = a.B; j.dout = a.dout;
+        return j;
+    };
+    auto stash_a = [&](DwJob& j, int t0, int tiles) { j.a_stash = a.stash; j.a_nt = NT; j.a_t0 = t0; j.a_tiles = tiles; };
+    auto stash_b = [&](DwJob& j, int t0, int tiles) { j.b_kind = 0; j.b_stash = a.stash; j.b_nt = NT; j.b_t0 = t0; j.b_tiles = tiles; };
+    auto outp = [&](DwJob& j, int pi, int rows, int cols) {
+        j.dW = grads[pi]; j.db = grads[pi + 1]; j.ldw = cols; j.out_rows = rows; j.out_cols = cols;
+    };
+    if (kind == MLP_MODULAR_ACTOR) {
+        const int Do = a.D - a.Di, H = T / 2;
+        { DwJob j = base(); j.a_stash = nullptr; j.a_tiles = 1; stash_b(j, T, T); outp(j, 10, 1, md); jobs[n++] = j; }            // net.2
+        { DwJob j = base(); stash_a(j, 2 * T, T); stash_b(j, 0, T); outp(j, 8, md, md); jobs[n++] = j; }                            // net.0
+        { DwJob j = base(); stash_a(j, 3 * T, H); j.b_kind = 1; j.b_tiles = T; j.W = params[0]; j.bias = params[1]; j.Din = Do;
+          j.col0 = 0; j.act = 1; outp(j, 2, md / 2, md); jobs[n++] = j; }                                                           // other_net.2
+        { DwJob j = base(); stash_a(j, 3 * T + H, H); j.b_kind = 1; j.b_tiles = T; j.W = params[4]; j.bias = params[5];
+          j.Din = a.Di; j.col0 = Do; j.act = 1; outp(j, 6, md / 2, md); jobs[n++] = j; }                                            // integrator_net.2
+        { DwJob j = base(); stash_a(j, 4 * T, T); j.b_kind = 2; j.b_tiles = 1; j.Din = Do; j.col0 = 0; outp(j, 0, md, Do); jobs[n++] = j; }   // other_net.0
+        { DwJob j = base(); stash_a(j, 5 * T, T); j.b_kind = 2; j.b_tiles = 1; j.Din = a.Di; j.col0 = Do; outp(j, 4, md, a.Di); jobs[n++] = j; } // integrator_net.0
+    } else {
+        const int act = kind == MLP_CRITIC ? 0 : 1;
+        { DwJob j = base(); j.a_stash = nullptr; j.a_tiles = 1; stash_b(j, T, T); outp(j, 6, 1, md); jobs[n++] = j; }               // net.6
+        { DwJob j = base(); stash_a(j, 2 * T, T); stash_b(j, 0, T); outp(j, 4, md, md); jobs[n++] = j; }                            // net.4
+        { DwJob j = base(); stash_a(j, 3 * T, T); j.b_kind = 1; j.b_tiles = T; j.W = params[0]; j.bias = params[1]; j.Din = a.D;
+          j.col0 = 0; j.act = act; outp(j, 2, md, md); jobs[n++] = j; }                                                             // net.2
+        { DwJob j = base(); stash_a(j, 4 * T, T); j.b_kind = 2; j.b_tiles = 1; j.Din = a.D; j.col0 = 0; outp(j, 0, md, a.D); jobs[n++] = j; }  // net.0
+    }
+    return n;
+}
+
+int launch_dw(const DwArgs& args, int B, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds_bytes = sizeof(float) * 8 * kDwTile;
+    if (!attr_set) {
+        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_dw_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    const int ntiles = (B + 31) / 32;
+    const int chunks = (ntiles + args.tiles_per_wg - 1) / args.tiles_per_wg;
+    hipLaunchKernelGGL(ppo_dw_kernel, dim3(chunks, args.njobs), dim3(kDwThreads), lds_bytes, s, args);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+}  // namespace pime

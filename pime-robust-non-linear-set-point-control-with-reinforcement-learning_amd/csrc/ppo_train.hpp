@@ -1,0 +1,43 @@
+// Launch-argument blocks of the fused PPO gradient kernels, shared by ppo_train.hip and abi.hip.
+#pragma once
+#include <stdint.h>
+
+namespace pime {
+
+struct PpoArgs {
+    const float *state, *action, *logprob, *adv, *r_sum;  // flat trajectory buffers, rows = transitions
+    const int64_t* indices;                               // [B] minibatch rows
+    int B, D, Di;
+    const float* a_std_log;     // actor: [1] parameter
+    const float* critic_scale;  // critic: [1] device scalar 1/(r_sum[idx].std() + 1e-5)  (agent.py:652)
+    float ratio_clip, lambda_entropy;
+    const float *img_fwd, *img_bwd;
+    float *stash, *dout;
+    float* loss_sums;  // [4]: sum(-surrogate), sum(entropy proxy), sum(smooth-l1), unused
+    float* g_std;      // actor: gradient of a_std_log (accumulated)
+};
+
+struct DwJob {
+    const float* a_stash;  // dZ stash base (NULL => head job: the A "tile" is the dOut vector in feature 0)
+    int a_nt, a_t0, a_tiles;
+    const float* dout;
+    int b_kind;            // 0: stash tiles, 1: first layer recomputed from the state, 2: raw state columns
+    const float* b_stash;
+    int b_nt, b_t0, b_tiles;
+    const float *W, *bias; // b_kind 1: nn.Linear [32*b_tiles][Din] + bias
+    int Din, col0, act;    // b_kind 1/2: state columns [col0, col0+Din); act of the recomputed layer
+    float *dW, *db;        // dW row-major [a feats][ldw]
+    int ldw, out_rows, out_cols;
+    const float* state;
+    const int64_t* indices;
+    int D, B;
+};
+
+constexpr int kMaxDwJobs = 12;
+
+struct DwArgs {
+    DwJob job[kMaxDwJobs];
+    int njobs, tiles_per_wg;
+};
+
+}  // namespace pime

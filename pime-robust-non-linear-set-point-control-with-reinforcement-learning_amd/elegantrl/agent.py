@@ -84,7 +84,11 @@ class AgentBase:
 
     def weights_changed(self):
         """Invalidate packed (kernel-layout) copies of the weights."""
+        fused = getattr(self, "_packed", {}).get("fused")
         self._packed = {}
+        if fused is not None and fused.params_are(self):
+            fused.repack()
+            self._packed["fused"] = fused
 
     @staticmethod
     def soft_update(target_net, current_net, tau):
@@ -108,6 +112,7 @@ class AgentPPO(AgentBase):
         self.compute_reward = None
         self._packed = {}
         self.noise_hook = None  # tests: callable(t, shape) -> exploration noise tensor (else torch.randn)
+        self.use_fused_update = True
 
     # ---- construction ------------------------------------------------------------------------------------
     def _build_nets(self, net_dim, state_dim, action_dim):
@@ -126,7 +131,8 @@ class AgentPPO(AgentBase):
         # ONE Adam over both nets (agent.py:565-566); rebuilt whenever the reference rebuilds it
         groups = [{"params": self.act.parameters(), "lr": self.learning_rate},
                   {"params": self.cri.parameters(), "lr": self.learning_rate}]
-        self.optimizer = torch.optim.Adam(groups)
+        # fused=True: one multi-tensor kernel per step on the GPU instead of ~10 foreach launches
+        self.optimizer = torch.optim.Adam(groups, fused=True) if self.device.type == "cuda" else torch.optim.Adam(groups)
         self.weights_changed()
 
     def init_actor_zero(self):
@@ -254,14 +260,15 @@ class AgentPPO(AgentBase):
             buf_r_sum, buf_advantage = self.compute_reward(buf_len, buf_reward, buf_mask, buf_value, shape=(T, N))
 
         n_steps = int(repeat_times * buf_len / batch_size)                         # :629
+        fused = self._fused_grad(batch_size)
+        if fused is not None:
+            return self._update_fused(fused, n_steps, buf_len, batch_size, repeat_times, buf_state, buf_action,
+                                      buf_r_sum, buf_logprob, buf_advantage)
         sums = torch.zeros(4, device=dev)  # united, actor, critic, entropy
         obj_actor = obj_critic = torch.zeros((), device=dev)
         params = [p for g in self.optimizer.param_groups for p in g["params"]]
         for step in range(n_steps):
-            if self.index_hook is not None:
-                indices = self.index_hook(step, buf_len, batch_size).to(dev)
-            else:
-                indices = torch.randint(buf_len, size=(batch_size,), device=dev)   # :630
+            indices = self._minibatch_indices(step, buf_len, batch_size, dev)
             state = buf_state[indices]
             action = buf_action[indices]
             r_sum = buf_r_sum[indices]
@@ -287,11 +294,69 @@ class AgentPPO(AgentBase):
         self._n_updates += int(repeat_times)
         if n_steps:
             mean = (sums / n_steps).tolist()                                       # the only host sync of the update
-            logger.record("train/united_loss", mean[0])
-            logger.record("train/actor_loss", mean[1])
-            logger.record("train/critic_loss", mean[2])
-            logger.record("train/entropy_losses", mean[3])
+            self._log_losses(*mean)
         return float(obj_actor.detach()), float(obj_critic.detach())
+
+    def _minibatch_indices(self, step, buf_len, batch_size, dev):
+        if self.index_hook is not None:
+            return self.index_hook(step, buf_len, batch_size).to(dev)
+        return torch.randint(buf_len, size=(batch_size,), device=dev)              # agent.py:630
+
+    @staticmethod
+    def _log_losses(united, actor, critic, entropy):
+        logger.record("train/united_loss", united)
+        logger.record("train/actor_loss", actor)
+        logger.record("train/critic_loss", critic)
+        logger.record("train/entropy_losses", entropy)
+
+    def _fused_grad(self, batch_size):
+        """The fused HIP gradient path when the backend offers it for these nets (width 64/128, action_dim 1, GPU);
+        otherwise None and the update runs through torch autograd on the same device."""
+        if not self.use_fused_update or not hasattr(self.backend, "fused_ppo"):
+            return None
+        f = self._packed.get("fused")
+        if f is None or f.max_batch < batch_size:
+            f = self.backend.fused_ppo(self.act, self.cri, batch_size)
+            self._packed["fused"] = f
+        return f if f else None
+
+    def _update_fused(self, fused, n_steps, buf_len, batch_size, repeat_times, buf_state, buf_action, buf_r_sum,
+                      buf_logprob, buf_advantage):
+        """Per optimizer step: indices -> (tiny torch ops for the minibatch r_sum.std()) -> three HIP launches that
+        leave d(obj_united)/d(theta) in the flat gradient buffer -> optional ONE all-reduce -> Adam."""
+        dev = buf_state.device
+        action = buf_action.reshape(-1).contiguous()
+        fused.loss_sums.zero_()
+        crit_w = torch.zeros((), device=dev)
+        scale = torch.ones(1, device=dev)
+        last = None
+        for step in range(n_steps):
+            indices = self._minibatch_indices(step, buf_len, batch_size, dev)
+            scale = (1.0 / (buf_r_sum[indices].std() + 1e-5)).reshape(1)           # agent.py:652
+            if step == n_steps - 1:
+                last = fused.loss_sums.clone()
+            fused.zero_grad()
+            fused(buf_state, action, buf_logprob, buf_advantage, buf_r_sum, indices, self.ratio_clip,
+                  self.lambda_entropy, scale)
+            if self.dp is not None:
+                self.dp.all_reduce_sum(fused.flat_grad)
+                fused.flat_grad.div_(self.dp.world)
+            self.optimizer.step()
+            fused.repack()
+            crit_w += scale[0]
+        self._packed = {"fused": fused}  # packed forward images of the value pass / rollout are stale now
+        self._n_updates += int(repeat_times)
+        if not n_steps:
+            return 0.0, 0.0
+        tot = fused.loss_sums.tolist()                                             # the only host sync of the update
+        lst = last.tolist()
+        B = float(batch_size)
+        ent, cri = tot[1] / (n_steps * B), tot[2] / (n_steps * B)
+        act = tot[0] / (n_steps * B) + self.lambda_entropy * ent
+        self._log_losses(act + cri * float(crit_w) / n_steps, act, cri, ent)
+        obj_a = (tot[0] - lst[0]) / B + self.lambda_entropy * (tot[1] - lst[1]) / B
+        obj_c = (tot[2] - lst[2]) / B
+        return obj_a, obj_c
 
     def _normalise_advantage(self, adv):
         """(adv - mean) / (std + 1e-5) over the WHOLE buffer with torch's unbiased std (agent.py:707); under data

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(PACKAGE_DIR, "libpime_hip.so")
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
+ABI_VERSION = 4
 ENV_PH, ENV_WT = 0, 1
 STATE_F64, STATE_MIXED = 0, 1
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
@@ -31,6 +32,17 @@ class PimeError(RuntimeError):
 
 class PhChem(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("kw", "kchem", "ka", "MNaOH", "MHA", "MNH3")]
+
+
+class PpoNet(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("D", C.c_int32), ("Di", C.c_int32), ("md", C.c_int32),
+                ("params", C.c_void_p), ("grads", C.c_void_p), ("a_std_log", C.c_void_p), ("g_a_std_log", C.c_void_p),
+                ("img_fwd", C.c_void_p), ("img_bwd", C.c_void_p), ("workspace", C.c_void_p)]
+
+
+class PpoBatch(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("action", C.c_void_p), ("logprob", C.c_void_p), ("adv", C.c_void_p),
+                ("r_sum", C.c_void_p), ("indices", C.c_void_p), ("B", C.c_int32)]
 
 
 class EnvCfg(C.Structure):
@@ -76,6 +88,11 @@ _SIGNATURES = {
     "pime_mlp_packed_floats": (C.c_int64, [_i32, _i32, _i32, _i32]),
     "pime_mlp_pack": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pime_mlp_forward": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+
+    "pime_ppo_bwd_image_floats": (C.c_int64, [_i32, _i32, _i32, _i32]),
+    "pime_ppo_workspace_floats": (C.c_int64, [_i32, _i32, _i32]),
+    "pime_ppo_pack_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "pime_ppo_minibatch_grad": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -103,8 +120,8 @@ def lib():
             fn = getattr(handle, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if handle.pime_abi_version() != 3:
-            raise PimeError(f"libpime_hip.so ABI {handle.pime_abi_version()} != binding ABI 3; rebuild")
+        if handle.pime_abi_version() != ABI_VERSION:
+            raise PimeError(f"libpime_hip.so ABI {handle.pime_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
         _lib = handle
     return _lib
 

@@ -104,3 +104,122 @@ class PackedMLP:
                                                        native.ptr(self.packed), native.ptr(out), _stream(x)),
                          "pime_mlp_forward")
         return out
+
+
+class FusedPPOGrad:
+    """Minibatch loss gradients of (actor, critic) by the fused HIP kernels (csrc/ppo_train.hip), written straight
+    into the parameters' .grad tensors.  Everything between drawing the minibatch indices and `optimizer.step()`.
+
+    All .grad tensors are views into ONE flat buffer (`self.flat_grad`), so zeroing is one memset and a data-parallel
+    all-reduce is one collective on that buffer."""
+
+    def __init__(self, act, cri, max_batch):
+        self.act, self.cri = act, cri
+        self.device = next(cri.parameters()).device
+        _need_cuda(next(cri.parameters()))
+        if getattr(act, "action_dim", 1) != 1:
+            raise native.PimeError("fused PPO gradients support action_dim == 1")
+        self.nets = []
+        self.max_batch = int(max_batch)
+        L = native.lib()
+        # flat gradient buffer over every trainable parameter, in optimizer order (actor first, then critic)
+        params = [p for p in list(act.parameters()) + list(cri.parameters()) if p.requires_grad]
+        self.params = params
+        total = sum(p.numel() for p in params)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        off = 0
+        for p in params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self._dump = torch.zeros(max(p.numel() for p in list(act.parameters()) + list(cri.parameters())),
+                                 dtype=torch.float32, device=self.device)  # sink for frozen parameters' gradients
+        self.loss_sums = torch.zeros(4, dtype=torch.float32, device=self.device)
+        for module in (act, cri):
+            kind = module.packed_kind
+            names = _PARAM_ORDER[kind]
+            sd = dict(module.named_parameters())
+            plist = [sd[f"{n}.{p}"] for n in names for p in ("weight", "bias")]
+            D, Di = module.state_dim, getattr(module, "integrator_dim", 0)
+            md = plist[0].shape[0]
+            k = _KINDS[kind]
+            n_fwd = L.pime_mlp_packed_floats(k, D, Di, md)
+            n_bwd = L.pime_ppo_bwd_image_floats(k, D, Di, md)
+            n_ws = L.pime_ppo_workspace_floats(k, self.max_batch, md)
+            if n_fwd <= 0 or n_bwd <= 0 or n_ws <= 0:
+                raise native.PimeError(f"fused PPO gradients unsupported for {kind} width {md}: {native.last_error()}")
+            net = dict(kind=k, D=D, Di=Di, md=md, plist=plist,
+                       img_fwd=torch.empty(n_fwd, dtype=torch.float32, device=self.device),
+                       img_bwd=torch.empty(n_bwd, dtype=torch.float32, device=self.device),
+                       ws=torch.empty(n_ws, dtype=torch.float32, device=self.device))
+            self.nets.append(net)
+        self._structs = None
+        self.repack()
+
+    @staticmethod
+    def supported(act, cri):
+        try:
+            for m in (act, cri):
+                kind = getattr(m, "packed_kind", None)
+                if kind is None or getattr(m, "action_dim", 1) != 1:
+                    return False
+                sd = dict(m.named_parameters())
+                md = sd[_PARAM_ORDER[kind][0] + ".weight"].shape[0]
+                if not PackedMLP.supported(kind, m.state_dim, getattr(m, "integrator_dim", 0), md):
+                    return False
+            return next(cri.parameters()).is_cuda
+        except Exception:
+            return False
+
+    def _ptr_array(self, tensors):
+        return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def repack(self):
+        """Re-lay both nets' weights into the forward / transposed LDS images (after every optimizer step)."""
+        L = native.lib()
+        with torch.cuda.device(self.device):
+            s = _stream(self.flat_grad)
+            for net in self.nets:
+                arr = self._ptr_array([p.detach() for p in net["plist"]])
+                native.check(L.pime_mlp_pack(net["kind"], net["D"], net["Di"], net["md"], arr, native.ptr(net["img_fwd"]), s))
+                native.check(L.pime_ppo_pack_bwd(net["kind"], net["D"], net["Di"], net["md"], arr, native.ptr(net["img_bwd"]), s))
+
+    def _build_structs(self):
+        out = []
+        keep = []
+        for net, module in zip(self.nets, (self.act, self.cri)):
+            grads = [p.grad if (p.requires_grad and p.grad is not None) else self._dump for p in net["plist"]]
+            pa, ga = self._ptr_array([p.detach() for p in net["plist"]]), self._ptr_array(grads)
+            keep += [pa, ga]
+            st = native.PpoNet(kind=net["kind"], D=net["D"], Di=net["Di"], md=net["md"],
+                               params=C.cast(pa, C.c_void_p), grads=C.cast(ga, C.c_void_p),
+                               img_fwd=net["img_fwd"].data_ptr(), img_bwd=net["img_bwd"].data_ptr(),
+                               workspace=net["ws"].data_ptr())
+            if module is self.act:
+                asl = module.a_std_log
+                g = asl.grad if (asl.requires_grad and asl.grad is not None) else self._dump
+                st.a_std_log, st.g_a_std_log = asl.data_ptr(), g.data_ptr()
+            out.append(st)
+        self._structs = (out[0], out[1], keep)
+
+    def params_are(self, agent):
+        """True while this object still wraps the agent's current nets (they are rebuilt by agent.init)."""
+        return agent.act is self.act and agent.cri is self.cri
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def __call__(self, state, action, logprob, adv, r_sum, indices, ratio_clip, lambda_entropy, critic_scale):
+        """Accumulates d(obj_united)/d(theta) of the minibatch `indices` into the .grad views.  All tensors float32
+        CUDA and contiguous; state [L, D]; action/logprob/adv/r_sum [L]; indices int64 [B]; critic_scale float32 [1]."""
+        B = indices.numel()
+        assert B <= self.max_batch and indices.dtype == torch.int64
+        if self._structs is None:
+            self._build_structs()
+        actor, critic, _ = self._structs
+        batch = native.PpoBatch(state=state.data_ptr(), action=action.data_ptr(), logprob=logprob.data_ptr(),
+                                adv=adv.data_ptr(), r_sum=r_sum.data_ptr(), indices=indices.data_ptr(), B=B)
+        with torch.cuda.device(self.device):
+            native.check(native.lib().pime_ppo_minibatch_grad(C.byref(actor), C.byref(critic), C.byref(batch),
+                                                              C.c_float(ratio_clip), C.c_float(lambda_entropy),
+                                                              native.ptr(critic_scale), native.ptr(self.loss_sums),
+                                                              _stream(state)), "pime_ppo_minibatch_grad")

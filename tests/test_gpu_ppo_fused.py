@@ -1,0 +1,130 @@
+"""Fused PPO minibatch-gradient kernels (csrc/ppo_train.hip) against PyTorch fp32 autograd of the reference's loss
+(elegantrl/agent.py:637-655) on the same minibatch.  A floating-point kernel: the checker is a plain torch fp32
+implementation on the same device, with tolerances stated per assertion."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _make(kind, md, D, seed):
+    from pime_amd.elegantrl.net import ActorPPO, CriticAdv
+    from pime_amd.elegantrl.net_residual import ActorResidualIntegratorModularPPO, ActorResidualPPO
+    torch.manual_seed(seed)
+    cri = CriticAdv(D, md).to(DEV)
+    if kind == "modular":
+        act = ActorResidualIntegratorModularPPO(md, D, 1, 1).to(DEV)
+    elif kind == "resid":
+        act = ActorResidualPPO(md, D, 1).to(DEV)
+    else:
+        act = ActorPPO(md, D, 1).to(DEV)
+    with torch.no_grad():
+        act.net[-1].weight.mul_(6.0)
+        act.a_std_log.fill_(-0.3)
+    return act, cri
+
+
+def _data(L, D, act, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    state = (torch.randn(L, D, generator=g) * torch.tensor([3., 3., 8., 1.][:D]) + torch.tensor([7., 7., 0., 0.][:D])).to(DEV)
+    with torch.no_grad():
+        mean = act.mean(state)
+        std = act.a_std_log.exp()
+        noise = torch.randn(L, 1, generator=g).to(DEV)
+        action = mean + noise * std
+        logprob = act.old_logprob(noise)
+        # move a third of the old log-probs so that both clip branches and both advantage signs occur
+        shift = (torch.rand(L, generator=g).to(DEV) - 0.5) * 0.8
+        logprob = logprob + torch.where(torch.rand(L, generator=g).to(DEV) < 0.35, shift, torch.zeros_like(shift))
+    adv = torch.randn(L, generator=g).to(DEV)
+    r_sum = (torch.randn(L, generator=g) * 30 - 40).to(DEV)
+    return state, action, logprob, adv, r_sum
+
+
+def _torch_grads(act, cri, state, action, logprob, adv, r_sum, idx, clip, lam):
+    for p in list(act.parameters()) + list(cri.parameters()):
+        p.grad = None
+    s, a, lp, ad, rs = state[idx], action[idx], logprob[idx], adv[idx], r_sum[idx]
+    new_lp = act.compute_logprob(s, a)
+    ratio = (new_lp - lp).exp()
+    sur = torch.min(ad * ratio, ad * ratio.clamp(1 - clip, 1 + clip))
+    ent = (new_lp.exp() * new_lp).mean()
+    obj_a = -sur.mean() + ent * lam
+    obj_c = torch.nn.functional.smooth_l1_loss(cri(s).squeeze(1), rs)
+    scale = 1.0 / (rs.std() + 1e-5)
+    (obj_a + obj_c * scale).backward()
+    grads = {n: p.grad.clone() for n, p in list(act.named_parameters()) + [("cri." + k, v) for k, v in cri.named_parameters()]
+             if p.grad is not None}
+    return grads, float(-sur.sum()), float((new_lp.exp() * new_lp).sum()), float(obj_c) * len(idx), scale.reshape(1)
+
+
+@pytest.mark.parametrize("kind,md,D,B", [("modular", 128, 3, 4096), ("modular", 128, 3, 1000), ("modular", 64, 4, 2048),
+                                         ("resid", 128, 3, 4096), ("resid", 64, 12, 777), ("ppo", 128, 3, 2048),
+                                         ("modular", 128, 3, 65536)])
+def test_fused_gradients_match_autograd(kind, md, D, B):
+    from pime_amd import ops
+    act, cri = _make(kind, md, D, seed=B + md)
+    L = max(3 * B, 5000)
+    state, action, logprob, adv, r_sum = _data(L, D, act, seed=1)
+    idx = torch.randint(L, (B,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    clip, lam = 0.2, 0.02
+    want, s_sur, s_ent, s_cri, scale = _torch_grads(act, cri, state, action, logprob, adv, r_sum, idx, clip, lam)
+    fused = ops.FusedPPOGrad(act, cri, B)
+    fused.zero_grad()
+    fused.loss_sums.zero_()
+    fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, clip, lam, scale)
+    torch.cuda.synchronize()
+    got = {n: p.grad for n, p in list(act.named_parameters()) + [("cri." + k, v) for k, v in cri.named_parameters()]
+           if p.requires_grad}
+    assert set(got) == set(want)
+    for name in want:
+        w, g = want[name], got[name]
+        # f32 sums over B samples in a different order: 3e-4 of the tensor's largest gradient entry
+        tol = 3e-4 * float(w.abs().max()) + 1e-7
+        err = float((w - g).abs().max())
+        assert err <= tol, f"{name}: max |diff| {err:.3e} > {tol:.3e} (|grad|max {float(w.abs().max()):.3e})"
+    sums = fused.loss_sums.tolist()
+    np.testing.assert_allclose(sums[0], s_sur, rtol=2e-4, atol=1e-3 * B ** 0.5)
+    np.testing.assert_allclose(sums[1], s_ent, rtol=2e-4, atol=1e-3 * B ** 0.5)
+    np.testing.assert_allclose(sums[2], s_cri, rtol=2e-4)
+
+
+def test_fused_update_net_matches_torch_update():
+    """Whole update_net: the fused path and the torch-autograd path, same start, same minibatch indices."""
+    from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from pime_amd.elegantrl.replay import TrajectoryBuffer
+    T, N, D = 50, 512, 3
+    idx_gen = torch.Generator(device="cpu").manual_seed(5)
+    idx_all = [torch.randint(T * N, (4096,), generator=idx_gen) for _ in range(64)]
+    out = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        ag = AgentResidualIntegratorModularPPO(device=DEV)
+        ag.lambda_gae_adv = 0.99
+        ag.init(128, D, 1, 1)
+        ag.init_residual({"init_K": np.array([[-0.02], [0.02], [0.035]])})
+        with torch.no_grad():
+            ag.act.net[-1].weight.normal_(0, 0.05)
+        ag.weights_changed()
+        ag.use_fused_update = fused
+        ag.index_hook = lambda step, L, B: idx_all[step]
+        buf = TrajectoryBuffer(T, N, D, 1, DEV)
+        g = torch.Generator(device="cpu").manual_seed(9)
+        buf.state[:T] = (torch.randn(T, N, D, generator=g) * torch.tensor([3., 3., 8.]) + torch.tensor([7., 7., 0.])).to(DEV)
+        buf.reward[:] = -(torch.rand(T, N, generator=g) * 20).to(DEV)
+        buf.mask[:] = 0.99
+        buf.mask[-1] = 0
+        buf.noise[:] = torch.randn(T, N, 1, generator=g).to(DEV)
+        with torch.no_grad():
+            flat = buf.state[:T].reshape(-1, D)
+            buf.action[:] = (ag.act.mean(flat) + buf.noise.reshape(-1, 1) * ag.act.a_std_log.exp()).reshape(T, N, 1)
+        buf.length = T
+        oa, oc = ag.update_net(buf, T * N, 4096, 1.0)   # 6 optimizer steps
+        out.append(({k: v.detach().clone() for k, v in list(ag.act.state_dict().items()) + list(ag.cri.state_dict().items())}, oa, oc))
+    (w0, a0, c0), (w1, a1, c1) = out
+    for k in w0:
+        np.testing.assert_allclose(w1[k].cpu().numpy(), w0[k].cpu().numpy(), rtol=0, atol=3e-5, err_msg=k)  # lr 1e-4 x 6 Adam steps
+    np.testing.assert_allclose(a1, a0, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(c1, c0, rtol=1e-3)
