@@ -28,7 +28,9 @@ def _make(kind, md, D, seed):
 
 def _data(L, D, act, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    state = (torch.randn(L, D, generator=g) * torch.tensor([3., 3., 8., 1.][:D]) + torch.tensor([7., 7., 0., 0.][:D])).to(DEV)
+    scale = torch.tensor(([3., 3., 8., 1.] * 8)[:D])
+    shift0 = torch.tensor(([7., 7., 0., 0.] * 8)[:D])
+    state = (torch.randn(L, D, generator=g) * scale + shift0).to(DEV)
     with torch.no_grad():
         mean = act.mean(state)
         std = act.a_std_log.exp()
@@ -57,7 +59,7 @@ def _torch_grads(act, cri, state, action, logprob, adv, r_sum, idx, clip, lam):
     (obj_a + obj_c * scale).backward()
     grads = {n: p.grad.clone() for n, p in list(act.named_parameters()) + [("cri." + k, v) for k, v in cri.named_parameters()]
              if p.grad is not None}
-    return grads, float(-sur.sum()), float((new_lp.exp() * new_lp).sum()), float(obj_c) * len(idx), scale.reshape(1)
+    return grads, float(-sur.sum().detach()), float((new_lp.exp() * new_lp).sum().detach()), float(obj_c.detach()) * len(idx), scale.reshape(1)
 
 
 @pytest.mark.parametrize("kind,md,D,B", [("modular", 128, 3, 4096), ("modular", 128, 3, 1000), ("modular", 64, 4, 2048),
