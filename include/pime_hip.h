@@ -191,7 +191,7 @@ int pime_mlp_forward(int32_t kind, const float* x, int32_t M, int32_t D, int32_t
  * compute_logprob of the residual actors (net_residual.py:48-54,182-190), the clipped surrogate + entropy proxy
  * (:637-645), CriticAdv forward + SmoothL1 (:648-649), the united loss (:652) and `obj_united.backward()` (:654-655)
  * -- i.e. everything between drawing the indices and `optimizer.step()`, which stays in PyTorch.
- * Three launches: critic fwd+bwd, actor fwd+bwd, one weight-gradient kernel (csrc/ppo_train.hip).
+ * Four launches: critic fwd+bwd, actor fwd+bwd, one weight-gradient kernel, critic-gradient scaling (csrc/ppo_train.hip).
  *
  * pime_ppo_net describes one net: the same (kind, D, Di, md, params) as pime_mlp_pack; `grads` are the .grad tensors in
  * the same order and are ACCUMULATED into with float atomics (zero them first); img_fwd = pime_mlp_pack image,
@@ -222,11 +222,13 @@ int64_t pime_ppo_bwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t m
 int64_t pime_ppo_workspace_floats(int32_t kind, int32_t B, int32_t md);
 int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const float* const* params, float* image,
                       pime_stream stream);
-/* critic_scale: [dev] float32[1] = 1 / (r_sum[indices].std() + 1e-5)  (agent.py:652)
+/* critic_scale: [dev] float32[1], WRITTEN: 1 / (r_sum[indices].std() + 1e-5) with torch's unbiased std (agent.py:652);
+ *               the critic's gradients are multiplied by it (fourth, tiny launch)
+ * moments:      [dev] float64[2] scratch (zeroed by the call)
  * loss_sums:    [dev] float32[4], ACCUMULATED: sum(-min(surr1,surr2)), sum(exp(logp)*logp), sum(smooth_l1), unused */
 int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* batch,
-                            float ratio_clip, float lambda_entropy, const float* critic_scale, float* loss_sums,
-                            pime_stream stream);
+                            float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
+                            float* loss_sums, pime_stream stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

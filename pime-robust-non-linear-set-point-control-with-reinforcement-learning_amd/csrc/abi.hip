@@ -1,5 +1,6 @@
 // C ABI of libpime_hip.so (include/pime_hip.h): handle management, argument checks, field I/O, launch dispatch.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -36,10 +37,12 @@ int launch_mlp_forward(int, const float*, int, int, int, int, const float*, floa
 // ppo_train.hip
 int64_t ppo_bwd_image_floats(int, int, int, int);
 int64_t ppo_workspace_floats(int, int, int);
+inline int stash_tiles_of(int kind, int md) { return (kind == 2 ? 6 : 5) * (md / 32); }
 int launch_pack_bwd(int, int, int, int, const float* const*, float*, hipStream_t);
 int launch_ppo_net(int, int, const PpoArgs&, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
 int launch_dw(const DwArgs&, int, hipStream_t);
+int launch_critic_scale(int, int, float* const*, const double*, int, float*, hipStream_t);
 
 }  // namespace pime
 
@@ -562,15 +565,16 @@ static int check_net(const pime_ppo_net* n, bool actor) {
 }
 
 int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b,
-                            float ratio_clip, float lambda_entropy, const float* critic_scale, float* loss_sums,
-                            pime_stream stream) {
+                            float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
+                            float* loss_sums, pime_stream stream) {
     if (int rc = check_net(actor, true)) return rc;
     if (int rc = check_net(critic, false)) return rc;
     PIME_REQUIRE(b && b->state && b->action && b->logprob && b->adv && b->r_sum && b->indices && b->B >= 1,
                  "pime_ppo_minibatch_grad: bad batch");
-    PIME_REQUIRE(critic_scale && loss_sums, "pime_ppo_minibatch_grad: NULL critic_scale / loss_sums");
+    PIME_REQUIRE(critic_scale && moments && loss_sums, "pime_ppo_minibatch_grad: NULL critic_scale / moments / loss_sums");
     PIME_REQUIRE(actor->D == critic->D, "actor and critic state_dim differ");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    PIME_HIP_TRY(hipMemsetAsync(moments, 0, 2 * sizeof(double), s));
     DwArgs dw{};
     const pime_ppo_net* nets[2] = {critic, actor};
     for (int k = 0; k < 2; ++k) {
@@ -578,17 +582,20 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         PpoArgs a{};
         a.state = b->state; a.action = b->action; a.logprob = b->logprob; a.adv = b->adv; a.r_sum = b->r_sum;
         a.indices = b->indices; a.B = b->B; a.D = n->D; a.Di = n->Di;
-        a.a_std_log = n->a_std_log; a.critic_scale = critic_scale; a.ratio_clip = ratio_clip; a.lambda_entropy = lambda_entropy;
+        a.a_std_log = n->a_std_log; a.moments = moments; a.ratio_clip = ratio_clip; a.lambda_entropy = lambda_entropy;
         a.img_fwd = n->img_fwd; a.img_bwd = n->img_bwd;
         const int64_t ntiles = (b->B + 31) / 32;
         a.stash = n->workspace;
-        a.dout = n->workspace + (ppo_workspace_floats(n->kind, b->B, n->md) - ntiles * 32);
+        a.dout = n->workspace + ntiles * (int64_t)stash_tiles_of(n->kind, n->md) * 1024;
+        a.xg = a.dout + ntiles * 32;
         a.loss_sums = loss_sums; a.g_std = n->g_a_std_log;
         if (int rc = launch_ppo_net(n->kind, n->md, a, s)) return rc;
         dw.njobs += build_dw_jobs(n->kind, n->md, a, n->params, n->grads, dw.job + dw.njobs);
     }
-    dw.tiles_per_wg = 4;
-    return launch_dw(dw, b->B, s);
+    dw.tiles_per_wg = 16;
+    if (const char* e = std::getenv("PIME_DW_DEBUG")) dw.debug_skip = std::atoi(e);  // timing ablations only
+    if (int rc = launch_dw(dw, b->B, s)) return rc;
+    return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, s);
 }
 
 }  // extern "C"

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
     }
     __syncthreads();
     float s0 = 0.f, s1 = 0.f, gstd = 0.f;
+    double m1 = 0.0, m2 = 0.0;
     for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
         PIME_NO_HOIST();
         const int pos = tile * 32 + (lane & 31);
@@ -158,6 +159,8 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
         const long long row = a.indices[valid ? pos : a.B - 1];
         const float* xrow = a.state + (size_t)row * a.D;
         float* st = a.stash + (size_t)tile * NT * 1024;
+        if (h == 0)  // contiguous copy of the gathered states for the dW kernel (its first-layer operands)
+            for (int c = 0; c < a.D; ++c) a.xg[(size_t)pos * a.D + c] = xrow[c];
         float y;
         if constexpr (MODULAR) {
             const int Do = a.D - a.Di;
@@ -201,8 +204,12 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
                 const float d = y - a.r_sum[row], ad = fabsf(d);         // SmoothL1, beta = 1 (agent.py:567,649)
                 const float l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
                 const float g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
-                dout = g * a.critic_scale[0] * invB;
-                if (h == 0) s0 += l;
+                dout = g * invB;  // unscaled: critic_scale_kernel applies 1/(std+1e-5) to the finished gradients
+                if (h == 0) {
+                    s0 += l;
+                    m1 += (double)a.r_sum[row];
+                    m2 += (double)a.r_sum[row] * (double)a.r_sum[row];
+                }
             } else {
                 const float asl = a.a_std_log[0], inv_sigma = __expf(-asl);
                 const float z = (y - a.action[row]) * inv_sigma;
@@ -231,8 +238,15 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
         if (h == 0 && pos < ntiles * 32) a.dout[pos] = dout;
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); gstd = wave_sum(gstd);
+    if constexpr (CRITIC) {
+        for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+    }
     if (lane == 0) {
-        if constexpr (CRITIC) atomicAdd(&a.loss_sums[2], s0);
+        if constexpr (CRITIC) {
+            atomicAdd(&a.loss_sums[2], s0);
+            atomicAdd(&a.moments[0], m1);
+            atomicAdd(&a.moments[1], m2);
+        }
         else { atomicAdd(&a.loss_sums[0], s0); atomicAdd(&a.loss_sums[1], s1); atomicAdd(a.g_std, gstd); }
     }
 
@@ -313,63 +327,103 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
 constexpr int kDwThreads = 256;
 constexpr int kDwPitch = 33;                 // 32 samples + 1: conflict-free for row writes and column reads
 constexpr int kDwTile = 32 * kDwPitch;
+constexpr int kDwMaxDin = kMaxObsDim;        // first-layer fan-in
+// LDS: operand tiles [AT + BT][32][33], then (b_kind 1) first-layer weights [32*BT][Din+1], then the tile's states [32][Din]
+__host__ __device__ inline int dw_lds_floats(int Din) { return 8 * kDwTile + 128 * (Din + 1) + 32 * Din; }
+
+// One float4 of a stashed tile per thread: elements 4*tid .. 4*tid+3 of [16 regs][64 lanes] -> feature-major LDS rows
+__device__ __forceinline__ void lds_put_frag4(float* tile, int tid, const float4& v) {
+    const int r = tid >> 4, ln = (tid & 15) * 4;
+    float* p = tile + feat32(r, ln >> 5) * kDwPitch + (ln & 31);
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+}
+
 template <int AT, int BT>
-__device__ void dw_job(const DwJob& j, int tiles_per_wg, float* lds) {
+__device__ void dw_job(const DwJob& j, int tiles_per_wg, int dbg, float* lds) {
     constexpr int NQ = AT * BT;
     constexpr int PER_WAVE = (NQ + 3) / 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
     float* A = lds;                    // [AT][32 feature rows][33]
     float* Bm = lds + AT * kDwTile;    // [BT][32 feature rows][33]
+    float* W1 = lds + 8 * kDwTile;     // b_kind 1: [32*BT][Din] weights then [32*BT] bias
+    float* xs = W1 + 128 * (j.Din + 1);  // [32][Din] states of the current sample tile
     const int ntiles = (j.B + 31) / 32;
     const int tile0 = blockIdx.x * tiles_per_wg;
+    const int tile_end = min(tile0 + tiles_per_wg, ntiles);
+    const bool head = j.a_stash == nullptr;
+    if (j.b_kind == 1) {  // first-layer weights stay in LDS for the whole job
+        const int nf = 32 * BT;
+        for (int e = tid; e < nf * j.Din; e += kDwThreads) W1[e] = j.W[e];
+        for (int e = tid; e < nf; e += kDwThreads) W1[nf * j.Din + e] = j.bias[e];
+    }
     f32x16 acc[PER_WAVE];
 #pragma unroll
     for (int q = 0; q < PER_WAVE; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     float dbsum = 0.f;  // thread t < 32*AT owns feature t's bias gradient
-    for (int tt = 0; tt < tiles_per_wg; ++tt) {
-        const int tile = tile0 + tt;
-        if (tile >= ntiles) break;
-        __syncthreads();  // previous tile's operands fully consumed
-        // ---- stage A: dZ tiles (fragment order in HBM -> feature-major rows in LDS)
-        if (j.a_stash) {
-            const float* src = j.a_stash + ((size_t)tile * j.a_nt + j.a_t0) * 1024;
-            for (int e = tid; e < AT * 1024; e += kDwThreads) {
-                const int t = e >> 10, r = (e >> 6) & 15, ln = e & 63;
-                A[t * kDwTile + feat32(r, ln >> 5) * kDwPitch + (ln & 31)] = src[e];
-            }
+
+    // register prefetch of the next sample tile: global loads stay in flight behind the current tile's MFMAs
+    float4 pa[AT], pb[BT];
+    float px[4];
+    auto prefetch = [&](int tile) {
+        if (!head) {
+            const float4* src = reinterpret_cast<const float4*>(j.a_stash + ((size_t)tile * j.a_nt + j.a_t0) * 1024);
+#pragma unroll
+            for (int t = 0; t < AT; ++t) pa[t] = src[t * 256 + tid];
         } else {
-            for (int e = tid; e < 1024; e += kDwThreads) {
-                const int f = e >> 5, m = e & 31;
-                A[f * kDwPitch + m] = f == 0 ? j.dout[tile * 32 + m] : 0.f;
+            pa[0].x = tid < 32 ? j.dout[tile * 32 + tid] : 0.f;
+        }
+        if (j.b_kind == 0) {
+            const float4* src = reinterpret_cast<const float4*>(j.b_stash + ((size_t)tile * j.b_nt + j.b_t0) * 1024);
+#pragma unroll
+            for (int t = 0; t < BT; ++t) pb[t] = src[t * 256 + tid];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = tid + k * kDwThreads;  // (sample, column) of the gathered state copy xg [B_pad][D]
+                px[k] = e < 32 * j.Din ? j.xg[((size_t)tile * 32 + e / j.Din) * j.D + j.col0 + e % j.Din] : 0.f;
             }
         }
-        // ---- stage B
-        if (j.b_kind == 0) {
-            const float* src = j.b_stash + ((size_t)tile * j.b_nt + j.b_t0) * 1024;
-            for (int e = tid; e < BT * 1024; e += kDwThreads) {
-                const int t = e >> 10, r = (e >> 6) & 15, ln = e & 63;
-                Bm[t * kDwTile + feat32(r, ln >> 5) * kDwPitch + (ln & 31)] = src[e];
-            }
+    };
+    if (tile0 < tile_end) prefetch(tile0);
+    for (int tile = tile0; tile < tile_end; ++tile) {
+        __syncthreads();  // previous tile's operands fully consumed
+        if (!head) {
+#pragma unroll
+            for (int t = 0; t < AT; ++t) lds_put_frag4(A + t * kDwTile, tid, pa[t]);
         } else {
-            for (int e = tid; e < BT * 1024; e += kDwThreads) {
-                const int f = e >> 5, m = e & 31;  // feature f (0..32*BT), sample m
-                const int pos = tile * 32 + m;
-                const long long row = j.indices[pos < j.B ? pos : j.B - 1];
-                const float* x = j.state + (size_t)row * j.D + j.col0;
-                float v;
-                if (j.b_kind == 2) {
-                    v = f < j.Din ? x[f] : 0.f;
-                } else {
-                    float s = j.bias[f];
-                    for (int c = 0; c < j.Din; ++c) s = fmaf(x[c], j.W[(size_t)f * j.Din + c], s);
-                    v = j.act == 0 ? (s > 0.f ? s : 0.f) : fast_tanh(s);
-                }
-                Bm[(f >> 5) * kDwTile + (f & 31) * kDwPitch + m] = v;
+            for (int e = tid; e < 1024; e += kDwThreads) A[(e >> 5) * kDwPitch + (e & 31)] = 0.f;
+        }
+        if (j.b_kind == 0) {
+#pragma unroll
+            for (int t = 0; t < BT; ++t) lds_put_frag4(Bm + t * kDwTile, tid, pb[t]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = tid + k * kDwThreads;
+                if (e < 32 * j.Din) xs[e] = px[k];
             }
         }
         __syncthreads();
+        if (head && tid < 32) A[tid] = pa[0].x;  // feature row 0 = dOut
+        if (j.b_kind != 0) {  // B tile from the states: thread = (sample m, feature group)
+            const int m = tid & 31;
+            const float* xm = xs + m * j.Din;
+            if (j.b_kind == 2) {
+                for (int f = tid >> 5; f < 32; f += 8) Bm[f * kDwPitch + m] = (f < j.Din && !(dbg & 4)) ? xm[f] : 0.f;
+            } else {
+                const int nf = 32 * BT;
+                for (int f = tid >> 5; f < nf; f += 8) {
+                    float s = W1[nf * j.Din + f];
+                    for (int c = 0; c < j.Din; ++c) s = fmaf(xm[c], W1[f * j.Din + c], s);
+                    const float v = j.act == 0 ? (s > 0.f ? s : 0.f) : fast_tanh(s);
+                    Bm[(f >> 5) * kDwTile + (f & 31) * kDwPitch + m] = (dbg & 4) ? 0.f : v;
+                }
+            }
+        }
+        if (head || j.b_kind != 0) __syncthreads();
+        if (tile + 1 < tile_end) prefetch(tile + 1);
         if (j.db && tid < 32 * AT) {
             const float* rowp = A + (tid >> 5) * kDwTile + (tid & 31) * kDwPitch;
             float s = 0.f;
@@ -381,7 +435,7 @@ __device__ void dw_job(const DwJob& j, int tiles_per_wg, float* lds) {
 #pragma unroll
         for (int q = 0; q < PER_WAVE; ++q) {
             const int tq = wave + 4 * q;
-            if (tq < NQ) {
+            if (tq < NQ && !(dbg & 2)) {
                 const int ot = tq / BT, kt = tq % BT;
                 const float* ap = A + ot * kDwTile + li * kDwPitch + h;
                 const float* bp = Bm + kt * kDwTile + li * kDwPitch + h;
@@ -398,7 +452,7 @@ __device__ void dw_job(const DwJob& j, int tiles_per_wg, float* lds) {
         if (tq < NQ) {
             const int ot = tq / BT, kt = tq % BT;
             const int col = kt * 32 + li;
-            if (col < j.out_cols) {
+            if (col < j.out_cols && !(dbg & 1)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rowi = ot * 32 + feat32(r, h);
@@ -415,15 +469,47 @@ __global__ __launch_bounds__(kDwThreads) void ppo_dw_kernel(DwArgs a) {
     const DwJob& j = a.job[blockIdx.y];
     const int key = j.a_tiles * 8 + j.b_tiles;
     switch (key) {
-        case 4 * 8 + 4: dw_job<4, 4>(j, a.tiles_per_wg, lds); break;
-        case 2 * 8 + 4: dw_job<2, 4>(j, a.tiles_per_wg, lds); break;
-        case 4 * 8 + 1: dw_job<4, 1>(j, a.tiles_per_wg, lds); break;
-        case 1 * 8 + 4: dw_job<1, 4>(j, a.tiles_per_wg, lds); break;
-        case 2 * 8 + 2: dw_job<2, 2>(j, a.tiles_per_wg, lds); break;
-        case 1 * 8 + 2: dw_job<1, 2>(j, a.tiles_per_wg, lds); break;
-        case 2 * 8 + 1: dw_job<2, 1>(j, a.tiles_per_wg, lds); break;
+        case 4 * 8 + 4: dw_job<4, 4>(j, a.tiles_per_wg, a.debug_skip, lds); break;
+        case 2 * 8 + 4: dw_job<2, 4>(j, a.tiles_per_wg, a.debug_skip, lds); break;
+        case 4 * 8 + 1: dw_job<4, 1>(j, a.tiles_per_wg, a.debug_skip, lds); break;
+        case 1 * 8 + 4: dw_job<1, 4>(j, a.tiles_per_wg, a.debug_skip, lds); break;
+        case 2 * 8 + 2: dw_job<2, 2>(j, a.tiles_per_wg, a.debug_skip, lds); break;
+        case 1 * 8 + 2: dw_job<1, 2>(j, a.tiles_per_wg, a.debug_skip, lds); break;
+        case 2 * 8 + 1: dw_job<2, 1>(j, a.tiles_per_wg, a.debug_skip, lds); break;
         default: break;
     }
+}
+
+// ==================================================================================================== critic scale
+// obj_united = obj_actor + obj_critic / (r_sum[idx].std() + 1e-5)  (agent.py:652).  The critic kernel back-propagates
+// the UNSCALED SmoothL1 and accumulates sum / sum-of-squares of the minibatch targets it gathers anyway (float64
+// atomics); this kernel turns the moments into torch's unbiased std and scales the critic's gradient tensors.
+struct ScaleArgs {
+    float* grad[8];
+    int n[8];
+    const double* moments;
+    int B;
+    float* scale_out;
+};
+
+__global__ void critic_scale_kernel(ScaleArgs a) {
+    const double s = a.moments[0], ss = a.moments[1], B = (double)a.B;
+    const double var = a.B > 1 ? fmax((ss - s * s / B) / (B - 1.0), 0.0) : 0.0;
+    const float scale = (float)(1.0 / ((double)(float)sqrt(var) + 1e-5));
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.scale_out[0] = scale;
+    float* g = a.grad[blockIdx.y];
+    const int n = a.n[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) g[i] *= scale;
+}
+
+int launch_critic_scale(int D, int md, float* const* grads, const double* moments, int B, float* scale_out, hipStream_t s) {
+    ScaleArgs a{};
+    const int sizes[8] = {md * D, md, md * md, md, md * md, md, md, 1};
+    for (int i = 0; i < 8; ++i) { a.grad[i] = grads[i]; a.n[i] = sizes[i]; }
+    a.moments = moments; a.B = B; a.scale_out = scale_out;
+    hipLaunchKernelGGL(critic_scale_kernel, dim3(16, 8), dim3(256), 0, s, a);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
 }
 
 // ==================================================================================================== host side
@@ -433,7 +519,7 @@ int64_t ppo_bwd_image_floats(int kind, int D, int Di, int md) { return bwd_layou
 
 int64_t ppo_workspace_floats(int kind, int B, int md) {
     const int64_t ntiles = (B + 31) / 32;
-    return ntiles * stash_tiles(kind, md / 32) * 1024 + ntiles * 32;
+    return ntiles * stash_tiles(kind, md / 32) * 1024 + ntiles * 32 + ntiles * 32 * kMaxObsDim;
 }
 
 int launch_pack_bwd(int kind, int D, int Di, int md, const float* const* params, float* out, hipStream_t s) {
@@ -488,7 +574,7 @@ int build_dw_jobs(int kind, int md, const PpoArgs& a, const float* const* params
     int n = 0;
     auto base = [&]() {
         DwJob j{};
-        j.state = a.state; j.indices = a.indices; j.D = a.D; j.B = a.B; j.dout = a.dout;
+        j.xg = a.xg; j.D = a.D; j.B = a.B; j.dout = a.dout;
         return j;
     };
     auto stash_a = [&](DwJob& j, int t0, int tiles) { j.a_stash = a.stash; j.a_nt = NT; j.a_t0 = t0; j.a_tiles = tiles; };
@@ -519,10 +605,12 @@ int build_dw_jobs(int kind, int md, const PpoArgs& a, const float* const* params
 
 int launch_dw(const DwArgs& args, int B, hipStream_t s) {
     static bool attr_set = false;
-    const size_t lds_bytes = sizeof(float) * 8 * kDwTile;
+    int din_max = 1;
+    for (int i = 0; i < args.njobs; ++i) din_max = args.job[i].Din > din_max ? args.job[i].Din : din_max;
+    const size_t lds_bytes = sizeof(float) * (size_t)dw_lds_floats(din_max);
     if (!attr_set) {
         PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_dw_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * dw_lds_floats(kDwMaxDin))));
         attr_set = true;
     }
     const int ntiles = (B + 31) / 32;

@@ -9,10 +9,10 @@ struct PpoArgs {
     const int64_t* indices;                               // [B] minibatch rows
     int B, D, Di;
     const float* a_std_log;     // actor: [1] parameter
-    const float* critic_scale;  // critic: [1] device scalar 1/(r_sum[idx].std() + 1e-5)  (agent.py:652)
+    double* moments;            // critic: [2] sum and sum of squares of the minibatch targets (float64 atomics)
     float ratio_clip, lambda_entropy;
     const float *img_fwd, *img_bwd;
-    float *stash, *dout;
+    float *stash, *dout, *xg;  // xg: [tiles*32][D] gathered minibatch states
     float* loss_sums;  // [4]: sum(-surrogate), sum(entropy proxy), sum(smooth-l1), unused
     float* g_std;      // actor: gradient of a_std_log (accumulated)
 };
@@ -28,8 +28,7 @@ struct DwJob {
     int Din, col0, act;    // b_kind 1/2: state columns [col0, col0+Din); act of the recomputed layer
     float *dW, *db;        // dW row-major [a feats][ldw]
     int ldw, out_rows, out_cols;
-    const float* state;
-    const int64_t* indices;
+    const float* xg;       // [tiles*32][D] gathered minibatch states (written by the net kernel)
     int D, B;
 };
 
@@ -37,7 +36,7 @@ constexpr int kMaxDwJobs = 12;
 
 struct DwArgs {
     DwJob job[kMaxDwJobs];
-    int njobs, tiles_per_wg;
+    int njobs, tiles_per_wg, debug_skip;  // debug_skip: timing-only ablation bits (PIME_DW_DEBUG env), 0 in production
 };
 
 }  // namespace pime

@@ -113,6 +113,7 @@ class AgentPPO(AgentBase):
         self._packed = {}
         self.noise_hook = None  # tests: callable(t, shape) -> exploration noise tensor (else torch.randn)
         self.use_fused_update = True
+        self.use_hip_graphs = True
 
     # ---- construction ------------------------------------------------------------------------------------
     def _build_nets(self, net_dim, state_dim, action_dim):
@@ -132,7 +133,9 @@ class AgentPPO(AgentBase):
         groups = [{"params": self.act.parameters(), "lr": self.learning_rate},
                   {"params": self.cri.parameters(), "lr": self.learning_rate}]
         # fused=True: one multi-tensor kernel per step on the GPU instead of ~10 foreach launches
-        self.optimizer = torch.optim.Adam(groups, fused=True) if self.device.type == "cuda" else torch.optim.Adam(groups)
+        # capturable=True: the step counter lives on the device, so the step can be replayed from a HIP graph
+        self.optimizer = torch.optim.Adam(groups, fused=True, capturable=True) if self.device.type == "cuda" \
+            else torch.optim.Adam(groups)
         self.weights_changed()
 
     def init_actor_zero(self):
@@ -322,28 +325,58 @@ class AgentPPO(AgentBase):
 
     def _update_fused(self, fused, n_steps, buf_len, batch_size, repeat_times, buf_state, buf_action, buf_r_sum,
                       buf_logprob, buf_advantage):
-        """Per optimizer step: indices -> (tiny torch ops for the minibatch r_sum.std()) -> three HIP launches that
-        leave d(obj_united)/d(theta) in the flat gradient buffer -> optional ONE all-reduce -> Adam."""
+        """Per optimizer step: indices -> minibatch r_sum scale -> three HIP launches that leave d(obj_united)/d(theta)
+        in the flat gradient buffer -> optional ONE all-reduce -> Adam -> re-pack of the kernel weight images.
+
+        The launch sequence of a step is identical every time, so after one eager step (which also creates Adam's
+        state) it is captured into two HIP graphs -- [scale, zero, gradients] and [Adam, re-pack], split where the
+        data-parallel all-reduce goes -- and replayed: the update is otherwise bound by ~200 us/step of host work."""
         dev = buf_state.device
-        action = buf_action.reshape(-1).contiguous()
+        action = buf_action.reshape(-1)
+        assert action.is_contiguous() and buf_state.is_contiguous()
         fused.loss_sums.zero_()
-        crit_w = torch.zeros((), device=dev)
-        scale = torch.ones(1, device=dev)
+        st = self._fused_static(fused, buf_len, batch_size, dev)
+        st.r_sum.copy_(buf_r_sum); st.logprob.copy_(buf_logprob); st.adv.copy_(buf_advantage)
+        key = (buf_state.data_ptr(), action.data_ptr(), buf_len, batch_size)
+        if st.key != key:
+            st.key, st.graph_a, st.graph_b = key, None, None
+
+        def grads(idx):
+            fused.zero_grad()
+            fused(buf_state, action, st.logprob, st.adv, st.r_sum, idx, self.ratio_clip, self.lambda_entropy, st.scale)
+            st.scale_sum.add_(st.scale)
+
+        def apply():
+            self.optimizer.step()
+            fused.repack()
+
+        st.scale_sum.zero_()
         last = None
         for step in range(n_steps):
             indices = self._minibatch_indices(step, buf_len, batch_size, dev)
-            scale = (1.0 / (buf_r_sum[indices].std() + 1e-5)).reshape(1)           # agent.py:652
             if step == n_steps - 1:
                 last = fused.loss_sums.clone()
-            fused.zero_grad()
-            fused(buf_state, action, buf_logprob, buf_advantage, buf_r_sum, indices, self.ratio_clip,
-                  self.lambda_entropy, scale)
+            use_graph = self.use_hip_graphs and st.warm
+            if use_graph and st.graph_a is None:
+                torch.cuda.synchronize(dev)
+                st.graph_a, st.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(st.graph_a):
+                    grads(st.idx)
+                with torch.cuda.graph(st.graph_b):
+                    apply()
+            if use_graph:
+                st.idx.copy_(indices)
+                st.graph_a.replay()
+            else:
+                grads(indices)
             if self.dp is not None:
                 self.dp.all_reduce_sum(fused.flat_grad)
                 fused.flat_grad.div_(self.dp.world)
-            self.optimizer.step()
-            fused.repack()
-            crit_w += scale[0]
+            if use_graph:
+                st.graph_b.replay()
+            else:
+                apply()
+                st.warm = True
         self._packed = {"fused": fused}  # packed forward images of the value pass / rollout are stale now
         self._n_updates += int(repeat_times)
         if not n_steps:
@@ -353,10 +386,25 @@ class AgentPPO(AgentBase):
         B = float(batch_size)
         ent, cri = tot[1] / (n_steps * B), tot[2] / (n_steps * B)
         act = tot[0] / (n_steps * B) + self.lambda_entropy * ent
-        self._log_losses(act + cri * float(crit_w) / n_steps, act, cri, ent)
+        self._log_losses(act + cri * float(st.scale_sum) / n_steps, act, cri, ent)
         obj_a = (tot[0] - lst[0]) / B + self.lambda_entropy * (tot[1] - lst[1]) / B
         obj_c = (tot[2] - lst[2]) / B
         return obj_a, obj_c
+
+    def _fused_static(self, fused, buf_len, batch_size, dev):
+        """Tensors with stable addresses that the captured graphs read (the per-update r_sum / log-prob / advantage
+        buffers are fresh allocations, so they are copied in)."""
+        st = getattr(fused, "static", None)
+        if st is None or st.buf_len != buf_len or st.batch != batch_size:
+            import types
+            f32 = dict(dtype=torch.float32, device=dev)
+            st = types.SimpleNamespace(buf_len=buf_len, batch=batch_size, key=None, graph_a=None, graph_b=None, warm=False,
+                                       r_sum=torch.empty(buf_len, **f32), logprob=torch.empty(buf_len, **f32),
+                                       adv=torch.empty(buf_len, **f32), scale=torch.ones(1, **f32),
+                                       scale_sum=torch.zeros(1, **f32),
+                                       idx=torch.zeros(batch_size, dtype=torch.int64, device=dev))
+            fused.static = st
+        return st
 
     def _normalise_advantage(self, adv):
         """(adv - mean) / (std + 1e-5) over the WHOLE buffer with torch's unbiased std (agent.py:707); under data

@@ -134,6 +134,7 @@ class FusedPPOGrad:
         self._dump = torch.zeros(max(p.numel() for p in list(act.parameters()) + list(cri.parameters())),
                                  dtype=torch.float32, device=self.device)  # sink for frozen parameters' gradients
         self.loss_sums = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.moments = torch.zeros(2, dtype=torch.float64, device=self.device)
         for module in (act, cri):
             kind = module.packed_kind
             names = _PARAM_ORDER[kind]
@@ -210,7 +211,8 @@ class FusedPPOGrad:
 
     def __call__(self, state, action, logprob, adv, r_sum, indices, ratio_clip, lambda_entropy, critic_scale):
         """Accumulates d(obj_united)/d(theta) of the minibatch `indices` into the .grad views.  All tensors float32
-        CUDA and contiguous; state [L, D]; action/logprob/adv/r_sum [L]; indices int64 [B]; critic_scale float32 [1]."""
+        CUDA and contiguous; state [L, D]; action/logprob/adv/r_sum [L]; indices int64 [B]; critic_scale float32 [1]
+        is WRITTEN with 1/(r_sum[indices].std()+1e-5), the factor applied to the critic's gradients (agent.py:652)."""
         B = indices.numel()
         assert B <= self.max_batch and indices.dtype == torch.int64
         if self._structs is None:
@@ -221,5 +223,6 @@ class FusedPPOGrad:
         with torch.cuda.device(self.device):
             native.check(native.lib().pime_ppo_minibatch_grad(C.byref(actor), C.byref(critic), C.byref(batch),
                                                               C.c_float(ratio_clip), C.c_float(lambda_entropy),
-                                                              native.ptr(critic_scale), native.ptr(self.loss_sums),
+                                                              native.ptr(critic_scale), native.ptr(self.moments),
+                                                              native.ptr(self.loss_sums),
                                                               _stream(state)), "pime_ppo_minibatch_grad")

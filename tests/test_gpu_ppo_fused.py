@@ -76,8 +76,10 @@ def test_fused_gradients_match_autograd(kind, md, D, B):
     fused = ops.FusedPPOGrad(act, cri, B)
     fused.zero_grad()
     fused.loss_sums.zero_()
-    fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, clip, lam, scale)
+    got_scale = torch.zeros(1, device=DEV)
+    fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, clip, lam, got_scale)
     torch.cuda.synchronize()
+    np.testing.assert_allclose(got_scale.item(), scale.item(), rtol=3e-6)  # 1/(r_sum[idx].std()+1e-5), computed in-kernel
     got = {n: p.grad for n, p in list(act.named_parameters()) + [("cri." + k, v) for k, v in cri.named_parameters()]
            if p.requires_grad}
     assert set(got) == set(want)
