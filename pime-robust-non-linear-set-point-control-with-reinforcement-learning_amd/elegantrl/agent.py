@@ -44,6 +44,8 @@ class AgentBase:
     def _pick_device(self):
         if self.device is None:
             self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.backend.check_device(self.device)
         return self.device
 
@@ -332,12 +334,16 @@ class AgentPPO(AgentBase):
         state) it is captured into two HIP graphs -- [scale, zero, gradients] and [Adam, re-pack], split where the
         data-parallel all-reduce goes -- and replayed: the update is otherwise bound by ~200 us/step of host work."""
         dev = buf_state.device
-        action = buf_action.reshape(-1)
-        assert action.is_contiguous() and buf_state.is_contiguous()
         fused.loss_sums.zero_()
-        st = self._fused_static(fused, buf_len, batch_size, dev)
+        st = self._fused_static(fused, buf_len, batch_size, buf_state.shape[1], dev)
         st.r_sum.copy_(buf_r_sum); st.logprob.copy_(buf_logprob); st.adv.copy_(buf_advantage)
-        key = (buf_state.data_ptr(), action.data_ptr(), buf_len, batch_size)
+        # states / actions: the trajectory buffer's storage is already contiguous and address-stable; a flat ring
+        # buffer hands out strided column views, which are copied once per update
+        action = buf_action.reshape(-1)
+        if not (action.is_contiguous() and buf_state.is_contiguous()):
+            st.action.copy_(action); st.state.copy_(buf_state)
+            action, buf_state = st.action, st.state
+        key = (buf_state.data_ptr(), action.data_ptr())
         if st.key != key:
             st.key, st.graph_a, st.graph_b = key, None, None
 
@@ -391,7 +397,7 @@ class AgentPPO(AgentBase):
         obj_c = (tot[2] - lst[2]) / B
         return obj_a, obj_c
 
-    def _fused_static(self, fused, buf_len, batch_size, dev):
+    def _fused_static(self, fused, buf_len, batch_size, state_dim, dev):
         """Tensors with stable addresses that the captured graphs read (the per-update r_sum / log-prob / advantage
         buffers are fresh allocations, so they are copied in)."""
         st = getattr(fused, "static", None)
@@ -401,6 +407,7 @@ class AgentPPO(AgentBase):
             st = types.SimpleNamespace(buf_len=buf_len, batch=batch_size, key=None, graph_a=None, graph_b=None, warm=False,
                                        r_sum=torch.empty(buf_len, **f32), logprob=torch.empty(buf_len, **f32),
                                        adv=torch.empty(buf_len, **f32), scale=torch.ones(1, **f32),
+                                       action=torch.empty(buf_len, **f32), state=torch.empty((buf_len, state_dim), **f32),
                                        scale_sum=torch.zeros(1, **f32),
                                        idx=torch.zeros(batch_size, dtype=torch.int64, device=dev))
             fused.static = st

@@ -112,7 +112,9 @@ class VecControlEnv:
         if self.device.type != "cuda":
             raise native.PimeError(f"pime_amd envs run on a gfx950 GPU only (got device '{device}'); there is no "
                                    "CPU fallback")
-        cfg.device_id = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if self.device.index is None:  # "cuda" -> the concrete ordinal, so tensor.device comparisons are exact
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        cfg.device_id = self.device.index
         self._lib = native.lib()
         with torch.cuda.device(self.device):
             self._h = C.c_void_p(self._lib.pime_env_create(C.byref(cfg)))

@@ -1,0 +1,141 @@
+"""Host-side agent logic against the reference-generated golden (tests/golden/ppo_update.npz), on CPU tensors with
+the oracle injected as the backend (the product backend is HIP-only).  Pins, seed for seed:
+  * same-seed network initialisation (construction order / RNG consumption of the reference),
+  * AgentResidual*.explore_env on a one-instance env (actions, noise, rewards, masks exactly as the reference buffer),
+  * AgentPPO.update_net (GAE + PPO losses + Adam) given the recorded minibatch indices,
+  * the deterministic evaluation episode (run.py:600-619)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle.cpu_stack import OracleBackend
+from oracle_env import OracleSinglePH, OracleSingleWT
+
+CASES = {
+    "ph": dict(agent="AgentResidualIntegratorModularPPO", state_dim=3, integrator=1),
+    "wt": dict(agent="AgentResidualPPO", state_dim=3, integrator=None),
+}
+
+
+def _sd(g, prefix):
+    return {k[len(prefix) + 1:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(prefix + ".")}
+
+
+def _agent(tag, g):
+    from pime_amd.elegantrl import agent_residual
+    hyper = g[f"{tag}:hyper"]
+    net_dim, lam = int(hyper[0]), float(hyper[4])
+    c = CASES[tag]
+    ag = getattr(agent_residual, c["agent"])(backend=OracleBackend(), device="cpu")
+    ag.lambda_gae_adv = lam
+    torch.manual_seed(3)
+    if c["integrator"] is not None:
+        ag.init(net_dim, c["state_dim"], 1, c["integrator"])
+    else:
+        ag.init(net_dim, c["state_dim"], 1)
+    K = np.array([-0.02, 0.02, 0.035]) if tag == "ph" else np.array([0., 0.4, -0.4])
+    ag.init_residual({"init_K": K.reshape(-1, 1)})
+    ag.init_actor_zero()
+    ag.fix_K()
+    with torch.no_grad():
+        ag.act.net[-1].weight.normal_(0, 0.05)
+    ag.weights_changed()
+    return ag, hyper
+
+
+@pytest.mark.parametrize("tag", ["ph", "wt"])
+def test_same_seed_initialisation(tag):
+    g = load_golden("ppo_update.npz")
+    ag, _ = _agent(tag, g)
+    for name, net in (("act0", ag.act), ("cri0", ag.cri)):
+        want = _sd(g, f"{tag}:{name}")
+        got = net.state_dict()
+        assert set(got) == set(want)
+        for k in want:
+            np.testing.assert_array_equal(got[k].numpy(), want[k].numpy(), err_msg=f"{name}.{k}")
+
+
+@pytest.mark.parametrize("tag", ["ph", "wt"])
+def test_explore_env_single_instance(tag, ph_table_oracle):
+    """The reference buffer (states, reward, mask, pre-tanh action, noise) is reproduced exactly: the torch RNG is in
+    the same state as the reference's after the same-seed construction, the env draws are injected."""
+    from pime_amd.elegantrl.replay import ReplayBuffer
+    g = load_golden("ppo_update.npz")
+    ag, hyper = _agent(tag, g)
+    target_step = int(hyper[1])
+    if tag == "ph":
+        env = OracleSinglePH(ph_table_oracle, g["ph:draws"])
+    else:
+        env = OracleSingleWT(g["wt:draws"], g["wt:step_noise"], num_stack=1)
+    buf = ReplayBuffer(target_step + env.max_step, env.state_dim, 1, if_on_policy=True, device="cpu")
+    steps = ag.explore_env(env, buf, target_step, 1.0, 0.99)
+    assert steps == int(g[f"{tag}:steps"])
+    buf.update_now_len_before_sample()
+    np.testing.assert_array_equal(buf.buf_state[:buf.now_len].numpy(), g[f"{tag}:buf_state"])
+    got, want = buf.buf_other[:buf.now_len].numpy(), g[f"{tag}:buf_other"]
+    np.testing.assert_array_equal(got[:, 1], want[:, 1])           # mask
+    np.testing.assert_array_equal(got[:, 3], want[:, 3])           # noise (same torch stream)
+    np.testing.assert_allclose(got[:, 2], want[:, 2], rtol=0, atol=0)  # pre-tanh action
+    np.testing.assert_allclose(got[:, 0], want[:, 0], rtol=1e-6, atol=1e-6)  # reward*scale
+
+
+@pytest.mark.parametrize("tag", ["ph", "wt"])
+def test_update_net_matches_reference(tag):
+    from pime_amd.elegantrl.replay import ReplayBuffer
+    g = load_golden("ppo_update.npz")
+    ag, hyper = _agent(tag, g)
+    target_step, batch, repeat = int(hyper[1]), int(hyper[2]), int(hyper[3])
+    ag.act.load_state_dict(_sd(g, f"{tag}:act0"))
+    ag.cri.load_state_dict(_sd(g, f"{tag}:cri0"))
+    ag.weights_changed()
+    state, other = g[f"{tag}:buf_state"], g[f"{tag}:buf_other"]
+    buf = ReplayBuffer(len(state) + 8, state.shape[1], 1, if_on_policy=True, device="cpu")
+    buf.extend_buffer(state, other)
+    idx = g[f"{tag}:indices"]
+    ag.index_hook = lambda step, L, B: torch.from_numpy(idx[step])
+    obj_a, obj_c = ag.update_net(buf, target_step, batch, repeat)
+    assert idx.shape[0] == int(repeat * len(state) / batch)
+    for name, net in (("act1", ag.act), ("cri1", ag.cri)):
+        want = _sd(g, f"{tag}:{name}")
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), want[k].numpy(), rtol=0, atol=2e-6, err_msg=f"{name}.{k}")
+    np.testing.assert_allclose([obj_a, obj_c], g[f"{tag}:obj"], rtol=2e-4, atol=1e-5)
+
+
+def test_evaluation_episode(ph_table_oracle):
+    """get_episode_return with the updated reference policy on the seeded env (run.py:600-619)."""
+    from pime_amd.elegantrl.run import get_episode_return
+    from pime_amd import gym_compat
+    g = load_golden("ppo_update.npz")
+    ag, _ = _agent("ph", g)
+    ag.act.load_state_dict(_sd(g, "ph:act1"))
+    # the reference seeded env.seed(17); np.random.seed(17) and then reset(): params from the global stream, x0/r from np_random
+    glob = np.random.RandomState(17)
+    envrng, _ = gym_compat.np_random(17)
+    qww, qc = glob.uniform(0.005, 0.015), glob.uniform(0.0015, 0.0025)
+    x0, r = envrng.uniform(low=0, high=50), envrng.uniform(3., 11.)
+    env = OracleSinglePH(ph_table_oracle, [(qww, qc, x0, r)])
+    ret, n = get_episode_return(env, ag.act, torch.device("cpu"))
+    want_ret, want_n = g["ph:eval"]
+    assert n == int(want_n)
+    # Not bitwise: in the reference's EVALUATION path the action is a float32 array, and because the freshly reset
+    # plant state is a python float, numpy's weak-scalar promotion turns `A*state + B*action` (ph.py:330) and the
+    # np.around of the LUT lookup (ph.py:188) into float32 arithmetic from the first step on (measured: state becomes
+    # a float32 ndarray; the LUT index is then k or k+1).  The rollout path (float64 actions, agent_residual.py:61)
+    # stays float64 and is reproduced exactly above.  This build keeps float64 everywhere: returns agree to 2e-4.
+    np.testing.assert_allclose(ret, want_ret, rtol=2e-4)
+
+
+def test_replay_buffer_ring_semantics():
+    from pime_amd.elegantrl.replay import ReplayBuffer
+    b = ReplayBuffer(10, 2, 1, if_on_policy=False, device="cpu")
+    for i in range(7):
+        b.append_buffer(np.array([i, -i], dtype=np.float32), (float(i), 0.99, 0.5))
+    b.extend_buffer(np.arange(12, dtype=np.float32).reshape(6, 2), np.ones((6, 3), dtype=np.float32) * 7)
+    assert b.if_full and b.next_idx == 3
+    b.update_now_len_before_sample()
+    assert b.now_len == 10
+    r, m, a, s, s2 = b.sample_batch(4, indices=torch.tensor([0, 1, 7, 8]))
+    np.testing.assert_array_equal(s2.numpy(), b.buf_state[[1, 2, 8, 9]].numpy())  # successor = next row
+    assert r.shape == (4, 1) and a.shape == (4, 1)

@@ -1,0 +1,89 @@
+"""Data-parallel path on CPU: world_size 2 over gloo (the GPU path uses the same code over RCCL).
+Two ranks, each with its own slice of env lanes (different Philox lane offsets) and exploration stream; after
+explore + update the replicas must be bit-identical, the flat-gradient all-reduce must equal the mean of the local
+gradients, and the advantage normalisation must use the moments of the UNION of both slices (agent.py:707)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    from oracle.cpu_stack import OracleBackend, OracleVecEnv
+    from pime_amd import dist as pdist
+    from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from pime_amd.elegantrl.replay import TrajectoryBuffer
+    dp = pdist.init_from_env(backend="gloo", device="cpu")
+    assert dp is not None and dp.world == world and dp.rank == rank
+    n = 32
+    env = OracleVecEnv("ph", n, seed=5, env_offset=dp.lane_offset(n))
+    torch.manual_seed(100 + rank)             # replicas start DIFFERENT on purpose ...
+    agent = AgentResidualIntegratorModularPPO(backend=OracleBackend(), device="cpu")
+    agent.lambda_gae_adv = 0.99
+    agent.init(32, 3, 1, 1)
+    agent.init_residual({"init_K": env.K.reshape(-1, 1)})
+    with torch.no_grad():
+        agent.act.net[-1].weight.normal_(0, 0.05)
+    agent.dp = dp
+    dp.broadcast_module(agent.act, agent.cri)  # ... and are made equal by the rank-0 broadcast
+    torch.manual_seed(1000 + rank)             # exploration / minibatch streams differ per rank
+    buf = TrajectoryBuffer(50, n, 3, 1, "cpu")
+    steps = agent.explore_env(env, buf, n * 50, 1.0, 0.99)
+
+    # (1) gradient averaging: local grads -> all-reduce -> compare with an all_gather'ed mean
+    params = [p for g in agent.optimizer.param_groups for p in g["params"]]
+    for p in params:
+        p.grad = torch.full_like(p, float(rank + 1)) * torch.arange(p.numel(), dtype=torch.float32).view_as(p)
+    local = torch.cat([p.grad.reshape(-1) for p in params]).clone()
+    agent.dp.average_gradients(params)
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    torch.distributed.all_gather(gathered, local)
+    avg_ok = torch.allclose(torch.cat([p.grad.reshape(-1) for p in params]), torch.stack(gathered).mean(0))
+
+    # (2) advantage normalisation over the union of both slices
+    adv_local = torch.randn(n * 50, generator=torch.Generator().manual_seed(7 + rank)) * (rank + 1) + rank
+    normed = agent._normalise_advantage(adv_local)
+    all_adv = [torch.zeros_like(adv_local) for _ in range(world)]
+    torch.distributed.all_gather(all_adv, adv_local)
+    union = torch.cat(all_adv)
+    want = (adv_local - union.mean()) / (union.std() + 1e-5)
+    norm_ok = torch.allclose(normed, want, rtol=1e-5, atol=1e-5)
+
+    # (3) a real update keeps the replicas identical
+    agent.update_net(buf, n * 50, 256, 2)
+    flat = torch.cat([p.detach().reshape(-1) for p in list(agent.act.parameters()) + list(agent.cri.parameters())])
+    torch.save({"flat": flat, "avg_ok": bool(avg_ok), "norm_ok": bool(norm_ok), "steps": steps,
+                "obs0": buf.state[0].clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo(tmp_path):
+    import oracle
+    oracle.build()  # compile the oracle once, before the ranks race for it
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"rank{k}.pt"), weights_only=True) for k in range(world)]
+    assert all(x["avg_ok"] for x in r), "flat-gradient all-reduce != mean of the local gradients"
+    assert all(x["norm_ok"] for x in r), "advantage normalisation is not over the union of the ranks' buffers"
+    assert r[0]["steps"] == r[1]["steps"] == 32 * 50
+    assert torch.equal(r[0]["flat"], r[1]["flat"]), "replicas diverged"
+    assert not torch.equal(r[0]["obs0"], r[1]["obs0"]), "ranks simulated the same env lanes (lane offset ignored)"

@@ -1,0 +1,243 @@
+"""The drop-in surface on the GPU: gym.make ids, the one-instance facades with the reference's class names / methods,
+seed-for-seed trajectories (global np.random + gym-seeded np_random exactly as the reference consumes them), the
+evaluation protocols of utils/test.py and utils/robust_test.py, PreprocessEnv metadata, and the MT19937 replay mode
+of the vectorised env (lane i == reference env seeded with base+i)."""
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gym():
+    from pime_amd import gym_compat, gym_control  # noqa: F401
+    return gym_compat
+
+
+def test_registry_and_metadata(gym):
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.env import PreprocessEnv
+    ids = sorted(gym.registry.env_specs)
+    assert gym_control.PH_V35 in ids and gym_control.PH_NOIB_V35 in ids and gym_control.WT_INTEGRATOR in ids
+    assert {gym_control.WT_STACKING.format(s) for s in (1, 4, 10)} <= set(ids)
+    env = PreprocessEnv(gym.make(gym_control.PH_V35), if_print=False)
+    assert (env.env_name, env.state_dim, env.action_dim, env.action_max, env.max_step, env.if_discrete) == \
+        (gym_control.PH_V35, 3, 1, 1.0, 50, False)          # max_step from TimeLimit._max_episode_steps
+    assert env.n_integrator == 1 and list(env.K) == [-0.02, 0.02, 0.035]
+    wt = PreprocessEnv(gym.make(gym_control.WT_INTEGRATOR, reward_type="distance", r=4.0), if_print=False)
+    assert (wt.state_dim, wt.max_step) == (4, 200) and wt.observation_space.low[0] == 0 and np.signbit(wt.observation_space.low[0])
+    st = PreprocessEnv(gym.make(gym_control.WT_STACKING.format(10), reward_type="distance", r=4.0), if_print=False)
+    assert st.state_dim == 30 and st.K.shape == (30,) and list(st.K[-3:]) == [0., 0.4, -0.4]
+
+
+@pytest.mark.parametrize("tag,env_id,kw", [("v35", "PH_V35", {}), ("noib", "PH_NOIB_V35", {}),
+                                           ("dist", "PH_V35", dict(reward_type="distance")),
+                                           ("punish", "PH_V35", dict(action_punishment=0.1, action_change_punishment=0.2))])
+def test_ph_facade_seed_for_seed(gym, tag, env_id, kw):
+    """env.seed(s); np.random.seed(s); reset(); 50 steps -- exactly the reference's numbers for seeds 0..3."""
+    from pime_amd import gym_control
+    g = load_golden("ph_rollouts.npz")
+    env = gym.make(getattr(gym_control, env_id), **kw)
+    if tag == "punish":
+        env.unwrapped.integral_punish = 0.05
+    K = np.array([-0.02, 0.02, 0.035])
+    for pol in ("prior", "resid"):
+        p = f"{tag}_{pol}_"
+        for s in range(4):
+            env.seed(s)
+            np.random.seed(s)
+            obs = env.reset()
+            u = env.unwrapped
+            np.testing.assert_allclose([u.qww_V, u.qc_V], g[p + "params"][s], rtol=1e-15)
+            np.testing.assert_allclose(obs, g[p + "obs0"][s], rtol=0, atol=1e-12)
+            for t in range(50):
+                obs, rew, done, info = env.step(g[p + "act"][s, t])
+                np.testing.assert_allclose(obs, g[p + "obs"][s, t], rtol=0, atol=1e-11)
+                np.testing.assert_allclose(u.state, g[p + "x"][s, t], rtol=1e-12)
+                np.testing.assert_allclose(rew, g[p + "rew"][s, t], rtol=2e-7, atol=1e-6)  # float32 reward word
+                assert done == bool(g[p + "done"][s, t])                                    # TimeLimit at 50
+    env.close()
+
+
+def test_ph_facade_chain_and_keep_params(gym):
+    from pime_amd import gym_control
+    g = load_golden("ph_rollouts.npz")
+    env = gym.make(gym_control.PH_V35)
+    env.seed(100)
+    np.random.seed(100)
+    K = np.array([-0.02, 0.02, 0.035])
+    for k in range(3):
+        obs = env.reset()
+        np.testing.assert_allclose(obs, g["chain_obs0"][k], atol=1e-12)
+        for t in range(50):
+            obs, rew, done, _ = env.step(float(obs.astype(np.float32) @ (-K)))
+            np.testing.assert_allclose(obs, g["chain_obs"][k, t], atol=1e-11)
+    env.seed(101)
+    np.random.seed(101)
+    env.reset()
+    env.unwrapped.set_reset_all(False)
+    for k in range(2):
+        obs = env.reset()
+        np.testing.assert_allclose(env.unwrapped.get_changable_parameters(), g["keep_params"][k], rtol=1e-15)
+        for t in range(50):
+            obs, rew, done, _ = env.step(g["keep_act"][k, t])
+            np.testing.assert_allclose(obs, g["keep_obs"][k, t], atol=1e-11)
+    env.close()
+
+
+def test_ph_step_response_protocol(gym):
+    """utils/test.py:1369-1407 driven through the facade's set_state / set_r / attribute surface."""
+    from pime_amd import gym_control
+    g = load_golden("ph_stepresponse.npz")
+    env = gym.make(gym_control.PH_V35)
+    u = env.unwrapped
+    env.seed(7)
+    np.random.seed(7)
+    u.set_reset_all(False)
+    K = np.array([-0.02, 0.02, 0.035])
+    for tag in ("nominal", "corner"):
+        u.set_params(*g[tag + "_params"])          # rebuilds the plant (the reference needs update_system for that)
+        last_state = np.zeros(1)
+        i = 0
+        for r in [10., 6, 3, 8, 5]:
+            env.reset()
+            env.set_state(last_state)
+            state = env.set_r(r)
+            for n in range(u.max_episode_steps):
+                a = float(state.astype(np.float32) @ (-K))
+                assert abs(a - g[tag + "_act"][i]) < 1e-12
+                assert abs(u.y - g[tag + "_y"][i]) < 1e-11 and u.r == g[tag + "_r"][i]
+                state, rew, done, info = env.step(a)
+                np.testing.assert_allclose(u.state, g[tag + "_x"][i], rtol=1e-12)
+                np.testing.assert_allclose(rew, g[tag + "_rew"][i], rtol=2e-7, atol=1e-6)
+                i += 1
+            last_state = u.state
+    env.close()
+
+
+@pytest.mark.parametrize("tag,kw", [("dist", dict(reward_type="distance", r=4.0)), ("sq", {}),
+                                    ("zero", dict(noise_scale=0., reward_type="distance", r=4.0))])
+def test_wt_facade_seed_for_seed(gym, tag, kw):
+    """All draws -- params, levels, goal and the per-step process noise -- come from the global np.random stream."""
+    from pime_amd import gym_control
+    g = load_golden("wt_rollouts.npz")
+    env = gym.make(gym_control.WT_INTEGRATOR, **kw)
+    for pol in ("prior", "resid"):
+        p = f"{tag}_{pol}_"
+        for s in range(2):
+            env.seed(s)
+            np.random.seed(s)
+            obs = env.reset()
+            np.testing.assert_allclose(env.get_changable_parameters(), g[p + "params"][s], rtol=1e-15)
+            np.testing.assert_allclose(obs, g[p + "obs0"][s], atol=1e-12)
+            for t in range(200):
+                obs, rew, done, _ = env.step(g[p + "act"][s, t])
+                np.testing.assert_allclose(obs, g[p + "obs"][s, t], rtol=1e-12, atol=1e-12)
+                np.testing.assert_allclose(rew, g[p + "rew"][s, t], rtol=2e-7, atol=1e-6)
+                assert done == bool(g[p + "done"][s, t])
+    env.close()
+
+
+def test_wt_robust_protocol_and_deepcopy(gym):
+    """utils/robust_test.py:4-46: deepcopy the env, overwrite a1/a2/Kp/max_step/if_reset_all by attribute, then run the
+    step-response protocol of utils/test.py:209-349."""
+    from pime_amd import gym_control
+    g = load_golden("wt_stepresponse.npz")
+    base = gym.make(gym_control.WT_INTEGRATOR, noise_scale=0., reward_type="distance", r=4.0)
+    base.seed(3)
+    np.random.seed(3)
+    base.reset()
+    K = np.array([0., 0.4, -0.4, 0.])
+    for tag in ("nominal", "robust1", "robust3"):
+        a1, a2, Kp, T = g[tag + "_params"]
+        env = deepcopy(base)
+        env.a1, env.a2, env.Kp = a1, a2, Kp
+        env.if_reset_all = False
+        env.max_step = int(T)
+        env.integral_punish = 0.
+        assert env.get_changable_parameters() == (a1, a2, Kp)
+        h1 = h2 = 0.
+        i = 0
+        for r in [3., 6., 9., 4., 2.]:
+            env.reset()
+            env.set_state(h1, h2)
+            state = env.set_r(r)
+            assert env.get_changable_parameters() == (a1, a2, Kp)   # reset kept them
+            for n in range(int(T)):
+                state, rew, done, _ = env.step(float(state.astype(np.float32) @ (-K)))
+                np.testing.assert_allclose(state, g[tag + "_obs"][i], rtol=1e-11, atol=1e-12)
+                i += 1
+            h1, h2 = env.h1, env.h2
+        env.close()
+    assert base.max_step == 200   # the copy's edits did not leak
+    base.close()
+
+
+@pytest.mark.parametrize("S", [1, 4, 10])
+def test_wt_stacking_facade(gym, S):
+    from pime_amd import gym_control
+    g = load_golden("wt_stacking.npz")
+    env = gym.make(gym_control.WT_STACKING.format(S), reward_type="distance", r=4.0)
+    env.seed(5)
+    np.random.seed(5)
+    p = f"s{S}_"
+    for k in range(2):
+        obs = env.reset()
+        np.testing.assert_allclose(obs, g[p + "obs0"][k], rtol=2e-7)
+        for t in range(24):
+            obs, rew, done, _ = env.step(g[p + "act"][k, t])
+            np.testing.assert_allclose(obs[-3:], g[p + "obs"][k, t][-3:], rtol=1e-12)      # newest frame: float64
+            np.testing.assert_allclose(obs, g[p + "obs"][k, t], rtol=2e-7)                 # older frames: float32 words
+    env.close()
+
+
+def test_vec_mt19937_replay_mode():
+    """VecPH(draws='mt19937', seed=0): lane i reproduces the reference env seeded with i (16 golden seeds at once)."""
+    from pime_amd import gym_control
+    g = load_golden("ph_rollouts.npz")
+    env = gym_control.make_vec(gym_control.PH_V35, 16, device="cuda:0", state_mode="f64", seed=0, draws="mt19937")
+    obs = env.reset()
+    np.testing.assert_array_equal(obs.cpu().numpy(), g["v35_prior_obs0"].astype(np.float32))
+    for t in range(50):
+        act = torch.as_tensor(g["v35_prior_act"][:, t], device="cuda:0")
+        obs, rew, done = env.step(act, auto_reset=False)
+        np.testing.assert_array_equal(obs.cpu().numpy(), g["v35_prior_obs"][:, t].astype(np.float32))
+    env.close()
+    wt = gym_control.make_vec(gym_control.WT_INTEGRATOR, 8, device="cuda:0", state_mode="f64", seed=0, draws="mt19937",
+                              reward_type="distance")
+    gw = load_golden("wt_rollouts.npz")
+    obs = wt.reset()
+    np.testing.assert_array_equal(obs.cpu().numpy(), gw["dist_prior_obs0"].astype(np.float32))
+    for t in range(200):
+        obs, rew, done = wt.step(torch.as_tensor(gw["dist_prior_act"][:, t], device="cuda:0"), auto_reset=False)
+        np.testing.assert_allclose(obs.cpu().numpy(), gw["dist_prior_obs"][:, t].astype(np.float32), rtol=1.2e-7)
+    wt.close()
+
+
+def test_train_entry_point_vectorised(tmp_path):
+    """python -m pime_amd.train with the reference's flags + --num_envs: two explore/update rounds end to end."""
+    from pime_amd import train
+    agent = train.main(["--algo", "ResidualIntegratorModularPPO", "--fix_K", "--env",
+                        "PH1DChangingParamUniformGoalIntegrator-SqaureDistance-v35", "--net_dim", "128", "--num_envs", "512",
+                        "--target_step", str(512 * 50), "--batch_size", "4096", "--repeat_times", "2", "--break_step",
+                        str(2 * 512 * 50), "--eval_times1", "8", "--eval_times2", "16", "--eval_gap", "1",
+                        "--lambda_gae_adv", "0.99", "--log_root", str(tmp_path)])
+    assert agent.act.priorK.requires_grad is False
+    files = [str(p) for p in tmp_path.rglob("*")]
+    assert any(f.endswith("actor.pth") for f in files) and any(f.endswith("critic.pth") for f in files)
+    assert any(f.endswith("progress.csv") for f in files) and any(f.endswith("args.txt") for f in files)
+
+
+def test_train_entry_point_single_instance(tmp_path):
+    """--num_envs 1: the gym.make + PreprocessEnv path of the reference's train.py, one instance on the GPU."""
+    from pime_amd import train
+    agent = train.main(["--algo", "ResidualPPO", "--env", "NonLinearWaterTankChangingParamUniformGoalStacking1-SquareDistance-v2",
+                        "--net_dim", "64", "--target_step", "400", "--batch_size", "128", "--repeat_times", "2",
+                        "--break_step", "400", "--eval_times1", "1", "--eval_times2", "2", "--eval_gap", "1",
+                        "--test_render_times", "400", "--log_root", str(tmp_path)])
+    assert agent.act.net[0].in_features == 3
