@@ -41,6 +41,8 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PH_STEP_BYTES = 94            # mixed mode, fused-residual step: see DESIGN.md table
 MLP_FLOPS_PER_ROW = {"critic": 2 * (3 * 128 + 128 * 128 * 2 + 128),
                      "modular_actor": 2 * (2 * 128 + 128 * 64 + 1 * 128 + 128 * 64 + 128 * 128 + 128)}
+# one minibatch gradient = forward + backward-dX + dW of both nets: 3 x 2 flop per weight per sample
+GRAD_FLOPS_PER_SAMPLE = 3 * (MLP_FLOPS_PER_ROW["critic"] + MLP_FLOPS_PER_ROW["modular_actor"])
 
 
 class KernelTimer:
@@ -62,9 +64,36 @@ class KernelTimer:
             return out
         return timed
 
+    def bracket(self, name, thunk):
+        if not self.enabled:
+            return thunk()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = thunk()
+        e.record()
+        self.pairs.setdefault(name, []).append((s, e))
+        return out
+
     def summary(self):
         torch.cuda.synchronize()
         return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.pairs.items()}
+
+
+def pmc_traffic_bytes(kernel_prefixes):
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/
+    r01_c_pmc_hbm_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters
+    cannot be read from inside the process, so this is the measured figure of the same command, or None."""
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    data = json.load(open(path))
+    total = 0.0
+    for pref in kernel_prefixes:
+        hit = [v for k, v in data.items() if pref in k]
+        if not hit:
+            return None
+        total += (hit[0]["fetch_mb_corrected"] + hit[0]["write_mb"]) * 1024 * 1024
+    return total
 
 
 def log(msg):
@@ -103,7 +132,7 @@ def one_step(env, agent, buf):
 
 def cpu_baseline():
     """The same hot path on the host: C oracle envs + torch-CPU nets with the product's own agent code, on a bounded
-    sample (2 048 lanes x one 50-step episode, batch 8 192, repeat 8 -> 100 optimizer steps, like the GPU schedule)."""
+    sample: ONE step of the same workload (16 384 lanes x one 50-step episode, batch 65 536, repeat 8 -> 100 optimizer steps)."""
     import oracle  # noqa: F401  (allowed here: bench.py's cpu_baseline leg)
     from oracle.cpu_stack import OracleBackend, OracleVecEnv
     from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
@@ -111,7 +140,7 @@ def cpu_baseline():
     # the box's CPU share, not the host's core count (oversubscribing torch's intra-op pool stalls for minutes)
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
-    n = 2048
+    n = LANES  # the full workload: ~15 s of host time
     env = OracleVecEnv("ph", n, seed=0)
     torch.manual_seed(0)
     agent = AgentResidualIntegratorModularPPO(backend=OracleBackend(), device="cpu")
@@ -154,6 +183,7 @@ def main():
     agent.policy_mean = timer.wrap("mlp_forward<modular_actor> rollout", agent.policy_mean)
     env.step_residual = timer.wrap("ph_step_kernel (fused residual)", env.step_residual)
     agent.backend.gae = timer.wrap("gae_scan_kernel", agent.backend.gae)
+    agent.launch_timer = timer.bracket  # "ppo_minibatch_grad": the 4 launches of one minibatch gradient
 
     def sync():
         torch.cuda.synchronize()
@@ -198,7 +228,18 @@ def main():
     per_step = {k: n * ms / args.steps for k, (n, ms) in ks.items()}
     dominant = max(per_step, key=per_step.get)
     n_dom, ms_dom = ks[dominant]
-    if "critic" in dominant or "actor" in dominant:
+    if dominant == "ppo_minibatch_grad":
+        achieved = GRAD_FLOPS_PER_SAMPLE * BATCH / (ms_dom * 1e-3) / 1e12
+        roofline = {"kernel": "ppo_minibatch_grad = ppo_fwd_bwd_kernel<critic> + ppo_fwd_bwd_kernel<modular_actor> + "
+                              "ppo_dw_kernel + critic_scale_kernel (one minibatch of 65536; per-kernel split in "
+                              "profiles/)", "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                    "traffic": pmc_traffic_bytes(["ppo_fwd_bwd_kernel<4, 0>", "ppo_fwd_bwd_kernel<4, 2>", "ppo_dw_kernel",
+                                                  "critic_scale_kernel"]),
+                    "traffic_source": "profiles/r01_c_pmc_hbm_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2)",
+                    "launches_per_step": n_dom / args.steps, "avg_launch_ms": ms_dom,
+                    "algorithmic_flops_per_launch": GRAD_FLOPS_PER_SAMPLE * BATCH}
+    elif "critic" in dominant or "actor" in dominant:
         kind = "critic" if "critic" in dominant else "modular_actor"
         rows = LANES * T_EP if kind == "critic" else LANES
         achieved = MLP_FLOPS_PER_ROW[kind] * rows / (ms_dom * 1e-3) / 1e12
@@ -210,6 +251,8 @@ def main():
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches_per_step": n_dom / args.steps,
                     "avg_launch_ms": ms_dom}
+    n_v, ms_v = ks["mlp_forward<critic> value pass"]
+    v_tf = MLP_FLOPS_PER_ROW["critic"] * LANES * T_EP / (ms_v * 1e-3) / 1e12
     n_env, ms_env = ks["ph_step_kernel (fused residual)"]
     env_gbs = PH_STEP_BYTES * LANES / (ms_env * 1e-3) / 1e9
     out = {
@@ -223,8 +266,12 @@ def main():
                    "state_mode": "mixed (f32 state, f64 x/A/B/C)", "parallelism": f"dp{world}"},
         "roofline": roofline,
         "roofline_env": {"kernel": "ph_step_kernel (fused residual)", "bound": "hbm", "achieved": env_gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": env_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": env_gbs / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_bytes(["ph_step_kernel"]), "algorithmic_bytes_per_launch": PH_STEP_BYTES * LANES,
                          "avg_launch_ms": ms_env, "note": "16384-lane launch moves 1.5 MB: launch-latency bound"},
+        "roofline_value_pass": {"kernel": "mlp_forward_kernel<4, critic> (819200 rows)", "bound": "mfma", "achieved": v_tf,
+                                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": v_tf / F32_MFMA_PEAK_TFLOPS,
+                                "avg_launch_ms": ms_v},
         "breakdown_ms": {"rollout": t_roll * 1e3, "update": t_upd * 1e3,
                          "hand_written_kernels_per_step": per_step},
     }

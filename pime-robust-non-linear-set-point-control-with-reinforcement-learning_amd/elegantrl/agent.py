@@ -116,6 +116,7 @@ class AgentPPO(AgentBase):
         self.noise_hook = None  # tests: callable(t, shape) -> exploration noise tensor (else torch.randn)
         self.use_fused_update = True
         self.use_hip_graphs = True
+        self.launch_timer = None  # optional callable(name, thunk) that brackets the thunk with HIP events
 
     # ---- construction ------------------------------------------------------------------------------------
     def _build_nets(self, net_dim, state_dim, action_dim):
@@ -372,9 +373,13 @@ class AgentPPO(AgentBase):
                     apply()
             if use_graph:
                 st.idx.copy_(indices)
-                st.graph_a.replay()
+                run = st.graph_a.replay
             else:
-                grads(indices)
+                run = lambda: grads(indices)  # noqa: E731
+            if self.launch_timer is not None:   # bench.py: HIP events around the gradient launches only
+                self.launch_timer("ppo_minibatch_grad", run)
+            else:
+                run()
             if self.dp is not None:
                 self.dp.all_reduce_sum(fused.flat_grad)
                 fused.flat_grad.div_(self.dp.world)
