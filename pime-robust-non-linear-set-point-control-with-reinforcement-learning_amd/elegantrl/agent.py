@@ -366,11 +366,18 @@ class AgentPPO(AgentBase):
             use_graph = self.use_hip_graphs and st.warm
             if use_graph and st.graph_a is None:
                 torch.cuda.synchronize(dev)
-                st.graph_a, st.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(st.graph_a):
-                    grads(st.idx)
-                with torch.cuda.graph(st.graph_b):
-                    apply()
+                try:
+                    # thread_local: the RCCL watchdog thread of a data-parallel run may touch the HIP API meanwhile
+                    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                        grads(st.idx)
+                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                        apply()
+                    st.graph_a, st.graph_b = ga, gb
+                except RuntimeError as exc:  # keep training on the eager launch sequence
+                    print(f"| HIP graph capture failed ({exc}); continuing with eager launches")
+                    self.use_hip_graphs = use_graph = False
+                    torch.cuda.synchronize(dev)
             if use_graph:
                 st.idx.copy_(indices)
                 run = st.graph_a.replay

@@ -241,3 +241,38 @@ def test_train_entry_point_single_instance(tmp_path):
                         "--break_step", "400", "--eval_times1", "1", "--eval_times2", "2", "--eval_gap", "1",
                         "--test_render_times", "400", "--log_root", str(tmp_path)])
     assert agent.act.net[0].in_features == 3
+
+
+@pytest.mark.parametrize("env_id,algo,lanes", [("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 4096),
+                                               ("WT_STACKING1", "ResidualPPO", 1024), ("PH_V35", "PPO", 1024)])
+def test_vectorised_training_round(env_id, algo, lanes):
+    """BASELINE config 2 shape (water tank, 4 096 lanes, residual agent) and friends: one explore + one fused update on
+    the GPU; the policy must still equal the prior controller at step 0 (zero-initialised residual) and the update
+    must move the weights and keep everything finite."""
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.run import make_buffer
+    from pime_amd.utils import MODELS
+    ids = dict(WT_INTEGRATOR=gym_control.WT_INTEGRATOR, WT_STACKING1=gym_control.WT_STACKING.format(1), PH_V35=gym_control.PH_V35)
+    kw = dict(reward_type="distance") if env_id.startswith("WT") else {}
+    env = gym_control.make_vec(ids[env_id], lanes, device="cuda:0", seed=1, **kw)
+    torch.manual_seed(0)
+    agent = MODELS[algo.lower()](device="cuda:0")
+    if "modular" in algo.lower():
+        agent.init(128, env.state_dim, 1, env.n_integrator)
+    else:
+        agent.init(128, env.state_dim, 1)
+    if "residual" in algo.lower():
+        agent.init_residual({"init_K": env.K.reshape(-1, 1)})
+        agent.init_actor_zero()
+        s = torch.randn(64, env.state_dim, device="cuda:0")
+        with torch.no_grad():
+            np.testing.assert_allclose(agent.act(s).cpu().numpy()[:, 0], env.get_linear_action(s).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    buf = make_buffer(agent, env, lanes * env.max_step)
+    before = torch.cat([p.detach().reshape(-1) for p in agent.cri.parameters()]).clone()
+    steps = agent.explore_env(env, buf, lanes * env.max_step, 1.0, 0.99)
+    assert steps == lanes * env.max_step and bool(buf.done[env.max_step - 1].all()) and not bool(buf.done[:env.max_step - 1].any())
+    obj_a, obj_c = agent.update_net(buf, steps, 8192, 1.0)
+    assert agent._packed.get("fused") is not None, "the fused HIP gradient path was not taken"
+    after = torch.cat([p.detach().reshape(-1) for p in agent.cri.parameters()])
+    assert np.isfinite(obj_a) and np.isfinite(obj_c) and torch.isfinite(after).all() and not torch.equal(before, after)
+    env.close()
