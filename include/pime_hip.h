@@ -230,6 +230,12 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
                             float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
                             float* loss_sums, pime_stream stream);
 
+/* replaces: self.optimizer.step() of the single Adam over both nets (elegantrl/agent.py:565-566,656-657; no weight
+ * decay, no amsgrad) when every parameter lives in ONE flat tensor.  All [dev] float32[n]; step [dev] float32[1] is the
+ * step counter, incremented by the call (so the launch pair can be replayed from a HIP graph). */
+int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float* step, pime_stream stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -43,6 +43,7 @@ int launch_ppo_net(int, int, const PpoArgs&, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
 int launch_dw(const DwArgs&, int, hipStream_t);
 int launch_critic_scale(int, int, float* const*, const double*, int, float*, hipStream_t);
+int launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float*, hipStream_t);
 
 }  // namespace pime
 
@@ -551,6 +552,12 @@ int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const flo
                       pime_stream stream) {
     PIME_REQUIRE(params != nullptr && image != nullptr, "pime_ppo_pack_bwd: NULL params/image");
     return launch_pack_bwd(kind, D, Di, md, params, image, static_cast<hipStream_t>(stream));
+}
+
+int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float* step, pime_stream stream) {
+    PIME_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && n >= 1, "pime_adam_step: bad arguments");
+    return launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, static_cast<hipStream_t>(stream));
 }
 
 static int check_net(const pime_ppo_net* n, bool actor) {

@@ -512,6 +512,39 @@ int launch_critic_scale(int D, int md, float* const* grads, const double* moment
     return PIME_OK;
 }
 
+// ==================================================================================================== Adam
+// torch.optim.Adam (no weight decay, no amsgrad; agent.py:565-566,656-657) over ONE flat parameter / gradient
+// tensor.  torch's fused multi-tensor Adam needs 27 us for the 22 small tensors of the two nets and 94 us when
+// handed the flat 67k-element tensor (one 64k chunk = one workgroup); this is a plain grid-wide elementwise pass.
+__global__ void adam_tick_kernel(float* step) { step[0] += 1.0f; }
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                            const float* __restrict__ step) {
+    const double t = (double)step[0];
+    const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    const float step_size = lr / bc1;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);       // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + gi * gi * (1.0f - b2);      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                float* step, hipStream_t s) {
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step);
+    const int block = 256;
+    long long grid = (n + block - 1) / block;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(block), 0, s, p, g, m, v, n, lr, b1, b2, eps, step);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
 // ==================================================================================================== host side
 int mlp_check(int kind, int D, int Di, int md);
 

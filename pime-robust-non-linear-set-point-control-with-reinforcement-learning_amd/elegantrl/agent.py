@@ -324,6 +324,8 @@ class AgentPPO(AgentBase):
         if f is None or f.max_batch < batch_size:
             f = self.backend.fused_ppo(self.act, self.cri, batch_size)
             self._packed["fused"] = f
+            if f:  # parameters now live in one flat tensor: give Adam that tensor (fresh state, as after init)
+                self.optimizer = f.make_optimizer(self.learning_rate)
         return f if f else None
 
     def _update_fused(self, fused, n_steps, buf_len, batch_size, repeat_times, buf_state, buf_action, buf_r_sum,

