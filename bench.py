@@ -166,13 +166,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block at
+    # communicator creation) are sent to stderr for the whole run, and the JSON is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from pime_amd import dist as pdist
     rank, world, local = pdist.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
-    dp = pdist.init_from_env(backend="nccl", device=device) if world > 1 else None
+    dp = pdist.init_from_env(backend="nccl", device=device) if (world > 1 or os.environ.get("PIME_FORCE_DP") == "1") else None
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     env, agent, buf = build_stack(device, rank, world, dp)
@@ -223,6 +229,8 @@ def main():
     t_roll, t_upd = b - a, c - b
 
     if rank != 0:
+        if dp is not None:
+            torch.distributed.destroy_process_group()
         return
     ks = timer.summary()
     per_step = {k: n * ms / args.steps for k, (n, ms) in ks.items()}
@@ -279,7 +287,9 @@ def main():
         log("cpu baseline (oracle env + torch CPU update) ...")
         out["cpu_baseline"] = cpu_baseline()
         log("cpu baseline done")
-    print(json.dumps(out))
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dp is not None:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

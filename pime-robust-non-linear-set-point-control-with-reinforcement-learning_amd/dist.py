@@ -20,7 +20,7 @@ def init_from_env(backend=None, device=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns a DataParallel or None when
     WORLD_SIZE == 1."""
     rank, world, local = env_rank_world()
-    if world <= 1:
+    if world <= 1 and os.environ.get("PIME_FORCE_DP") != "1":  # PIME_FORCE_DP=1: exercise the collectives on one rank
         return None
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -29,7 +29,8 @@ def init_from_env(backend=None, device=None):
         torch.cuda.set_device(local)
     if not td.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        td.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return DataParallel(rank, world, local, device)
 
 
