@@ -139,3 +139,60 @@ def test_replay_buffer_ring_semantics():
     r, m, a, s, s2 = b.sample_batch(4, indices=torch.tensor([0, 1, 7, 8]))
     np.testing.assert_array_equal(s2.numpy(), b.buf_state[[1, 2, 8, 9]].numpy())  # successor = next row
     assert r.shape == (4, 1) and a.shape == (4, 1)
+
+
+def _sd_nets(g, tag):
+    return {k[len(tag) + 1:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(tag + ".")}
+
+
+def test_reference_state_dicts_load_and_reproduce_outputs():
+    """Checkpoint compatibility (agent.py:86-114 writes plain state_dicts): the reference's state_dict keys load
+    strictly into this package's modules, and forward / get_action_noise (injected noise) / compute_logprob reproduce
+    the reference's own torch outputs (tests/golden/nets.npz)."""
+    from pime_amd.elegantrl.net import Actor, ActorPPO, CriticAdv, CriticTwin
+    from pime_amd.elegantrl.net_residual import ActorResidualIntegratorModularPPO, ActorResidualPPO
+    g = load_golden("nets.npz")
+    x3, x4, a1, eps = (torch.from_numpy(g[k]) for k in ("x3", "x4", "a1", "eps"))
+    cases = [("modular3", ActorResidualIntegratorModularPPO(128, 3, 1, 1), x3),
+             ("modular4", ActorResidualIntegratorModularPPO(64, 4, 1, 1), x4),
+             ("resid3", ActorResidualPPO(32, 3, 1), x3)]
+    for tag, net, x in cases:
+        net.load_state_dict(_sd_nets(g, tag), strict=True)
+        with torch.no_grad():
+            np.testing.assert_allclose(net(x).numpy(), g[f"{tag}:forward"], rtol=1e-6, atol=1e-6)
+            action, noise = net.get_action_noise(x, noise=eps)
+            np.testing.assert_allclose(action.numpy(), g[f"{tag}:action"], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(net.compute_logprob(x, a1).numpy(), g[f"{tag}:logprob"], rtol=1e-5, atol=1e-5)
+    cri = CriticAdv(3, 128)
+    cri.load_state_dict(_sd_nets(g, "critic3"), strict=True)
+    twin = CriticTwin(32, 4, 1)
+    twin.load_state_dict(_sd_nets(g, "twin4"), strict=True)
+    det = Actor(32, 4, 1)
+    det.load_state_dict(_sd_nets(g, "actor4"), strict=True)
+    ppo = ActorPPO(32, 3, 1)
+    ppo.load_state_dict(_sd_nets(g, "ppo3"), strict=True)
+    with torch.no_grad():
+        np.testing.assert_allclose(cri(x3).numpy(), g["critic3:forward"], rtol=1e-6, atol=1e-6)
+        q1, q2 = twin.get_q1_q2(x4, a1)
+        np.testing.assert_allclose(q1.numpy(), g["twin4:q1"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(q2.numpy(), g["twin4:q2"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(det(x4).numpy(), g["actor4:forward"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(ppo(x3).numpy(), g["ppo3:forward"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(ppo.compute_logprob(x3, a1).numpy(), g["ppo3:logprob"], rtol=1e-5, atol=1e-5)
+
+
+def test_save_load_model_round_trip(tmp_path):
+    g = load_golden("ppo_update.npz")
+    ag, _ = _agent("ph", g)
+    ag.save_load_model(str(tmp_path), if_save=True)
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["actor.pth", "critic.pth"]
+    want = {k: v.clone() for k, v in ag.act.state_dict().items()}
+    with torch.no_grad():
+        for p in ag.act.parameters():
+            p.add_(1.0)
+    ag.save_load_model(str(tmp_path), if_save=False)
+    for k, v in ag.act.state_dict().items():
+        assert torch.equal(v, want[k])
+    assert set(want) == {"a_std_log", "priorK", "other_net.0.weight", "other_net.0.bias", "other_net.2.weight",
+                         "other_net.2.bias", "integrator_net.0.weight", "integrator_net.0.bias", "integrator_net.2.weight",
+                         "integrator_net.2.bias", "net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias"}

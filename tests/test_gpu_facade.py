@@ -276,3 +276,32 @@ def test_vectorised_training_round(env_id, algo, lanes):
     after = torch.cat([p.detach().reshape(-1) for p in agent.cri.parameters()])
     assert np.isfinite(obj_a) and np.isfinite(obj_c) and torch.isfinite(after).all() and not torch.equal(before, after)
     env.close()
+
+
+def test_batched_step_response_protocols():
+    """pime_amd.protocols: both golden pH plants as two lanes of ONE env, the robust water-tank plants as lanes of one
+    env -- same numbers as the reference's one-plant-at-a-time loops (utils/test.py:209-349,1369-1407)."""
+    from pime_amd import gym_control, protocols
+    g = load_golden("ph_stepresponse.npz")
+    env = gym_control.make_vec(gym_control.PH_V35, 2, device="cuda:0", state_mode="f64", seed=0)
+    res = protocols.ph_step_response(env, plants=[g["nominal_params"], g["corner_params"]])
+    for lane, tag in enumerate(("nominal", "corner")):
+        np.testing.assert_allclose(res["action"][:, lane], g[tag + "_act"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(res["y"][:, lane], g[tag + "_y"], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(res["I"][:, lane], g[tag + "_I"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(res["x"][:, lane], g[tag + "_x"], rtol=1e-12)
+        np.testing.assert_allclose(res["reward"][:, lane], g[tag + "_rew"], rtol=2e-7, atol=1e-6)
+    env.close()
+    gw = load_golden("wt_stepresponse.npz")
+    env = gym_control.make_vec(gym_control.WT_INTEGRATOR, 2, device="cuda:0", state_mode="f64", seed=0,
+                               reward_type="distance", noise_scale=0.0)
+    res = protocols.wt_step_response(env, steps=500, plants=[gw["robust1_params"][:3], gw["robust3_params"][:3]])
+    for lane, tag in enumerate(("robust1", "robust3")):
+        np.testing.assert_allclose(res["obs"][:, lane], gw[tag + "_obs"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(res["action"][:, lane], gw[tag + "_act"], rtol=0, atol=1e-12)
+    env.close()
+    # the params_ph grid (9 plants) in one go: every lane settles near its last set-point with the prior PI controller
+    env = gym_control.make_vec(gym_control.PH_V35, len(protocols.PH_PARAM_GRID), device="cuda:0", state_mode="f64", seed=0)
+    res = protocols.ph_step_response(env, plants=protocols.PH_PARAM_GRID)
+    assert res["y"].shape == (250, 9) and np.isfinite(res["y"]).all()
+    env.close()
