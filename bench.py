@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 # algorithmic cost models (DESIGN.md "Kernels")
-PH_STEP_BYTES = 94            # mixed mode, fused-residual step: see DESIGN.md table
+PH_STEP_BYTES = 97            # mixed mode, fused-residual step: 64 B read + 33 B written per env-step
 MLP_FLOPS_PER_ROW = {"critic": 2 * (3 * 128 + 128 * 128 * 2 + 128),
                      "modular_actor": 2 * (2 * 128 + 128 * 64 + 1 * 128 + 128 * 64 + 128 * 128 + 128)}
 # one minibatch gradient = forward + backward-dX + dW of both nets: 3 x 2 flop per weight per sample

@@ -304,3 +304,40 @@ def test_ph_full_size_properties():
     assert np.mean(qww1 != qww0) > 0.999
     assert np.all(env.get_field("episode") == 1) and np.all(env.get_field("t") == 0)
     env.close()
+
+
+@pytest.mark.parametrize("N", [1, 63, 65, 257])
+def test_ragged_lane_counts_and_masked_reset(table, N):
+    """Lane counts that are not multiples of the wave size, and a partial (masked) reset: untouched lanes keep their
+    state, reset lanes start a new episode with new Philox draws (episode counter advanced only for them)."""
+    from pime_amd.vec_env import VecPH, VecWaterTank
+    env = VecPH(N, device=DEV, state_mode="f64", seed=21)
+    ref = oracle.OraclePH(N, table, seed=21)
+    np.testing.assert_array_equal(_np(env.reset()), ref.reset())
+    rng = np.random.RandomState(N)
+    for t in range(7):
+        a = rng.uniform(-1, 1, N)
+        obs, rew, done = env.step(_t(a), auto_reset=False)
+        w_obs, _, w_rew, _ = ref.step(a)
+        np.testing.assert_array_equal(_np(obs), w_obs)
+    mask = (rng.uniform(size=N) < 0.5).astype(np.uint8)
+    if N == 1:
+        mask[:] = 1
+    before = _np(env.observe()).copy()
+    obs = _np(env.reset(mask=mask))
+    want = ref.reset(mask=mask)
+    sel = mask.astype(bool)
+    np.testing.assert_array_equal(obs[sel], want[sel])
+    np.testing.assert_array_equal(_np(env.observe())[~sel], before[~sel])
+    np.testing.assert_array_equal(env.get_field("episode"), ref.get("episode"))
+    np.testing.assert_array_equal(env.get_field("t")[sel], 0)
+    assert np.all(env.get_field("t")[~sel] == 7)
+    env.close()
+    wt = VecWaterTank(N, device=DEV, state_mode="f64", seed=4, reward_type="distance")
+    rw = oracle.OracleWT(N, reward_type="distance", seed=4)
+    np.testing.assert_array_equal(_np(wt.reset()), rw.reset())
+    a = rng.uniform(-1, 1, N)
+    obs, rew, done = wt.step(_t(a), auto_reset=False)
+    w_obs, _, w_rew, _ = rw.step(a)
+    np.testing.assert_allclose(_np(obs), w_obs, rtol=2e-7)
+    wt.close()
