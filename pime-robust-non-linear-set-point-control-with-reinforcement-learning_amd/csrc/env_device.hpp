@@ -1,0 +1,130 @@
+// Register-resident form of one pH env lane: the step / reset arithmetic shared by the per-step kernels
+// (env_kernels.hip) and the fused multi-step rollout kernel (rollout.hip), so both run literally the same code.
+// Reference semantics: /root/reference/gym_control/envs/ph.py:320-348 (step), :448-478 (NoBound), :409-445 (reset),
+// :114-121 (ZOH), :187-189 (LUT), gym TimeLimit.
+#pragma once
+#include "env_state.hpp"
+
+namespace pime {
+
+template <typename T>
+__device__ __forceinline__ T clip(T v, T lo, T hi) {  // np.clip = minimum(maximum(v, lo), hi)
+    const T m = v > lo ? v : lo;
+    return m < hi ? m : hi;
+}
+
+template <typename S>
+__device__ __forceinline__ S reward_of(int reward_type, S achieved, S goal, S thr) {
+    const S d = fabs(achieved - goal);
+    if (reward_type == PIME_REWARD_DISTANCE) return -d;
+    if (reward_type == PIME_REWARD_SQUARE) return -(d * d);
+    return d > thr ? S(-1) : S(-0.0);
+}
+
+template <typename S>
+__device__ __forceinline__ S ph_lookup(const PhParams& p, const S* __restrict__ table, double C, double x) {
+    // observe_state (ph.py:187-189): first i with MHCl[i] >= around(C*x, 5)  ==  rint(C*x*1e5)  
+    long long k = __double2ll_rn(C * x * p.table_scale);  // round-half-even like np.around
+    k = k < 0 ? 0 : (k >= p.table_len ? p.table_len - 1 : k);  // reference: IndexError (unreachable in range)
+    return table[k];
+}
+
+template <typename S>
+struct PhLane {
+    double x, A, B, C, qww, qc;
+    S I, r, last_a;
+    int t, episode;
+    bool plant_changed;  // (A,B,C,qww,qc) were rewritten by a resampling reset and must be stored
+};
+
+template <typename S>
+__device__ __forceinline__ void ph_lane_load(const PhParams& p, const PhPtrs<S>& st, int i, PhLane<S>& L) {
+    L.x = st.x[i]; L.A = st.A[i]; L.B = st.B[i]; L.C = st.C[i];
+    L.I = st.I[i]; L.r = st.r[i];
+    L.t = st.t[i]; L.episode = st.episode[i];
+    L.last_a = p.has_punish ? st.last_a[i] : S(0);
+    L.qww = L.qc = 0.0;
+    L.plant_changed = false;
+}
+
+template <typename S>
+__device__ __forceinline__ void ph_lane_store(const PhParams& p, const PhPtrs<S>& st, int i, const PhLane<S>& L) {
+    st.x[i] = L.x; st.I[i] = L.I; st.r[i] = L.r; st.t[i] = L.t; st.episode[i] = L.episode;
+    if (p.has_punish) st.last_a[i] = L.last_a;
+    if (L.plant_changed) {
+        st.A[i] = L.A; st.B[i] = L.B; st.C[i] = L.C; st.qww[i] = L.qww; st.qc[i] = L.qc;
+    }
+}
+
+// reset_all / reset_r (ph.py:412-445).  gid = global lane id (Philox counter word); draws = this lane's 4 injected
+// values (qww_V, qc_V, x0, r) or nullptr for in-kernel Philox.
+template <typename S>
+__device__ __forceinline__ void ph_lane_reset(const PhParams& p, const S* __restrict__ table, uint32_t gid,
+                                              const double* __restrict__ draws, PhLane<S>& L, float (&obs)[3]) {
+    const int ep = L.episode + 1;
+    L.episode = ep;
+    const bool resample = p.resample_every > 0 && (ep % p.resample_every) == 0;
+    double qww, qc, x0, r;
+    if (draws) {  // seed-for-seed replay of the reference's MT19937 draws (host generated)
+        qww = draws[0]; qc = draws[1]; x0 = draws[2]; r = draws[3];
+    } else {
+        double u0, u1, u2, u3;
+        philox_pair(p.seed, gid, (uint32_t)ep, 0, STREAM_RESET, u0, u1);
+        philox_pair(p.seed, gid, (uint32_t)ep, 1, STREAM_RESET, u2, u3);
+        qww = p.qww_lo + (p.qww_hi - p.qww_lo) * u0;  // np.random.uniform(lo, hi), ph.py:410
+        qc = p.qc_lo + (p.qc_hi - p.qc_lo) * u1;
+        x0 = p.x0_lo + (p.x0_hi - p.x0_lo) * u2;      // ph.py:420
+        r = p.r_lo + (p.r_hi - p.r_lo) * u3;          // ph.py:424
+    }
+    if (resample) {  // update_system (ph.py:114-121): ZOH of qc_V/(s+qww_V) at T -> closed form
+        const double e = -qww * p.sample_t;
+        L.qww = qww; L.qc = qc;
+        L.A = exp(e);
+        L.B = -expm1(e) / qww;
+        L.C = qc;
+        L.plant_changed = true;
+    }
+    L.x = x0;
+    const S y = ph_lookup<S>(p, table, L.C, x0);
+    L.t = 0;
+    L.r = (S)r;
+    L.I = S(0);
+    obs[0] = (float)y; obs[1] = (float)r; obs[2] = 0.0f;
+}
+
+// One env step for the (unclipped) env action `a`; no reset.  Returns the TimeLimit done flag.
+template <typename S>
+__device__ __forceinline__ bool ph_lane_step(const PhParams& p, const S* __restrict__ table, double a, PhLane<S>& L,
+                                             float (&obs)[3], float& reward) {
+    a = clip(a, -1.0, 1.0);                                   // ph.py:321
+    S delta_u = S(0);
+    if (p.has_punish) {
+        delta_u = L.t != 0 ? (S)a - L.last_a : S(0);          // :322
+        L.last_a = (S)a;
+    }
+    L.t += 1;                                                 // :325
+    const double u = p.u_low + (p.u_high - p.u_low) * ((a - -1.0) / (1.0 - -1.0));  // action(): :155-159
+    L.x = L.A * L.x + L.B * u;                                // :330
+    const S y = ph_lookup<S>(p, table, L.C, L.x);             // :332
+    S rew = reward_of<S>(p.reward_type, y, L.r, (S)p.thr);    // :334
+    const S I_raw = L.I + (L.r - y);                          // :339-340
+    L.I = p.integral_bound ? clip(I_raw, (S)-p.integral_max, (S)p.integral_max) : I_raw;  // :341 / :470
+    if (p.has_punish) {
+        rew -= (S)p.action_punish * fabs((S)u);               // :336
+        rew -= (S)p.action_change_punish * fabs(delta_u);     // :337
+        rew += -(S)p.integral_punish * fabs(p.integral_bound ? I_raw : L.I);  // :343 / :473
+    }
+    reward = (float)rew;
+    obs[0] = (float)y; obs[1] = (float)L.r; obs[2] = (float)L.I;
+    return L.t >= p.max_steps;  // gym TimeLimit; the env itself returns False (:348)
+}
+
+// env action of the residual policy: np.tanh(action_f32) + state_f32 @ priorK_f64 (agent_residual.py:61)
+__device__ __forceinline__ double ph_residual_action(float a_pre, const float (&obs_in)[3], const PriorK& K) {
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dot += (double)obs_in[j] * K.k[j];
+    return (double)tanhf(a_pre) + dot;
+}
+
+}  // namespace pime

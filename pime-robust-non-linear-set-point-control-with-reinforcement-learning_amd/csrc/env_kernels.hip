@@ -12,80 +12,24 @@
 //   WT step   gym_control/envs/nonlinear_watertank.py:800-826 (+ :258-260, :271-272, :484-514), Stacking :1118-1147
 //   WT reset  :890-939, :1166-1208
 //   residual  elegantrl/agent_residual.py:61
-#include "env_state.hpp"
+#include "env_device.hpp"
 
 namespace pime {
 
-template <typename T>
-__device__ __forceinline__ T clip(T v, T lo, T hi) {  // np.clip = minimum(maximum(v, lo), hi)
-    const T m = v > lo ? v : lo;
-    return m < hi ? m : hi;
-}
-
-template <typename S>
-__device__ __forceinline__ S reward_of(int reward_type, S achieved, S goal, S thr) {
-    const S d = fabs(achieved - goal);
-    if (reward_type == PIME_REWARD_DISTANCE) return -d;
-    if (reward_type == PIME_REWARD_SQUARE) return -(d * d);
-    return d > thr ? S(-1) : S(-0.0);
-}
-
 // ============================================================================================ pH
-template <typename S>
-__device__ __forceinline__ S ph_lookup(const PhParams& p, const S* __restrict__ table, double C, double x) {
-    // observe_state (ph.py:187-189): first i with MHCl[i] >= around(C*x, 5)  ==  rint(C*x*1e5)  
-    long long k = __double2ll_rn(C * x * p.table_scale);  // round-half-even like np.around
-    k = k < 0 ? 0 : (k >= p.table_len ? p.table_len - 1 : k);  // reference: IndexError (unreachable in range)
-    return table[k];
-}
-
-template <typename S>
-__device__ __forceinline__ void ph_reset_lane(const PhParams& p, const PhPtrs<S>& st, int i,
-                                              const double* __restrict__ draws, float* __restrict__ obs) {
-    const int ep = st.episode[i] + 1;
-    st.episode[i] = ep;
-    const bool resample = p.resample_every > 0 && (ep % p.resample_every) == 0;
-    double qww, qc, x0, r;
-    if (draws) {  // seed-for-seed replay of the reference's MT19937 draws (host generated)
-        qww = draws[4 * (size_t)i + 0]; qc = draws[4 * (size_t)i + 1];
-        x0 = draws[4 * (size_t)i + 2]; r = draws[4 * (size_t)i + 3];
-    } else {
-        double u0, u1, u2, u3;
-        philox_pair(p.seed, p.env_offset + (uint32_t)i, (uint32_t)ep, 0, STREAM_RESET, u0, u1);
-        philox_pair(p.seed, p.env_offset + (uint32_t)i, (uint32_t)ep, 1, STREAM_RESET, u2, u3);
-        qww = p.qww_lo + (p.qww_hi - p.qww_lo) * u0;  // np.random.uniform(lo, hi), ph.py:410
-        qc = p.qc_lo + (p.qc_hi - p.qc_lo) * u1;
-        x0 = p.x0_lo + (p.x0_hi - p.x0_lo) * u2;      // ph.py:420
-        r = p.r_lo + (p.r_hi - p.r_lo) * u3;          // ph.py:424
-    }
-    double C;
-    if (resample) {  // update_system (ph.py:114-121): ZOH of qc_V/(s+qww_V) at T -> closed form
-        st.qww[i] = qww;
-        st.qc[i] = qc;
-        const double e = -qww * p.sample_t;
-        st.A[i] = exp(e);
-        st.B[i] = -expm1(e) / qww;
-        st.C[i] = C = qc;
-    } else {
-        C = st.C[i];
-    }
-    st.x[i] = x0;
-    const S y = ph_lookup<S>(p, st.table, C, x0);
-    st.t[i] = 0;
-    st.r[i] = (S)r;
-    st.I[i] = S(0);
-    obs[3 * (size_t)i + 0] = (float)y;
-    obs[3 * (size_t)i + 1] = (float)r;
-    obs[3 * (size_t)i + 2] = 0.0f;
-}
-
+// (lane arithmetic in env_device.hpp; the kernels below are load -> step/reset -> store)
 template <typename S>
 __global__ void ph_reset_kernel(PhParams p, PhPtrs<S> st, const uint8_t* __restrict__ mask,
                                 const double* __restrict__ draws, float* __restrict__ obs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     if (mask && !mask[i]) return;
-    ph_reset_lane<S>(p, st, i, draws, obs);
+    PhLane<S> L;
+    ph_lane_load<S>(p, st, i, L);
+    float o[3];
+    ph_lane_reset<S>(p, st.table, p.env_offset + (uint32_t)i, draws ? draws + 4 * (size_t)i : nullptr, L, o);
+    ph_lane_store<S>(p, st, i, L);
+    obs[3 * (size_t)i + 0] = o[0]; obs[3 * (size_t)i + 1] = o[1]; obs[3 * (size_t)i + 2] = o[2];
 }
 
 template <typename S, typename ActT, bool RESIDUAL>
@@ -95,48 +39,22 @@ __global__ void ph_step_kernel(PhParams p, PhPtrs<S> st, const ActT* __restrict_
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     double a;
-    if constexpr (RESIDUAL) {  // agent_residual.py:61: np.tanh(action_f32) + state_f32 @ priorK_f64
-        double dot = 0.0;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dot += (double)obs_in[3 * (size_t)i + j] * K.k[j];
-        a = (double)tanhf((float)act[i]) + dot;
+    if constexpr (RESIDUAL) {
+        const float o_in[3] = {obs_in[3 * (size_t)i], obs_in[3 * (size_t)i + 1], obs_in[3 * (size_t)i + 2]};
+        a = ph_residual_action((float)act[i], o_in, K);
     } else {
         a = (double)act[i];
     }
-    a = clip(a, -1.0, 1.0);                                   // ph.py:321
-    int t = st.t[i];
-    S delta_u = S(0);
-    if (p.has_punish) {
-        delta_u = t != 0 ? (S)a - st.last_a[i] : S(0);        // :322
-        st.last_a[i] = (S)a;
-    }
-    t += 1;                                                   // :325
-    const double u = p.u_low + (p.u_high - p.u_low) * ((a - -1.0) / (1.0 - -1.0));  // action(): :155-159
-    const double C = st.C[i];
-    const double x = st.A[i] * st.x[i] + st.B[i] * u;         // :330
-    const S y = ph_lookup<S>(p, st.table, C, x);              // :332
-    const S r = st.r[i];
-    S rew = reward_of<S>(p.reward_type, y, r, (S)p.thr);      // :334
-    const S I_raw = st.I[i] + (r - y);                        // :339-340
-    const S I = p.integral_bound ? clip(I_raw, (S)-p.integral_max, (S)p.integral_max) : I_raw;  // :341 / :470
-    if (p.has_punish) {
-        rew -= (S)p.action_punish * fabs((S)u);               // :336
-        rew -= (S)p.action_change_punish * fabs(delta_u);     // :337
-        rew += -(S)p.integral_punish * fabs(p.integral_bound ? I_raw : I);  // :343 / :473
-    }
-    const bool d = t >= p.max_steps;  // gym TimeLimit; the env itself returns False (:348)
-    reward[i] = (float)rew;
+    PhLane<S> L;
+    ph_lane_load<S>(p, st, i, L);
+    float o[3], rew;
+    const bool d = ph_lane_step<S>(p, st.table, a, L, o, rew);
+    reward[i] = rew;
     done[i] = (uint8_t)d;
-    if (d && p.auto_reset) {
-        ph_reset_lane<S>(p, st, i, reset_draws, obs);
-    } else {
-        st.x[i] = x;
-        st.I[i] = I;
-        st.t[i] = t;
-        obs[3 * (size_t)i + 0] = (float)y;
-        obs[3 * (size_t)i + 1] = (float)r;
-        obs[3 * (size_t)i + 2] = (float)I;
-    }
+    if (d && p.auto_reset)
+        ph_lane_reset<S>(p, st.table, p.env_offset + (uint32_t)i, reset_draws ? reset_draws + 4 * (size_t)i : nullptr, L, o);
+    ph_lane_store<S>(p, st, i, L);
+    obs[3 * (size_t)i + 0] = o[0]; obs[3 * (size_t)i + 1] = o[1]; obs[3 * (size_t)i + 2] = o[2];
 }
 
 template <typename S>

@@ -60,11 +60,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const float* _
                                                                   float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MlpLayout L = mlp_layout(KIND, D, Di, T * 32);
-    {  // stage the packed image: straight 16-B copies, coalesced in HBM and conflict-free in LDS
-        const float4* src = reinterpret_cast<const float4*>(packed);
-        float4* dst = reinterpret_cast<float4*>(lds);
-        for (int i = threadIdx.x; i < L.total / 4; i += blockDim.x) dst[i] = src[i];
-    }
+    stage_image(lds, packed, L.total / 4);  // straight 16-B copies, coalesced in HBM and conflict-free in LDS
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6, h = lane >> 5;
     const int ntiles = (M + 31) / 32;

@@ -144,11 +144,7 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
 
     // ------------------------------------------------------------------ phase A: forward + loss gradient
     const MlpLayout L = mlp_layout(KIND, a.D, a.Di, T * 32);
-    {
-        const float4* src = reinterpret_cast<const float4*>(a.img_fwd);
-        float4* dst = reinterpret_cast<float4*>(lds);
-        for (int i = threadIdx.x; i < L.total / 4; i += blockDim.x) dst[i] = src[i];
-    }
+    stage_image(lds, a.img_fwd, L.total / 4);
     __syncthreads();
     float s0 = 0.f, s1 = 0.f, gstd = 0.f;
     double m1 = 0.0, m2 = 0.0;
@@ -159,6 +155,11 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
         const long long row = a.indices[valid ? pos : a.B - 1];
         const float* xrow = a.state + (size_t)row * a.D;
         float* st = a.stash + (size_t)tile * NT * 1024;
+        // per-sample loss inputs: issued now so that their (index-dependent) latency hides behind the layers
+        const float in_rsum = CRITIC ? a.r_sum[row] : 0.f;
+        const float in_action = CRITIC ? 0.f : a.action[row];
+        const float in_logprob = CRITIC ? 0.f : a.logprob[row];
+        const float in_adv = CRITIC ? 0.f : a.adv[row];
         if (h == 0)  // contiguous copy of the gathered states for the dW kernel (its first-layer operands)
             for (int c = 0; c < a.D; ++c) a.xg[(size_t)pos * a.D + c] = xrow[c];
         float y;
@@ -201,23 +202,23 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
         float dout = 0.f;
         if (valid) {
             if constexpr (CRITIC) {
-                const float d = y - a.r_sum[row], ad = fabsf(d);         // SmoothL1, beta = 1 (agent.py:567,649)
+                const float d = y - in_rsum, ad = fabsf(d);         // SmoothL1, beta = 1 (agent.py:567,649)
                 const float l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
                 const float g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
                 dout = g * invB;  // unscaled: critic_scale_kernel applies 1/(std+1e-5) to the finished gradients
                 if (h == 0) {
                     s0 += l;
-                    m1 += (double)a.r_sum[row];
-                    m2 += (double)a.r_sum[row] * (double)a.r_sum[row];
+                    m1 += (double)in_rsum;
+                    m2 += (double)in_rsum * (double)in_rsum;
                 }
             } else {
                 const float asl = a.a_std_log[0], inv_sigma = __expf(-asl);
-                const float z = (y - a.action[row]) * inv_sigma;
+                const float z = (y - in_action) * inv_sigma;
                 const float logp = -(asl + kLogSqrt2Pi + 0.5f * z * z);           // compute_logprob
-                const float ratio = __expf(logp - a.logprob[row]);
+                const float ratio = __expf(logp - in_logprob);
                 const float lo = 1.f - a.ratio_clip, hi = 1.f + a.ratio_clip;
                 const float clamped = fminf(fmaxf(ratio, lo), hi);
-                const float adv = a.adv[row];
+                const float adv = in_adv;
                 const float u = adv * ratio, c = adv * clamped;                   // agent.py:639-641
                 // torch.min backward: the smaller operand gets the gradient, ties split it; clamp passes it inside [lo,hi]
                 const float w_u = u < c ? 1.f : (u == c ? 0.5f : 0.f);
@@ -253,11 +254,7 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
     // ------------------------------------------------------------------ phase B: backward chain
     __syncthreads();  // every wave is done reading the forward image
     const BwdLayout Lb = bwd_layout(KIND, a.D, a.Di, T * 32);
-    {
-        const float4* src = reinterpret_cast<const float4*>(a.img_bwd);
-        float4* dst = reinterpret_cast<float4*>(lds);
-        for (int i = threadIdx.x; i < Lb.total / 4; i += blockDim.x) dst[i] = src[i];
-    }
+    stage_image(lds, a.img_bwd, Lb.total / 4);
     __syncthreads();
     for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
         PIME_NO_HOIST();
@@ -308,9 +305,9 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
             stash_load<T>(st + T * 1024, lane, hh);                              // H3
             times_act_grad<T, ACT>(d, hh);
             stash_store<T>(st + 2 * T * 1024, lane, d);                          // dZ3
+            stash_load<T>(st, lane, hh);                                         // H2: in flight behind the next layer
             PIME_NO_HOIST();
             layer_mfma<T, T, 2, false>(lds + Lb.off[2], nullptr, lane, d, d2);   // dH2 = W(net.4)^T dZ3
-            stash_load<T>(st, lane, hh);                                         // H2
             times_act_grad<T, ACT>(d2, hh);
             stash_store<T>(st + 3 * T * 1024, lane, d2);                         // dZ2
             PIME_NO_HOIST();

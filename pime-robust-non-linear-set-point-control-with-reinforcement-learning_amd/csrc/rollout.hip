@@ -1,0 +1,153 @@
+// Fused on-device rollout for the pH env: ONE launch advances every lane through `n_steps` steps --
+// policy forward on the f32 matrix cores, exploration noise, residual action composition, env step (+ in-kernel
+// auto-reset) and the trajectory-buffer writes -- with the env state and the observation in registers for the whole
+// episode.  Replaces the per-step launch sequence of AgentResidual*.explore_env
+// (/root/reference/elegantrl/agent_residual.py:52-69: select_action -> env.step(tanh(a)+s@priorK) -> append_buffer),
+// i.e. ~8 launches x 50 steps per rollout.
+//
+// One wave owns 32 lanes (both lane halves carry the same 32 envs: the MFMA layout needs the sample on lane&31, and
+// the env arithmetic is cheap enough to do redundantly instead of shuffling).  Two waves per workgroup so that 512
+// tiles spread over all 256 CUs with one wave per SIMD: per step a wave is latency-bound on its own 3-layer MFMA chain
+// (512 MFMAs x 64 cycles), so sharing a SIMD would only stretch the episode.
+// The env arithmetic is env_device.hpp -- literally the code of ph_step_kernel / ph_reset_kernel.
+#include "env_device.hpp"
+#include "mlp_device.hpp"
+#include "rollout.hpp"
+
+namespace pime {
+
+constexpr uint32_t STREAM_EXPLORE = 2;
+
+// first layer from a register-resident input of compile-time width
+template <int OT, int ACT, int DIN>
+__device__ __forceinline__ void layer_first_regs(const float* __restrict__ w0, const float* x, int h, f32x16 (&out)[OT]) {
+    const float* wb = w0 + DIN * (OT * 32) + h;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = wb[(ot * 16 + r) * 2];
+#pragma unroll
+    for (int j = 0; j < DIN; ++j) {
+        const float* wj = w0 + j * (OT * 32) + h;
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[ot][r] = fmaf(x[j], wj[(ot * 16 + r) * 2], out[ot][r]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = activate<ACT>(out[ot][r]);
+}
+
+constexpr int kRolloutThreads = 128;
+
+template <int T, int KIND>
+__global__ __launch_bounds__(kRolloutThreads) void rollout_ph_kernel(RolloutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int D = 3, Di = 1, Do = D - Di;
+    constexpr int H = T / 2 > 0 ? T / 2 : 1;
+    const MlpLayout L = mlp_layout(KIND, D, Di, T * 32);
+    stage_image(lds, a.img, L.total / 4);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int N = a.p.n;
+    const int m = (blockIdx.x * (kRolloutThreads / 64) + wave) * 32 + (lane & 31);
+    const bool valid = m < N;
+    const int i = valid ? m : N - 1;  // idle lanes shadow the last env (compute, never store)
+    const bool writer = valid && h == 0;
+    const float sigma = __expf(a.a_std_log[0]);
+
+    PhLane<float> E;
+    ph_lane_load<float>(a.p, a.st, i, E);
+    float obs[3] = {a.state[3 * (size_t)i], a.state[3 * (size_t)i + 1], a.state[3 * (size_t)i + 2]};
+    for (int t = 0; t < a.n_steps; ++t) {
+        PIME_NO_HOIST();
+        float a_avg;
+        if constexpr (KIND == MLP_MODULAR_ACTOR) {
+            f32x16 cat[T];
+            {
+                f32x16 a0[T];
+                layer_first_regs<T, 1, Do>(lds + L.off[0], obs, h, a0);
+                PIME_NO_HOIST();
+                layer_mfma<T, H, 1>(lds + L.off[1], lds + L.off[2], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
+            }
+            {
+                f32x16 a0[T];
+                PIME_NO_HOIST();
+                layer_first_regs<T, 1, Di>(lds + L.off[3], obs + Do, h, a0);
+                PIME_NO_HOIST();
+                layer_mfma<T, H, 1>(lds + L.off[4], lds + L.off[5], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
+            }
+            f32x16 n0[T];
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 1>(lds + L.off[6], lds + L.off[7], lane, cat, n0);
+            PIME_NO_HOIST();
+            a_avg = layer_head<T>(lds + L.off[8], lds[L.off[9]], lane, n0);
+        } else {
+            f32x16 a0[T], a1[T];
+            layer_first_regs<T, 1, D>(lds + L.off[0], obs, h, a0);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 1>(lds + L.off[1], lds + L.off[2], lane, a0, a1);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 1>(lds + L.off[3], lds + L.off[4], lane, a1, a0);
+            PIME_NO_HOIST();
+            a_avg = layer_head<T>(lds + L.off[5], lds[L.off[6]], lane, a0);
+        }
+        // exploration noise eps ~ N(0,1): Box-Muller on a Philox pair keyed by the global lane (net_residual.py:178)
+        double ua, ub;
+        philox_pair(a.noise_seed, a.p.env_offset + (uint32_t)i, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE, ua, ub);
+        const float eps = (float)(sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586476925286766559 * ub));
+        const float a_pre = a_avg + eps * sigma;                                   // net_residual.py:179
+        const double a_env = ph_residual_action(a_pre, obs, a.K);                  // agent_residual.py:61
+        float nxt[3], rew;
+        const bool d = ph_lane_step<float>(a.p, a.st.table, a_env, E, nxt, rew);
+        const size_t k = (size_t)t * N + i;
+        if (writer) {
+            a.action[k] = a_pre;
+            a.noise[k] = eps;
+            a.reward[k] = rew;
+            a.done[k] = (uint8_t)d;
+        }
+        if (d) ph_lane_reset<float>(a.p, a.st.table, a.p.env_offset + (uint32_t)i, nullptr, E, nxt);  // auto-reset
+        if (writer) {
+            float* s = a.state + ((size_t)(t + 1) * N + i) * 3;
+            s[0] = nxt[0]; s[1] = nxt[1]; s[2] = nxt[2];
+        }
+        obs[0] = nxt[0]; obs[1] = nxt[1]; obs[2] = nxt[2];
+    }
+    if (writer) ph_lane_store<float>(a.p, a.st, i, E);
+}
+
+int mlp_check(int kind, int D, int Di, int md);
+
+template <int T, int KIND>
+static int launch_rollout_t(const RolloutArgs& a, hipStream_t s) {
+    const MlpLayout L = mlp_layout(KIND, 3, 1, T * 32);
+    const size_t lds_bytes = (size_t)L.total * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_ph_kernel<T, KIND>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int tiles = (a.p.n + 31) / 32, per_wg = kRolloutThreads / 64;
+    hipLaunchKernelGGL((rollout_ph_kernel<T, KIND>), dim3((tiles + per_wg - 1) / per_wg), dim3(kRolloutThreads), lds_bytes,
+                       s, a);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+int launch_rollout_ph(int kind, int md, const RolloutArgs& a, hipStream_t s) {
+    if (int rc = mlp_check(kind, 3, kind == MLP_MODULAR_ACTOR ? 1 : 0, md)) return rc;
+    PIME_REQUIRE(kind != MLP_CRITIC, "rollout needs an actor image");
+    const int T = md / 32;
+    if (T == 4 && kind == MLP_MODULAR_ACTOR) return launch_rollout_t<4, MLP_MODULAR_ACTOR>(a, s);
+    if (T == 2 && kind == MLP_MODULAR_ACTOR) return launch_rollout_t<2, MLP_MODULAR_ACTOR>(a, s);
+    if (T == 4 && kind == MLP_PLAIN_ACTOR) return launch_rollout_t<4, MLP_PLAIN_ACTOR>(a, s);
+    if (T == 2 && kind == MLP_PLAIN_ACTOR) return launch_rollout_t<2, MLP_PLAIN_ACTOR>(a, s);
+    set_error("no fused rollout instantiation for kind %d width %d", kind, md);
+    return PIME_ERR_ARG;
+}
+
+}  // namespace pime

@@ -116,6 +116,7 @@ class AgentPPO(AgentBase):
         self.noise_hook = None  # tests: callable(t, shape) -> exploration noise tensor (else torch.randn)
         self.use_fused_update = True
         self.use_hip_graphs = True
+        self.use_fused_rollout = True
         self.launch_timer = None  # optional callable(name, thunk) that brackets the thunk with HIP events
 
     # ---- construction ------------------------------------------------------------------------------------
@@ -204,6 +205,18 @@ class AgentPPO(AgentBase):
                 state = next_state
         return actual_step
 
+    def _rollout_priorK(self):
+        """Prior-controller gain of the fused rollout: none for plain PPO (the env sees tanh(a_pre), agent.py:599)."""
+        return np.zeros(self.act.state_dim)
+
+    def _fused_rollout_ok(self, env):
+        if not (self.use_fused_rollout and getattr(env, "supports_fused_rollout", False)) or self.noise_hook is not None:
+            return False
+        if not hasattr(self, "_rollout_seed"):
+            self._rollout_seed = int(torch.initial_seed()) & (2 ** 63 - 1)   # exploration stream follows torch's seed
+            self._rollout_epoch = 0
+        return self._packed_for("act") is not None and self.act.state_dim == 3
+
     def _vec_env_step(self, env, a_pre, obs, out_obs, out_reward, out_done):
         """Plain PPO: the env sees tanh(a_pre) (agent.py:599)."""
         return env.step(torch.tanh(a_pre), auto_reset=True, out_obs=out_obs, out_reward=out_reward, out_done=out_done)
@@ -219,6 +232,7 @@ class AgentPPO(AgentBase):
         assert episodes * env.max_step <= T_max, "TrajectoryBuffer horizon too short for target_step"
         std = None
         t = 0
+        fused = self._fused_rollout_ok(env)
         # Every lane sits at the start of an episode either because nothing ran yet (-> reset) or because the last
         # step of the previous rollout auto-reset it inside the kernel (-> just read the observation back).
         if env.fresh:
@@ -226,6 +240,14 @@ class AgentPPO(AgentBase):
         else:
             env.reset(out=buffer.state[0])
         for ep in range(episodes):
+            if fused:  # one launch per episode: policy forward + noise + env step + buffer writes (csrc/rollout.hip)
+                n = env.max_step
+                self._rollout_epoch += 1
+                env.rollout(self._packed_for("act"), self.act.a_std_log.detach(), self._rollout_priorK(), n,
+                            self._rollout_seed, self._rollout_epoch, buffer.state[t:t + n + 1], buffer.action[t:t + n],
+                            buffer.noise[t:t + n], buffer.reward[t:t + n], buffer.done[t:t + n])
+                t += n
+                continue
             for _ in range(env.max_step):
                 obs = buffer.state[t]
                 with torch.no_grad():

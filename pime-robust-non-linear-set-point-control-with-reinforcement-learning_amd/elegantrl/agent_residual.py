@@ -38,6 +38,9 @@ class AgentResidualPPO(AgentPPO, Residual):
         return env.step_residual(a_pre, obs, self.priorK.reshape(-1), auto_reset=True, out_obs=out_obs,
                                  out_reward=out_reward, out_done=out_done)
 
+    def _rollout_priorK(self):
+        return self.priorK.reshape(-1)
+
     def frozen_transfer(self):
         self.act.frozen_transfer()
         self.cri.frozen_transfer()

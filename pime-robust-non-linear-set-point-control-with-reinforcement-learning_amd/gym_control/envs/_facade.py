@@ -55,7 +55,7 @@ class SingleEnvFacade(gym.Env):
         clone = self._clone_blank()
         for f in self._copy_fields:
             clone._vec.set_field(f, self._vec.get_field(f))
-        clone._vec._t_host[:] = self._vec._t_host
+        clone._vec._t_all, clone._vec._t_lanes = self._vec._t_all, None if self._vec._t_lanes is None else self._vec._t_lanes.copy()
         clone._vec._was_reset = self._vec._was_reset
         for k, v in self.__dict__.items():
             if k not in ("_vec", "_device_action", "observation_space", "action_space", "np_random"):

@@ -106,6 +106,7 @@ class VecControlEnv:
     has_step_noise = False
     action_dim = 1
     if_discrete = False
+    supports_fused_rollout = False
 
     def __init__(self, cfg, device, draws, K):
         self.device = torch.device(device)
@@ -132,7 +133,11 @@ class VecControlEnv:
         self.obs = torch.zeros((N, D), dtype=torch.float32, device=self.device)
         self.reward = torch.zeros((N,), dtype=torch.float32, device=self.device)
         self.done = torch.zeros((N,), dtype=torch.uint8, device=self.device)
-        self._t_host = np.zeros(N, dtype=np.int64)  # mirror of the per-lane step counter (episodes are fixed length)
+        # Host mirror of the per-lane step counter (episodes are fixed length, so the host can tell which lanes end
+        # without reading the device).  While every lane is at the same step -- the normal case -- it is ONE integer;
+        # a masked reset or a write to the `t` field switches to a per-lane array.
+        self._t_all = 0
+        self._t_lanes = None
         self._was_reset = False
 
     # -- lifetime ------------------------------------------------------------------------------------------
@@ -166,27 +171,41 @@ class VecControlEnv:
         obs = self.obs if out is None else out
         if mask is None:
             lanes, mask_dev = range(self.num_envs), None
-            self._t_host[:] = 0
+            self._t_all, self._t_lanes = 0, None
         else:
             m = torch.as_tensor(mask).to(torch.uint8)
             lanes = np.nonzero(m.cpu().numpy())[0]
             mask_dev = m.to(self.device)
-            self._t_host[lanes] = 0
+            self._lane_steps()[lanes] = 0
         draws = self._dev64(self.draws.reset_draws(self, lanes)) if self.draws.injects else None
         native.check(self._lib.pime_env_reset(self._h, native.ptr(mask_dev), native.ptr(draws), native.ptr(obs),
                                               self._stream()), "pime_env_reset")
         self._was_reset = True
         return obs
 
+    def _lane_steps(self):
+        """Per-lane view of the step mirror (materialised on first need)."""
+        if self._t_lanes is None:
+            self._t_lanes = np.full(self.num_envs, self._t_all, dtype=np.int64)
+        return self._t_lanes
+
     def _pre_step(self, auto_reset):
         noise = self._dev64(self.draws.step_noise(self)) if self.draws.injects else None
-        self._t_host += 1
-        ending = np.nonzero(self._t_host >= self.max_step)[0]
+        if self._t_lanes is None:                      # lock-step fast path: O(1) host work per launch
+            self._t_all += 1
+            ending = range(self.num_envs) if self._t_all >= self.max_step else ()
+            if auto_reset and len(ending):
+                self._t_all = 0
+        else:
+            self._t_lanes += 1
+            ending = np.nonzero(self._t_lanes >= self.max_step)[0]
+            if auto_reset and len(ending):
+                self._t_lanes[ending] = 0
+                if not self._t_lanes.any():
+                    self._t_all, self._t_lanes = 0, None   # back in lock-step
         reset_draws = None
-        if auto_reset and len(ending):
-            if self.draws.injects:
-                reset_draws = self._dev64(self.draws.reset_draws(self, ending))
-            self._t_host[ending] = 0
+        if auto_reset and len(ending) and self.draws.injects:
+            reset_draws = self._dev64(self.draws.reset_draws(self, ending))
         return noise, reset_draws
 
     def step(self, action, auto_reset=True, out_obs=None, out_reward=None, out_done=None):
@@ -227,7 +246,7 @@ class VecControlEnv:
     @property
     def fresh(self):
         """True when every lane is at step 0 of an episode (just reset, or auto-reset by the last step)."""
-        return self._was_reset and not self._t_host.any()
+        return self._was_reset and (self._t_all == 0 if self._t_lanes is None else not self._t_lanes.any())
 
     def observe(self, out=None):
         obs = self.obs if out is None else out
@@ -247,7 +266,8 @@ class VecControlEnv:
         native.check(self._lib.pime_env_write_field(self._h, native.FIELD[self.field_prefix + name], native.ptr(v),
                                                     native.ptr(m), self._stream()), f"write_field({name})")
         if name == "t":
-            self._t_host[:] = v.astype(np.int64) if mask is None else np.where(m.astype(bool), v, self._t_host)
+            t = self._lane_steps()
+            t[:] = v.astype(np.int64) if mask is None else np.where(m.astype(bool), v, t)
 
     def set_reset_all(self, if_reset_all, every=1):
         """if_reset_all False keeps the ensemble params across resets (ph.py:111-112; attribute
@@ -329,6 +349,27 @@ class VecPH(VecControlEnv):
         x0 = env_rs.uniform(low=0, high=50)
         r = env_rs.uniform(3., 11.)
         return qww, qc, x0, r
+
+    @property
+    def supports_fused_rollout(self):
+        """The one-launch-per-episode rollout kernel exists for the mixed-precision pH env with in-kernel draws."""
+        return self.cfg.state_mode == native.STATE_MIXED and not self.draws.injects
+
+    def rollout(self, packed_actor, a_std_log, priorK, n_steps, noise_seed, noise_epoch, state, action, noise, reward, done):
+        """Advance every lane `n_steps` steps under the packed residual policy in ONE launch (csrc/rollout.hip):
+        state [n_steps+1, N, 3] (slot 0 = current observation), action / noise / reward [n_steps, N], done uint8.
+        Requires whole episodes from a fresh env (every lane at step 0), like AgentResidual*.explore_env collects."""
+        assert self.fresh and n_steps % self.max_step == 0, "fused rollout advances whole episodes from a fresh env"
+        for t_ in (state, action, noise, reward, done):
+            assert t_.is_contiguous() and t_.device == self.device
+        k = np.ascontiguousarray(np.asarray(priorK, dtype=np.float64).reshape(-1))
+        assert k.size == 3 and packed_actor.D == 3
+        native.check(self._lib.pime_rollout_ph(
+            self._h, native.MLP_MODULAR_ACTOR if packed_actor.kind == "modular_actor" else native.MLP_PLAIN_ACTOR,
+            packed_actor.md, native.ptr(packed_actor.packed), native.ptr(a_std_log), native.ptr(k), int(n_steps),
+            C.c_uint64(noise_seed), C.c_uint32(noise_epoch), native.ptr(state), native.ptr(action), native.ptr(noise),
+            native.ptr(reward), native.ptr(done), self._stream()), "pime_rollout_ph")
+        # whole episodes with in-kernel auto-reset: every lane is back at step 0 of a new episode
 
     def get_changable_parameters(self):
         return self.get_field("qww_V"), self.get_field("qc_V")
