@@ -188,6 +188,7 @@ def main():
     agent.state_value = timer.wrap("mlp_forward<critic> value pass", agent.state_value)
     agent.policy_mean = timer.wrap("mlp_forward<modular_actor> rollout", agent.policy_mean)
     env.step_residual = timer.wrap("ph_step_kernel (fused residual)", env.step_residual)
+    env.rollout = timer.wrap("rollout_ph_kernel (50 steps, one launch)", env.rollout)
     agent.backend.gae = timer.wrap("gae_scan_kernel", agent.backend.gae)
     agent.launch_timer = timer.bracket  # "ppo_minibatch_grad": the 4 launches of one minibatch gradient
 
@@ -261,8 +262,23 @@ def main():
                     "avg_launch_ms": ms_dom}
     n_v, ms_v = ks["mlp_forward<critic> value pass"]
     v_tf = MLP_FLOPS_PER_ROW["critic"] * LANES * T_EP / (ms_v * 1e-3) / 1e12
-    n_env, ms_env = ks["ph_step_kernel (fused residual)"]
-    env_gbs = PH_STEP_BYTES * LANES / (ms_env * 1e-3) / 1e9
+    ro_key = "rollout_ph_kernel (50 steps, one launch)"
+    if ro_key in ks:   # fused rollout: policy forward + noise + env step + buffer writes for a whole episode per launch
+        n_env, ms_env = ks[ro_key]
+        ro_tf = MLP_FLOPS_PER_ROW["modular_actor"] * LANES * T_EP / (ms_env * 1e-3) / 1e12
+        roofline_env = {"kernel": "rollout_ph_kernel<4, modular_actor> (16384 lanes x 50 steps per launch)", "bound": "mfma",
+                        "achieved": ro_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ro_tf / F32_MFMA_PEAK_TFLOPS,
+                        "traffic": None, "avg_launch_ms": ms_env,
+                        "note": "one 32-lane tile per SIMD, serial 512-MFMA chain per env step: latency bound by design; the "
+                                "step-per-launch env kernels reach 5.0 TB/s (pH) / 2.5 TB/s (WT) at >= 1M lanes, "
+                                "profiles/r01_e_env_roofline_sweep.jsonl"}
+    else:
+        n_env, ms_env = ks["ph_step_kernel (fused residual)"]
+        env_gbs = PH_STEP_BYTES * LANES / (ms_env * 1e-3) / 1e9
+        roofline_env = {"kernel": "ph_step_kernel (fused residual)", "bound": "hbm", "achieved": env_gbs,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": env_gbs / HBM_PEAK_GBS,
+                        "traffic": pmc_traffic_bytes(["ph_step_kernel"]), "algorithmic_bytes_per_launch": PH_STEP_BYTES * LANES,
+                        "avg_launch_ms": ms_env, "note": "16384-lane launch moves 1.5 MB: launch-latency bound"}
     out = {
         "metric": "env-steps/sec (rollout+update), pH env, 16384 parallel envs",
         "value": total / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -273,10 +289,7 @@ def main():
                    "lanes_per_gpu": LANES, "episode_len": T_EP, "batch": BATCH, "repeat_times": REPEAT,
                    "state_mode": "mixed (f32 state, f64 x/A/B/C)", "parallelism": f"dp{world}"},
         "roofline": roofline,
-        "roofline_env": {"kernel": "ph_step_kernel (fused residual)", "bound": "hbm", "achieved": env_gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": env_gbs / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes(["ph_step_kernel"]), "algorithmic_bytes_per_launch": PH_STEP_BYTES * LANES,
-                         "avg_launch_ms": ms_env, "note": "16384-lane launch moves 1.5 MB: launch-latency bound"},
+        "roofline_env": roofline_env,
         "roofline_value_pass": {"kernel": "mlp_forward_kernel<4, critic> (819200 rows)", "bound": "mfma", "achieved": v_tf,
                                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": v_tf / F32_MFMA_PEAK_TFLOPS,
                                 "avg_launch_ms": ms_v},
