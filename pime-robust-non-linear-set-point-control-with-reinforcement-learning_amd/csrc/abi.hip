@@ -619,6 +619,8 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         a.dout = n->workspace + ntiles * (int64_t)stash_tiles_of(n->kind, n->md) * 1024;
         a.xg = a.dout + ntiles * 32;
         a.loss_sums = loss_sums; a.g_std = n->g_a_std_log;
+        a.stagger = 3;  // measured best of 0..4 on MI355X (532 -> 522 us per minibatch gradient)
+        if (const char* e = std::getenv("PIME_STAGGER")) a.stagger = std::atoi(e);  // tuning knob
         if (int rc = launch_ppo_net(n->kind, n->md, a, s)) return rc;
         dw.njobs += build_dw_jobs(n->kind, n->md, a, n->params, n->grads, dw.job + dw.njobs);
     }

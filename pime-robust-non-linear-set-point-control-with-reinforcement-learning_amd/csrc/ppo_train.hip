@@ -146,6 +146,11 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
     const MlpLayout L = mlp_layout(KIND, a.D, a.Di, T * 32);
     stage_image(lds, a.img_fwd, L.total / 4);
     __syncthreads();
+    // The two waves that share a SIMD (w and w+4) run the same program; in lock-step their MFMA segments collide on
+    // the matrix pipe and their VALU / memory segments leave it idle (PMC: pipe busy 47 %, waves issue-stalled 67 %).
+    // Delaying the second group by about one MFMA segment makes the segments complementary.
+    const int stagger = __builtin_amdgcn_readfirstlane(wave >= 4 ? a.stagger : 0);
+    for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(127);  // 127 * 64 cycles each
     float s0 = 0.f, s1 = 0.f, gstd = 0.f;
     double m1 = 0.0, m2 = 0.0;
     for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
     const BwdLayout Lb = bwd_layout(KIND, a.D, a.Di, T * 32);
     stage_image(lds, a.img_bwd, Lb.total / 4);
     __syncthreads();
+    for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(127);
     for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
         PIME_NO_HOIST();
         const int pos = tile * 32 + (lane & 31);

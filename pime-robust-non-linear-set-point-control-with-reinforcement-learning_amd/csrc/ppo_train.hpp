@@ -15,6 +15,7 @@ struct PpoArgs {
     float *stash, *dout, *xg;  // xg: [tiles*32][D] gathered minibatch states
     float* loss_sums;  // [4]: sum(-surrogate), sum(entropy proxy), sum(smooth-l1), unused
     float* g_std;      // actor: gradient of a_std_log (accumulated)
+    int stagger;       // start delay of waves 4-7 in units of s_sleep(127) (8128 cycles)
 };
 
 struct DwJob {
