@@ -158,12 +158,51 @@ def cpu_baseline():
                       f"repeat {REPEAT}: C oracle env (1 thread) {t1 - t0:.2f}s + torch-CPU PPO update ({cores} threads) {t2 - t1:.2f}s"}
 
 
+def bench_water_tank(args, device, json_fd):
+    """BASELINE config 2: water-tank Integrator env, 4096 lanes x 200-step episodes, ResidualIntegratorModularPPO
+    net_dim 128, batch 65536, repeat 8 (run_watertank_changing.sh shape scaled to N*T samples)."""
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from pime_amd.elegantrl.run import make_buffer
+    lanes, T = 4096, 200
+    env = gym_control.make_vec(gym_control.WT_INTEGRATOR, lanes, device=device, state_mode="mixed", seed=0,
+                               reward_type="distance")
+    torch.manual_seed(0)
+    agent = AgentResidualIntegratorModularPPO(device=device)
+    agent.init(NET_DIM, env.state_dim, 1, env.n_integrator)
+    agent.init_residual({"init_K": env.K.reshape(-1, 1)})
+    agent.init_actor_zero()
+    agent.fix_K()
+    buf = make_buffer(agent, env, lanes * T)
+
+    def step():
+        n = agent.explore_env(env, buf, lanes * T, 1.0, GAMMA)
+        agent.update_net(buf, lanes * T, BATCH, REPEAT)
+        return n
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total = sum(step() for _ in range(args.steps))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": "env-steps/sec (rollout+update), water-tank env, 4096 parallel envs", "value": total / dt,
+           "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "water tank Integrator-v2 (reward 'distance'), 4096 lanes x 200-step episodes, "
+                                  "ResidualIntegratorModularPPO net_dim 128, batch 65536, repeat 8"}}
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="ph", choices=["ph", "wt"],
+                    help="ph: the headline config (BASELINE config 3); wt: config 2, water tank, 4096 lanes x 200 steps "
+                         "(reported for DESIGN.md; the headline metric is the ph line)")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block at
@@ -181,6 +220,8 @@ def main():
     dp = pdist.init_from_env(backend="nccl", device=device) if (world > 1 or os.environ.get("PIME_FORCE_DP") == "1") else None
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    if args.workload == "wt":
+        return bench_water_tank(args, device, json_fd)
     env, agent, buf = build_stack(device, rank, world, dp)
     timer = KernelTimer()
     # time the hand-written kernels where the agent calls them

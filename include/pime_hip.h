@@ -235,13 +235,14 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
  * 52-69: select_action -> env.step(np.tanh(action) + state @ priorK) -> buffer.append_buffer), as ONE launch: policy
  * forward (packed actor image, pime_mlp_pack), exploration noise (in-kernel Philox stream 2 keyed by noise_seed,
  * counter (lane, noise_epoch, t)), residual composition, env step with in-kernel auto-reset, trajectory writes.
- * pH env handle in PIME_STATE_MIXED mode with Philox draws; kind = PIME_MLP_PLAIN_ACTOR | PIME_MLP_MODULAR_ACTOR.
- *   state  [dev] float32[n_steps+1, N, 3]: slot 0 must hold the current observation on entry (pime_env_reset /
+ * pH or water-tank (Integrator observation) env handle in PIME_STATE_MIXED mode with Philox draws;
+ * kind = PIME_MLP_PLAIN_ACTOR | PIME_MLP_MODULAR_ACTOR.
+ *   state  [dev] float32[n_steps+1, N, obs_dim]: slot 0 must hold the current observation on entry (pime_env_reset /
  *          pime_env_observe), slots 1..n_steps are written;  action (pre-tanh), noise, reward [dev] float32[n_steps, N];
- *          done [dev] uint8[n_steps, N];  priorK [host] float64[3]. */
-int pime_rollout_ph(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
-                    const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, float* state,
-                    float* action, float* noise, float* reward, uint8_t* done, pime_stream stream);
+ *          done [dev] uint8[n_steps, N];  priorK [host] float64[obs_dim]. */
+int pime_rollout(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
+                 const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, float* state,
+                 float* action, float* noise, float* reward, uint8_t* done, pime_stream stream);
 
 /* replaces: self.optimizer.step() of the single Adam over both nets (elegantrl/agent.py:565-566,656-657; no weight
  * decay, no amsgrad) when every parameter lives in ONE flat tensor.  All [dev] float32[n]; step [dev] float32[1] is the

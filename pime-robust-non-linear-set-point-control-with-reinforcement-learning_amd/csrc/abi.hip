@@ -45,7 +45,7 @@ int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, 
 int launch_dw(const DwArgs&, int, hipStream_t);
 int launch_critic_scale(int, int, float* const*, const double*, int, float*, hipStream_t);
 int launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float*, hipStream_t);
-int launch_rollout_ph(int, int, const RolloutArgs&, hipStream_t);
+int launch_rollout(int, int, const RolloutArgs&, hipStream_t);
 
 }  // namespace pime
 
@@ -556,25 +556,28 @@ int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const flo
     return launch_pack_bwd(kind, D, Di, md, params, image, static_cast<hipStream_t>(stream));
 }
 
-int pime_rollout_ph(pime_env* e, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
-                    const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, float* state,
-                    float* action, float* noise, float* reward, uint8_t* done, pime_stream stream) {
+int pime_rollout(pime_env* e, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
+                 const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, float* state,
+                 float* action, float* noise, float* reward, uint8_t* done, pime_stream stream) {
     PIME_REQUIRE(e != nullptr, "NULL env handle");
-    PIME_REQUIRE(e->cfg.kind == PIME_ENV_PH && e->cfg.state_mode == PIME_STATE_MIXED,
-                 "pime_rollout_ph: needs a pH env handle in PIME_STATE_MIXED mode");
+    PIME_REQUIRE(e->cfg.state_mode == PIME_STATE_MIXED, "pime_rollout: needs an env handle in PIME_STATE_MIXED mode");
+    PIME_REQUIRE(e->cfg.kind == PIME_ENV_PH || e->cfg.num_stack == 0,
+                 "pime_rollout: the water-tank Stacking observation is not supported by the fused rollout");
     PIME_REQUIRE(packed_actor && a_std_log && priorK && state && action && noise && reward && done && n_steps >= 1,
-                 "pime_rollout_ph: bad arguments");
-    if (!e->was_reset) { set_error("pime_rollout_ph before pime_env_reset"); return PIME_ERR_STATE; }
+                 "pime_rollout: bad arguments");
+    if (!e->was_reset) { set_error("pime_rollout before pime_env_reset"); return PIME_ERR_STATE; }
     if (int rc = use_device(e)) return rc;
     RolloutArgs a{};
-    a.p = e->ph;
-    a.p.auto_reset = 1;
-    a.st = e->ph32;
+    a.env = e->cfg.kind == PIME_ENV_PH ? 0 : 1;
+    a.n = e->cfg.n_envs;
+    a.env_offset = e->cfg.env_offset;
+    if (a.env == 0) { a.p = e->ph; a.p.auto_reset = 1; a.st = e->ph32; }
+    else { a.wp = e->wt; a.wp.auto_reset = 1; a.wst = e->wt32; }
     a.img = packed_actor; a.a_std_log = a_std_log;
-    for (int j = 0; j < 3; ++j) a.K.k[j] = priorK[j];
+    for (int j = 0; j < e->obs_dim; ++j) a.K.k[j] = priorK[j];
     a.n_steps = n_steps; a.noise_seed = noise_seed; a.noise_epoch = noise_epoch;
     a.state = state; a.action = action; a.noise = noise; a.reward = reward; a.done = done;
-    return launch_rollout_ph(kind, md, a, static_cast<hipStream_t>(stream));
+    return launch_rollout(kind, md, a, static_cast<hipStream_t>(stream));
 }
 
 int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

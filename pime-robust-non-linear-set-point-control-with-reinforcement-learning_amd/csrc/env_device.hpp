@@ -127,4 +127,109 @@ __device__ __forceinline__ double ph_residual_action(float a_pre, const float (&
     return (double)tanhf(a_pre) + dot;
 }
 
+// ============================================================================================ water tank
+// Register-resident lane of NonLinearWaterTankChangingParamUniformGoal{Integrator,Stacking}
+// (/root/reference/gym_control/envs/nonlinear_watertank.py:800-826, :1118-1147 step; :890-939, :1166-1208 reset).
+// The Stacking variant's frame ring stays in memory and is handled by the caller; everything else is here.
+template <typename S>
+struct WtLane {
+    S h1, h2, r, I, a1, a2, kp;
+    int t, episode;
+    bool plant_changed;
+};
+
+template <typename S>
+__device__ __forceinline__ void wt_lane_load(const WtParams& p, const WtPtrs<S>& st, int i, WtLane<S>& L) {
+    L.h1 = st.h1[i]; L.h2 = st.h2[i]; L.r = st.r[i];
+    L.I = p.num_stack == 0 ? st.I[i] : S(0);
+    L.a1 = st.a1[i]; L.a2 = st.a2[i]; L.kp = st.kp[i];
+    L.t = st.t[i]; L.episode = st.episode[i];
+    L.plant_changed = false;
+}
+
+template <typename S>
+__device__ __forceinline__ void wt_lane_store(const WtParams& p, const WtPtrs<S>& st, int i, const WtLane<S>& L) {
+    st.h1[i] = L.h1; st.h2[i] = L.h2; st.r[i] = L.r; st.t[i] = L.t; st.episode[i] = L.episode;
+    if (p.num_stack == 0) st.I[i] = L.I;
+    if (L.plant_changed) { st.a1[i] = L.a1; st.a2[i] = L.a2; st.kp[i] = L.kp; }
+}
+
+// draws = this lane's 6 injected values (a1, a2, Kp, h1, h2, r) or nullptr for in-kernel Philox
+template <typename S>
+__device__ __forceinline__ void wt_lane_reset(const WtParams& p, uint32_t gid, const double* __restrict__ draws,
+                                              WtLane<S>& L) {
+    const int ep = L.episode + 1;
+    L.episode = ep;
+    const bool resample = p.resample_every > 0 && (ep % p.resample_every) == 0;
+    double v[6];
+    if (draws) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = draws[j];
+    } else {
+        double u[6];
+#pragma unroll
+        for (uint32_t s = 0; s < 3; ++s) philox_pair(p.seed, gid, (uint32_t)ep, s, STREAM_RESET, u[2 * s], u[2 * s + 1]);
+        v[0] = p.a1_lo + (p.a1_hi - p.a1_lo) * u[0];  // sample_parameters :890-894
+        v[1] = p.a2_lo + (p.a2_hi - p.a2_lo) * u[1];
+        v[2] = p.kp_lo + (p.kp_hi - p.kp_lo) * u[2];
+        v[3] = p.h_lo + (p.h_hi - p.h_lo) * u[3];     // :912
+        v[4] = p.h_lo + (p.h_hi - p.h_lo) * u[4];
+        v[5] = p.r_lo + (p.r_hi - p.r_lo) * u[5];     // :913
+    }
+    if (resample) {
+        L.a1 = (S)v[0]; L.a2 = (S)v[1]; L.kp = (S)v[2];
+        L.plant_changed = true;
+    }
+    L.h1 = (S)v[3]; L.h2 = (S)v[4]; L.r = (S)v[5];
+    L.t = 0;
+    L.I = S(0);
+}
+
+// the two process-noise normals of step L.t+1 (already scaled): injected pair or Philox Box-Muller (:271-272,:810-811)
+template <typename S>
+__device__ __forceinline__ void wt_lane_noise(const WtParams& p, uint32_t gid, const WtLane<S>& L,
+                                              const double* __restrict__ noise, double& z1n, double& z2n) {
+    if (noise) {
+        z1n = noise[0]; z2n = noise[1];
+    } else {
+        double ua, ub;
+        philox_pair(p.seed, gid, (uint32_t)L.episode, (uint32_t)(L.t + 1), STREAM_NOISE, ua, ub);
+        const double rad = sqrt(-2.0 * log(1.0 - ua)), ang = 6.283185307179586476925286766559 * ub;
+        double sn, cs;
+        sincos(ang, &sn, &cs);
+        z1n = p.noise_scale * (rad * cs);
+        z2n = p.noise_scale * (rad * sn);
+    }
+}
+
+// One env step for env action `a` (NOT clipped, :258-260); returns done (:816-821)
+template <typename S>
+__device__ __forceinline__ bool wt_lane_step(const WtParams& p, double a, double z1n, double z2n, WtLane<S>& L,
+                                             float& reward) {
+    L.t += 1;                                                           // :801
+    const S u = (S)(a * p.pmax / 2. + p.pmax / 2.);                     // action_P
+    S h1 = L.h1, h2 = L.h2;
+    const S A1 = (S)p.A1, A2 = (S)p.A2, G = (S)p.G, dt = (S)p.dt;
+    const S lo = S(-0.0), hi = (S)INFINITY;                            // Box(low=-0, high=inf) :252-257
+    for (int s = 0; s < p.n_discrete; ++s) {                            // :805-809, both roots from the OLD h1,h2
+        const S s1 = sqrt(2 * G * h1), s2 = sqrt(2 * G * h2);
+        const S n1 = h1 + (-L.a1 / A1 * s1 + L.kp / A1 * u) * dt;
+        const S n2 = h2 + (L.a1 / A2 * s1 - L.a2 / A2 * s2) * dt;
+        h1 = clip(n1, lo, hi);
+        h2 = clip(n2, lo, hi);
+    }
+    h1 = clip(h1 + (S)z1n, lo, hi);                                     // :810-813
+    h2 = clip(h2 + (S)z2n, lo, hi);
+    L.h1 = h1; L.h2 = h2;
+    S rew = reward_of<S>(p.reward_type, h2, L.r, (S)p.thr);
+    if (p.reward_type != PIME_REWARD_SPARSE) rew = rew * (S)p.z1;       // :506,508
+    if (p.num_stack == 0) {
+        const S I_raw = L.I + (L.r - h2);                               // :822-823
+        rew += -(S)p.integral_punish * fabs(I_raw);                     // :824
+        L.I = clip(I_raw, (S)-p.integral_max, (S)p.integral_max);       // :825
+    }
+    reward = (float)rew;
+    return !(L.t < p.max_steps);
+}
+
 }  // namespace pime

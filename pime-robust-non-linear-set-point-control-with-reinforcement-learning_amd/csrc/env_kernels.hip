@@ -79,41 +79,11 @@ __device__ __forceinline__ void wt_write_obs(const WtParams& p, const WtPtrs<S>&
     }
 }
 
+// frames of the Stacking variant after a reset: every frame = first frame (:1181-1183)
 template <typename S>
-__device__ __forceinline__ void wt_reset_lane(const WtParams& p, const WtPtrs<S>& st, int i,
-                                              const double* __restrict__ draws, float* __restrict__ obs) {
-    const int ep = st.episode[i] + 1;
-    st.episode[i] = ep;
-    const bool resample = p.resample_every > 0 && (ep % p.resample_every) == 0;
-    double v[6];
-    if (draws) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) v[j] = draws[6 * (size_t)i + j];
-    } else {
-        double u[6];
-#pragma unroll
-        for (uint32_t s = 0; s < 3; ++s)
-            philox_pair(p.seed, p.env_offset + (uint32_t)i, (uint32_t)ep, s, STREAM_RESET, u[2 * s], u[2 * s + 1]);
-        v[0] = p.a1_lo + (p.a1_hi - p.a1_lo) * u[0];  // sample_parameters :890-894
-        v[1] = p.a2_lo + (p.a2_hi - p.a2_lo) * u[1];
-        v[2] = p.kp_lo + (p.kp_hi - p.kp_lo) * u[2];
-        v[3] = p.h_lo + (p.h_hi - p.h_lo) * u[3];     // :912
-        v[4] = p.h_lo + (p.h_hi - p.h_lo) * u[4];
-        v[5] = p.r_lo + (p.r_hi - p.r_lo) * u[5];     // :913
-    }
-    if (resample) {
-        st.a1[i] = (S)v[0]; st.a2[i] = (S)v[1]; st.kp[i] = (S)v[2];
-    }
-    const S h1 = (S)v[3], h2 = (S)v[4], r = (S)v[5];
-    st.h1[i] = h1; st.h2[i] = h2; st.r[i] = r;
-    st.t[i] = 0;
-    if (p.num_stack > 0) {  // every frame = first frame (:1181-1183)
-        S* f = st.frames + (size_t)i * p.obs_dim;
-        for (int s = 0; s < p.num_stack; ++s) { f[3 * s] = h1; f[3 * s + 1] = h2; f[3 * s + 2] = r; }
-    } else {
-        st.I[i] = S(0);
-    }
-    wt_write_obs<S>(p, st, i, h1, h2, r, S(0), obs);
+__device__ __forceinline__ void wt_fill_frames(const WtParams& p, const WtPtrs<S>& st, int i, const WtLane<S>& L) {
+    S* f = st.frames + (size_t)i * p.obs_dim;
+    for (int s = 0; s < p.num_stack; ++s) { f[3 * s] = L.h1; f[3 * s + 1] = L.h2; f[3 * s + 2] = L.r; }
 }
 
 template <typename S>
@@ -122,7 +92,12 @@ __global__ void wt_reset_kernel(WtParams p, WtPtrs<S> st, const uint8_t* __restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     if (mask && !mask[i]) return;
-    wt_reset_lane<S>(p, st, i, draws, obs);
+    WtLane<S> L;
+    wt_lane_load<S>(p, st, i, L);
+    wt_lane_reset<S>(p, p.env_offset + (uint32_t)i, draws ? draws + 6 * (size_t)i : nullptr, L);
+    wt_lane_store<S>(p, st, i, L);
+    if (p.num_stack > 0) wt_fill_frames<S>(p, st, i, L);
+    wt_write_obs<S>(p, st, i, L.h1, L.h2, L.r, L.I, obs);
 }
 
 template <typename S, typename ActT, bool RESIDUAL>
@@ -133,64 +108,35 @@ __global__ void wt_step_kernel(WtParams p, WtPtrs<S> st, const ActT* __restrict_
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     double a;
-    if constexpr (RESIDUAL) {
+    if constexpr (RESIDUAL) {  // agent_residual.py:61
         double dot = 0.0;
         for (int j = 0; j < p.obs_dim; ++j) dot += (double)obs_in[(size_t)i * p.obs_dim + j] * K.k[j];
         a = (double)tanhf((float)act[i]) + dot;
     } else {
         a = (double)act[i];
     }
-    const int t = st.t[i] + 1;                                          // :801
-    const S u = (S)(a * p.pmax / 2. + p.pmax / 2.);                     // action_P :258-260 (a is NOT clipped)
-    S h1 = st.h1[i], h2 = st.h2[i];
-    const S a1 = st.a1[i], a2 = st.a2[i], kp = st.kp[i], r = st.r[i];
-    const S A1 = (S)p.A1, A2 = (S)p.A2, G = (S)p.G, dt = (S)p.dt;
-    const S lo = S(-0.0), hi = (S)INFINITY;                            // Box(low=-0, high=inf) :252-257
-    for (int s = 0; s < p.n_discrete; ++s) {                            // :805-809, both roots from the OLD h1,h2
-        const S s1 = sqrt(2 * G * h1), s2 = sqrt(2 * G * h2);
-        const S n1 = h1 + (-a1 / A1 * s1 + kp / A1 * u) * dt;
-        const S n2 = h2 + (a1 / A2 * s1 - a2 / A2 * s2) * dt;
-        h1 = clip(n1, lo, hi);
-        h2 = clip(n2, lo, hi);
-    }
+    const uint32_t gid = p.env_offset + (uint32_t)i;
+    WtLane<S> L;
+    wt_lane_load<S>(p, st, i, L);
     double z1n, z2n;
-    if (noise) {
-        z1n = noise[2 * (size_t)i]; z2n = noise[2 * (size_t)i + 1];
-    } else {  // Philox Box-Muller; the reference draws np.random.normal twice (:271-272,:810-811)
-        double ua, ub;
-        philox_pair(p.seed, p.env_offset + (uint32_t)i, (uint32_t)st.episode[i], (uint32_t)t, STREAM_NOISE, ua, ub);
-        const double rad = sqrt(-2.0 * log(1.0 - ua)), ang = 6.283185307179586476925286766559 * ub;
-        double sn, cs;
-        sincos(ang, &sn, &cs);
-        z1n = p.noise_scale * (rad * cs);
-        z2n = p.noise_scale * (rad * sn);
-    }
-    h1 = clip(h1 + (S)z1n, lo, hi);                                     // :810-813
-    h2 = clip(h2 + (S)z2n, lo, hi);
-    S rew = reward_of<S>(p.reward_type, h2, r, (S)p.thr);
-    if (p.reward_type != PIME_REWARD_SPARSE) rew = rew * (S)p.z1;       // :506,508
-    const bool d = !(t < p.max_steps);                                  // :816-821
-    S I = S(0);
-    if (p.num_stack == 0) {
-        const S I_raw = st.I[i] + (r - h2);                             // :822-823
-        rew += -(S)p.integral_punish * fabs(I_raw);                     // :824
-        I = clip(I_raw, (S)-p.integral_max, (S)p.integral_max);         // :825
-    }
-    reward[i] = (float)rew;
+    wt_lane_noise<S>(p, gid, L, noise ? noise + 2 * (size_t)i : nullptr, z1n, z2n);
+    float rew;
+    const bool d = wt_lane_step<S>(p, a, z1n, z2n, L, rew);
+    reward[i] = rew;
     done[i] = (uint8_t)d;
     if (d && p.auto_reset) {
-        wt_reset_lane<S>(p, st, i, reset_draws, obs);
-        return;
-    }
-    st.h1[i] = h1; st.h2[i] = h2; st.t[i] = t;
-    if (p.num_stack > 0) {  // deque(maxlen=S).append([h1,h2,r]) (:1143-1144)
-        S* f = st.frames + (size_t)i * p.obs_dim;
-        for (int j = 0; j < p.obs_dim - 3; ++j) f[j] = f[j + 3];
-        f[p.obs_dim - 3] = h1; f[p.obs_dim - 2] = h2; f[p.obs_dim - 1] = r;
+        wt_lane_reset<S>(p, gid, reset_draws ? reset_draws + 6 * (size_t)i : nullptr, L);
+        wt_lane_store<S>(p, st, i, L);
+        if (p.num_stack > 0) wt_fill_frames<S>(p, st, i, L);
     } else {
-        st.I[i] = I;
+        wt_lane_store<S>(p, st, i, L);
+        if (p.num_stack > 0) {  // deque(maxlen=S).append([h1,h2,r]) (:1143-1144)
+            S* f = st.frames + (size_t)i * p.obs_dim;
+            for (int j = 0; j < p.obs_dim - 3; ++j) f[j] = f[j + 3];
+            f[p.obs_dim - 3] = L.h1; f[p.obs_dim - 2] = L.h2; f[p.obs_dim - 1] = L.r;
+        }
     }
-    wt_write_obs<S>(p, st, i, h1, h2, r, I, obs);
+    wt_write_obs<S>(p, st, i, L.h1, L.h2, L.r, L.I, obs);
 }
 
 template <typename S>

@@ -1,4 +1,4 @@
-// Fused on-device rollout for the pH env: ONE launch advances every lane through `n_steps` steps --
+// Fused on-device rollout for the pH and water-tank (Integrator observation) envs: ONE launch advances every lane through `n_steps` steps --
 // policy forward on the f32 matrix cores, exploration noise, residual action composition, env step (+ in-kernel
 // auto-reset) and the trajectory-buffer writes -- with the env state and the observation in registers for the whole
 // episode.  Replaces the per-step launch sequence of AgentResidual*.explore_env
@@ -42,25 +42,30 @@ __device__ __forceinline__ void layer_first_regs(const float* __restrict__ w0, c
 
 constexpr int kRolloutThreads = 128;
 
-template <int T, int KIND>
-__global__ __launch_bounds__(kRolloutThreads) void rollout_ph_kernel(RolloutArgs a) {
+template <int T, int KIND, int ENV>
+__global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int D = 3, Di = 1, Do = D - Di;
+    constexpr int D = ENV == 0 ? 3 : 4, Di = 1, Do = D - Di;
     constexpr int H = T / 2 > 0 ? T / 2 : 1;
     const MlpLayout L = mlp_layout(KIND, D, Di, T * 32);
     stage_image(lds, a.img, L.total / 4);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int N = a.p.n;
+    const int N = a.n;
     const int m = (blockIdx.x * (kRolloutThreads / 64) + wave) * 32 + (lane & 31);
     const bool valid = m < N;
     const int i = valid ? m : N - 1;  // idle lanes shadow the last env (compute, never store)
     const bool writer = valid && h == 0;
+    const uint32_t gid = a.env_offset + (uint32_t)i;
     const float sigma = __expf(a.a_std_log[0]);
 
-    PhLane<float> E;
-    ph_lane_load<float>(a.p, a.st, i, E);
-    float obs[3] = {a.state[3 * (size_t)i], a.state[3 * (size_t)i + 1], a.state[3 * (size_t)i + 2]};
+    PhLane<float> E;   // exactly one of the two lanes is live, selected at compile time
+    WtLane<float> W;
+    if constexpr (ENV == 0) ph_lane_load<float>(a.p, a.st, i, E);
+    else wt_lane_load<float>(a.wp, a.wst, i, W);
+    float obs[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) obs[j] = a.state[(size_t)D * i + j];
     for (int t = 0; t < a.n_steps; ++t) {
         PIME_NO_HOIST();
         float a_avg;
@@ -96,57 +101,75 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_ph_kernel(RolloutArgs
         }
         // exploration noise eps ~ N(0,1): Box-Muller on a Philox pair keyed by the global lane (net_residual.py:178)
         double ua, ub;
-        philox_pair(a.noise_seed, a.p.env_offset + (uint32_t)i, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE, ua, ub);
+        philox_pair(a.noise_seed, gid, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE, ua, ub);
         const float eps = (float)(sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586476925286766559 * ub));
         const float a_pre = a_avg + eps * sigma;                                   // net_residual.py:179
-        const double a_env = ph_residual_action(a_pre, obs, a.K);                  // agent_residual.py:61
-        float nxt[3], rew;
-        const bool d = ph_lane_step<float>(a.p, a.st.table, a_env, E, nxt, rew);
+        double dot = 0.0;                                                          // agent_residual.py:61
+#pragma unroll
+        for (int j = 0; j < D; ++j) dot += (double)obs[j] * a.K.k[j];
+        const double a_env = (double)tanhf(a_pre) + dot;
+        float nxt[D], rew;
+        bool d;
+        if constexpr (ENV == 0) {
+            float o3[3];
+            d = ph_lane_step<float>(a.p, a.st.table, a_env, E, o3, rew);
+            if (d) ph_lane_reset<float>(a.p, a.st.table, gid, nullptr, E, o3);     // in-kernel auto-reset
+            nxt[0] = o3[0]; nxt[1] = o3[1]; nxt[2] = o3[2];
+        } else {
+            double z1n, z2n;
+            wt_lane_noise<float>(a.wp, gid, W, nullptr, z1n, z2n);
+            d = wt_lane_step<float>(a.wp, a_env, z1n, z2n, W, rew);
+            if (d) wt_lane_reset<float>(a.wp, gid, nullptr, W);
+            nxt[0] = W.h1; nxt[1] = W.h2; nxt[2] = W.r; nxt[D - 1] = W.I;
+        }
         const size_t k = (size_t)t * N + i;
         if (writer) {
             a.action[k] = a_pre;
             a.noise[k] = eps;
             a.reward[k] = rew;
             a.done[k] = (uint8_t)d;
+            float* s = a.state + ((size_t)(t + 1) * N + i) * D;
+#pragma unroll
+            for (int j = 0; j < D; ++j) s[j] = nxt[j];
         }
-        if (d) ph_lane_reset<float>(a.p, a.st.table, a.p.env_offset + (uint32_t)i, nullptr, E, nxt);  // auto-reset
-        if (writer) {
-            float* s = a.state + ((size_t)(t + 1) * N + i) * 3;
-            s[0] = nxt[0]; s[1] = nxt[1]; s[2] = nxt[2];
-        }
-        obs[0] = nxt[0]; obs[1] = nxt[1]; obs[2] = nxt[2];
+#pragma unroll
+        for (int j = 0; j < D; ++j) obs[j] = nxt[j];
     }
-    if (writer) ph_lane_store<float>(a.p, a.st, i, E);
+    if (writer) {
+        if constexpr (ENV == 0) ph_lane_store<float>(a.p, a.st, i, E);
+        else wt_lane_store<float>(a.wp, a.wst, i, W);
+    }
 }
 
 int mlp_check(int kind, int D, int Di, int md);
 
-template <int T, int KIND>
+template <int T, int KIND, int ENV>
 static int launch_rollout_t(const RolloutArgs& a, hipStream_t s) {
-    const MlpLayout L = mlp_layout(KIND, 3, 1, T * 32);
+    const MlpLayout L = mlp_layout(KIND, ENV == 0 ? 3 : 4, 1, T * 32);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_ph_kernel<T, KIND>),
+        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<T, KIND, ENV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const int tiles = (a.p.n + 31) / 32, per_wg = kRolloutThreads / 64;
-    hipLaunchKernelGGL((rollout_ph_kernel<T, KIND>), dim3((tiles + per_wg - 1) / per_wg), dim3(kRolloutThreads), lds_bytes,
-                       s, a);
+    const int tiles = (a.n + 31) / 32, per_wg = kRolloutThreads / 64;
+    hipLaunchKernelGGL((rollout_kernel<T, KIND, ENV>), dim3((tiles + per_wg - 1) / per_wg), dim3(kRolloutThreads),
+                       lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 
-int launch_rollout_ph(int kind, int md, const RolloutArgs& a, hipStream_t s) {
-    if (int rc = mlp_check(kind, 3, kind == MLP_MODULAR_ACTOR ? 1 : 0, md)) return rc;
+int launch_rollout(int kind, int md, const RolloutArgs& a, hipStream_t s) {
+    if (int rc = mlp_check(kind, a.env == 0 ? 3 : 4, kind == MLP_MODULAR_ACTOR ? 1 : 0, md)) return rc;
     PIME_REQUIRE(kind != MLP_CRITIC, "rollout needs an actor image");
     const int T = md / 32;
-    if (T == 4 && kind == MLP_MODULAR_ACTOR) return launch_rollout_t<4, MLP_MODULAR_ACTOR>(a, s);
-    if (T == 2 && kind == MLP_MODULAR_ACTOR) return launch_rollout_t<2, MLP_MODULAR_ACTOR>(a, s);
-    if (T == 4 && kind == MLP_PLAIN_ACTOR) return launch_rollout_t<4, MLP_PLAIN_ACTOR>(a, s);
-    if (T == 2 && kind == MLP_PLAIN_ACTOR) return launch_rollout_t<2, MLP_PLAIN_ACTOR>(a, s);
-    set_error("no fused rollout instantiation for kind %d width %d", kind, md);
+#define PIME_RO(TT, KK, EE) \
+    if (T == TT && kind == KK && a.env == EE) return launch_rollout_t<TT, KK, EE>(a, s);
+    PIME_RO(4, MLP_MODULAR_ACTOR, 0) PIME_RO(2, MLP_MODULAR_ACTOR, 0) PIME_RO(4, MLP_PLAIN_ACTOR, 0) PIME_RO(2, MLP_PLAIN_ACTOR, 0)
+    PIME_RO(4, MLP_MODULAR_ACTOR, 1) PIME_RO(2, MLP_MODULAR_ACTOR, 1) PIME_RO(4, MLP_PLAIN_ACTOR, 1) PIME_RO(2, MLP_PLAIN_ACTOR, 1)
+#undef PIME_RO
+    set_error("no fused rollout instantiation for env %d kind %d width %d", a.env, kind, md);
     return PIME_ERR_ARG;
 }
 

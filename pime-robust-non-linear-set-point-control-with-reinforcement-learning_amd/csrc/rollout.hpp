@@ -4,15 +4,20 @@
 
 namespace pime {
 struct RolloutArgs {
+    int env;                 // 0: pH (obs [y, r, I]), 1: water tank, Integrator observation [h1, h2, r, I]
+    int n;                   // lanes
+    uint32_t env_offset;
     PhParams p;
     PhPtrs<float> st;
+    WtParams wp;
+    WtPtrs<float> wst;
     const float* img;        // packed actor forward image (pime_mlp_pack)
     const float* a_std_log;  // [1]
     PriorK K;
     int n_steps;
     uint64_t noise_seed;     // Philox key of the exploration noise (stream 2), counter (lane, noise_epoch, t)
     uint32_t noise_epoch;
-    float *state, *action, *noise, *reward;  // [n_steps+1, N, 3], [n_steps, N] x3
+    float *state, *action, *noise, *reward;  // [n_steps+1, N, D], [n_steps, N] x3
     uint8_t* done;                           // [n_steps, N]
 };
 }  // namespace pime

@@ -215,7 +215,7 @@ class AgentPPO(AgentBase):
         if not hasattr(self, "_rollout_seed"):
             self._rollout_seed = int(torch.initial_seed()) & (2 ** 63 - 1)   # exploration stream follows torch's seed
             self._rollout_epoch = 0
-        return self._packed_for("act") is not None and self.act.state_dim == 3
+        return self._packed_for("act") is not None and self.act.state_dim == env.obs_dim
 
     def _vec_env_step(self, env, a_pre, obs, out_obs, out_reward, out_done):
         """Plain PPO: the env sees tanh(a_pre) (agent.py:599)."""

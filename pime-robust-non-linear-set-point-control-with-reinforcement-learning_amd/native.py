@@ -92,7 +92,7 @@ _SIGNATURES = {
     "pime_ppo_bwd_image_floats": (C.c_int64, [_i32, _i32, _i32, _i32]),
     "pime_ppo_workspace_floats": (C.c_int64, [_i32, _i32, _i32]),
     "pime_ppo_pack_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "pime_rollout_ph": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pime_rollout": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pime_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     "pime_ppo_minibatch_grad": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
 }

@@ -106,7 +106,6 @@ class VecControlEnv:
     has_step_noise = False
     action_dim = 1
     if_discrete = False
-    supports_fused_rollout = False
 
     def __init__(self, cfg, device, draws, K):
         self.device = torch.device(device)
@@ -253,6 +252,29 @@ class VecControlEnv:
         native.check(self._lib.pime_env_observe(self._h, native.ptr(obs), self._stream()), "pime_env_observe")
         return obs
 
+    @property
+    def supports_fused_rollout(self):
+        """The one-launch-per-episode rollout kernel exists for mixed-precision state, in-kernel (Philox) draws and --
+        for the water tank -- the Integrator observation."""
+        return (self.cfg.state_mode == native.STATE_MIXED and not self.draws.injects
+                and (self.kind == native.ENV_PH or self.cfg.num_stack == 0))
+
+    def rollout(self, packed_actor, a_std_log, priorK, n_steps, noise_seed, noise_epoch, state, action, noise, reward, done):
+        """Advance every lane `n_steps` steps under the packed residual policy in ONE launch (csrc/rollout.hip):
+        state [n_steps+1, N, D] (slot 0 = current observation), action / noise / reward [n_steps, N], done uint8.
+        Requires whole episodes from a fresh env (every lane at step 0), like AgentResidual*.explore_env collects."""
+        assert self.fresh and n_steps % self.max_step == 0, "fused rollout advances whole episodes from a fresh env"
+        for t_ in (state, action, noise, reward, done):
+            assert t_.is_contiguous() and t_.device == self.device
+        k = np.ascontiguousarray(np.asarray(priorK, dtype=np.float64).reshape(-1))
+        assert k.size == self.obs_dim and packed_actor.D == self.obs_dim
+        native.check(self._lib.pime_rollout(
+            self._h, native.MLP_MODULAR_ACTOR if packed_actor.kind == "modular_actor" else native.MLP_PLAIN_ACTOR,
+            packed_actor.md, native.ptr(packed_actor.packed), native.ptr(a_std_log), native.ptr(k), int(n_steps),
+            C.c_uint64(noise_seed), C.c_uint32(noise_epoch), native.ptr(state), native.ptr(action), native.ptr(noise),
+            native.ptr(reward), native.ptr(done), self._stream()), "pime_rollout")
+        # whole episodes with in-kernel auto-reset: every lane is back at step 0 of a new episode
+
     # -- state access (float64 numpy on the host; synchronous) -------------------------------------------------
     def get_field(self, name):
         out = np.empty(self.num_envs, dtype=np.float64)
@@ -349,27 +371,6 @@ class VecPH(VecControlEnv):
         x0 = env_rs.uniform(low=0, high=50)
         r = env_rs.uniform(3., 11.)
         return qww, qc, x0, r
-
-    @property
-    def supports_fused_rollout(self):
-        """The one-launch-per-episode rollout kernel exists for the mixed-precision pH env with in-kernel draws."""
-        return self.cfg.state_mode == native.STATE_MIXED and not self.draws.injects
-
-    def rollout(self, packed_actor, a_std_log, priorK, n_steps, noise_seed, noise_epoch, state, action, noise, reward, done):
-        """Advance every lane `n_steps` steps under the packed residual policy in ONE launch (csrc/rollout.hip):
-        state [n_steps+1, N, 3] (slot 0 = current observation), action / noise / reward [n_steps, N], done uint8.
-        Requires whole episodes from a fresh env (every lane at step 0), like AgentResidual*.explore_env collects."""
-        assert self.fresh and n_steps % self.max_step == 0, "fused rollout advances whole episodes from a fresh env"
-        for t_ in (state, action, noise, reward, done):
-            assert t_.is_contiguous() and t_.device == self.device
-        k = np.ascontiguousarray(np.asarray(priorK, dtype=np.float64).reshape(-1))
-        assert k.size == 3 and packed_actor.D == 3
-        native.check(self._lib.pime_rollout_ph(
-            self._h, native.MLP_MODULAR_ACTOR if packed_actor.kind == "modular_actor" else native.MLP_PLAIN_ACTOR,
-            packed_actor.md, native.ptr(packed_actor.packed), native.ptr(a_std_log), native.ptr(k), int(n_steps),
-            C.c_uint64(noise_seed), C.c_uint32(noise_epoch), native.ptr(state), native.ptr(action), native.ptr(noise),
-            native.ptr(reward), native.ptr(done), self._stream()), "pime_rollout_ph")
-        # whole episodes with in-kernel auto-reset: every lane is back at step 0 of a new episode
 
     def get_changable_parameters(self):
         return self.get_field("qww_V"), self.get_field("qc_V")

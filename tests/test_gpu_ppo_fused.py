@@ -134,58 +134,67 @@ def test_fused_update_net_matches_torch_update():
     np.testing.assert_allclose(c1, c0, rtol=1e-3)
 
 
-@pytest.mark.parametrize("algo", ["ResidualIntegratorModularPPO", "ResidualPPO", "PPO"])
-def test_fused_rollout_matches_stepwise_rollout(algo):
-    """pime_rollout_ph (one launch per episode) against the per-step launch sequence with the SAME exploration noise:
-    the step-wise agent replays the noise the fused kernel drew (noise_hook), the envs share seed and Philox stream, so
-    states / actions / rewards / done flags must agree step for step over two episodes (auto-reset in between).
-    Tolerance: the fused kernel's policy mean is the same MFMA code, the env arithmetic is literally the same device
-    functions; the only difference is f32 summation order of `a_avg + eps*sigma`, i.e. ulps -> 'pH within one LUT cell'
-    on rare lanes, which are dropped once they diverge."""
+@pytest.mark.parametrize("env_name,algo", [("PH_V35", "ResidualIntegratorModularPPO"), ("PH_V35", "ResidualPPO"),
+                                           ("PH_V35", "PPO"), ("WT_INTEGRATOR", "ResidualIntegratorModularPPO"),
+                                           ("WT_INTEGRATOR", "ResidualPPO")])
+def test_fused_rollout_matches_stepwise_rollout(env_name, algo):
+    """pime_rollout (one launch per episode) against the per-step launch sequence with the SAME exploration noise:
+    the step-wise agent replays the noise the fused kernel drew (noise_hook), the envs share seed and Philox streams
+    (resets AND water-tank process noise), so states / actions / rewards / done flags must agree step for step over
+    two episodes (auto-reset in between).  The env arithmetic is literally the same device functions
+    (csrc/env_device.hpp); the policy mean is the same MFMA code; what differs is f32 rounding of `a_avg + eps*sigma`,
+    i.e. ulps -> for pH 'within one LUT cell' on rare lanes, which are dropped once they diverge."""
     from pime_amd import gym_control
     from pime_amd.elegantrl.run import make_buffer
     from pime_amd.utils import MODELS
     N = 1024
+    is_ph = env_name == "PH_V35"
+    env_id = getattr(gym_control, env_name)
+    kw = {} if is_ph else dict(reward_type="distance", max_step=40)
     bufs = []
     for fused in (True, False):
-        env = gym_control.make_vec(gym_control.PH_V35, N, device=DEV, seed=11)
+        env = gym_control.make_vec(env_id, N, device=DEV, seed=11, **kw)
+        T = env.max_step
         torch.manual_seed(0)
         ag = MODELS[algo.lower()](device=DEV)
         if "modular" in algo.lower():
-            ag.init(128, 3, 1, 1)
+            ag.init(128, env.state_dim, 1, 1)
         else:
-            ag.init(128, 3, 1)
+            ag.init(128, env.state_dim, 1)
         if "residual" in algo.lower():
             ag.init_residual({"init_K": env.K.reshape(-1, 1)})
         with torch.no_grad():
             ag.act.net[-1].weight.normal_(0, 0.1)
         ag.weights_changed()
         ag.use_fused_rollout = fused
-        buf = make_buffer(ag, env, 2 * N * env.max_step)
+        buf = make_buffer(ag, env, 2 * N * T)
         if not fused:
             ref_noise = bufs[0].noise.clone()
             ag.noise_hook = lambda t, shape: ref_noise[t].reshape(shape)
-        steps = ag.explore_env(env, buf, 2 * N * env.max_step, 1.0, 0.99)
-        assert steps == 2 * N * 50
+        else:
+            assert ag._fused_rollout_ok(env), "fused rollout path not available"
+        steps = ag.explore_env(env, buf, 2 * N * T, 1.0, 0.99)
+        assert steps == 2 * N * T
         bufs.append(buf)
         env.close()
     f, s = bufs
-    noise = f.noise[:100].cpu().numpy()
+    noise = f.noise[:2 * T].cpu().numpy()
     assert abs(noise.mean()) < 0.02 and abs(noise.std() - 1.0) < 0.02      # N(0,1) exploration noise
-    np.testing.assert_array_equal(f.done[:100].cpu().numpy(), s.done[:100].cpu().numpy())
-    assert f.done[49].all() and f.done[99].all() and not f.done[:49].any()
+    np.testing.assert_array_equal(f.done[:2 * T].cpu().numpy(), s.done[:2 * T].cpu().numpy())
+    assert f.done[T - 1].all() and f.done[2 * T - 1].all() and not f.done[:T - 1].any()
     np.testing.assert_array_equal(f.state[0].cpu().numpy(), s.state[0].cpu().numpy())
     alive = np.ones(N, dtype=bool)
-    for t in range(100):
-        if t == 50:
+    for t in range(2 * T):
+        if t == T:
             alive[:] = True   # a new episode starts from the same Philox reset draws on every lane
         fa, sa = f.action[t, :, 0].cpu().numpy(), s.action[t, :, 0].cpu().numpy()
         fs, ss = f.state[t + 1].cpu().numpy(), s.state[t + 1].cpu().numpy()
-        np.testing.assert_allclose(fa[alive], sa[alive], rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(f.reward[t].cpu().numpy()[alive], s.reward[t].cpu().numpy()[alive], rtol=2e-4, atol=2e-4)
-        dy = np.abs(fs[:, 0] - ss[:, 0])
-        if t not in (49, 99):
-            assert dy[alive].max() <= 0.0297
-        alive &= dy <= 1e-5
-        np.testing.assert_allclose(fs[alive], ss[alive], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(fa[alive], sa[alive], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(f.reward[t].cpu().numpy()[alive], s.reward[t].cpu().numpy()[alive], rtol=3e-4, atol=3e-4)
+        if is_ph:
+            dy = np.abs(fs[:, 0] - ss[:, 0])
+            if t not in (T - 1, 2 * T - 1):
+                assert dy[alive].max() <= 0.0297
+            alive &= dy <= 1e-5
+        np.testing.assert_allclose(fs[alive], ss[alive], rtol=1e-4, atol=1e-4)
     assert alive.mean() > 0.95
