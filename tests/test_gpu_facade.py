@@ -305,3 +305,15 @@ def test_batched_step_response_protocols():
     res = protocols.ph_step_response(env, plants=protocols.PH_PARAM_GRID)
     assert res["y"].shape == (250, 9) and np.isfinite(res["y"]).all()
     env.close()
+
+
+def test_train_entry_point_td3(tmp_path):
+    """`--algo TD3` on a one-instance env: the pieces BASELINE.json's "residual TD3" names (Actor, CriticTwin, AgentTD3,
+    flat ring buffer with i/i+1 adjacency) run end to end; the reference itself crashes here because train.py forces
+    if_residual=True onto an agent without init_actor_zero."""
+    from pime_amd import train
+    agent = train.main(["--algo", "TD3", "--env", "NonLinearWaterTankChangingParamUniformGoalIntegrator-SquareDistance-v2",
+                        "--net_dim", "32", "--target_step", "200", "--batch_size", "64", "--break_step", "200",
+                        "--eval_times1", "1", "--eval_times2", "2", "--eval_gap", "1", "--test_render_times", "200",
+                        "--log_root", str(tmp_path)])
+    assert agent.cri_target is not None and agent.act.net[0].in_features == 4
