@@ -434,18 +434,34 @@ __device__ void dw_job(const DwJob& j, int tiles_per_wg, int dbg, float* lds) {
             for (int m = 0; m < 32; ++m) s += rowp[m];
             dbsum += s;
         }
-        // ---- 16 k-steps of two samples each
+        // ---- 16 k-steps of two samples each.  All operand reads of a half (8 k-steps) are issued before its first
+        // MFMA, and the second half's reads before the first half's MFMAs, so the LDS latency hides behind matrix
+        // work (the naive per-tile loop compiled to read -> lgkmcnt(0) -> 2 MFMAs, exposing it every 128 cycles).
+        // kt = tq % BT is the same for every tile of a wave (4 % BT == 0), so B is read once per k-step.
+        if (wave < NQ && !(dbg & 2)) {
+            const int kt = wave % BT;
+            const float* bp = Bm + kt * kDwTile + li * kDwPitch + h;
+            float av[2][PER_WAVE][8], bv[2][8];
 #pragma unroll
-        for (int q = 0; q < PER_WAVE; ++q) {
-            const int tq = wave + 4 * q;
-            if (tq < NQ && !(dbg & 2)) {
-                const int ot = tq / BT, kt = tq % BT;
-                const float* ap = A + ot * kDwTile + li * kDwPitch + h;
-                const float* bp = Bm + kt * kDwTile + li * kDwPitch + h;
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc[q], 0, 0, 0);
+                for (int s = 0; s < 8; ++s) bv[half][s] = bp[2 * (8 * half + s)];
+#pragma unroll
+                for (int q = 0; q < PER_WAVE; ++q)
+                    if (wave + 4 * q < NQ) {
+                        const float* ap = A + ((wave + 4 * q) / BT) * kDwTile + li * kDwPitch + h;
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) av[half][q][s] = ap[2 * (8 * half + s)];
+                    }
             }
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+#pragma unroll
+                    for (int q = 0; q < PER_WAVE; ++q)
+                        if (wave + 4 * q < NQ)
+                            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[half][q][s], bv[half][s], acc[q], 0, 0, 0);
         }
     }
     // ---- combine: D[i = a feature][j = b feature], col on the lane, rows in the registers
@@ -472,7 +488,6 @@ __global__ __launch_bounds__(kDwThreads) void ppo_dw_kernel(DwArgs a) {
     const DwJob& j = a.job[blockIdx.y];
     const int key = j.a_tiles * 8 + j.b_tiles;
     switch (key) {
-        case 4 * 8 + 4: dw_job<4, 4>(j, a.tiles_per_wg, a.debug_skip, lds); break;
         case 2 * 8 + 4: dw_job<2, 4>(j, a.tiles_per_wg, a.debug_skip, lds); break;
         case 4 * 8 + 1: dw_job<4, 1>(j, a.tiles_per_wg, a.debug_skip, lds); break;
         case 1 * 8 + 4: dw_job<1, 4>(j, a.tiles_per_wg, a.debug_skip, lds); break;
@@ -636,7 +651,21 @@ int build_dw_jobs(int kind, int md, const PpoArgs& a, const float* const* params
           j.col0 = 0; j.act = act; outp(j, 2, md, md); jobs[n++] = j; }                                                             // net.2
         { DwJob j = base(); stash_a(j, 4 * T, T); j.b_kind = 2; j.b_tiles = 1; j.Din = a.D; j.col0 = 0; outp(j, 0, md, a.D); jobs[n++] = j; }  // net.0
     }
-    return n;
+    // A 128x128 gradient as one (4 x 4)-tile job needs 64 accumulator + 32 prefetch + 80 operand registers per lane,
+    // which caps the kernel at two workgroups per CU and leaves it latency-bound (PMC: waves parked on memory 54 %,
+    // matrix pipe busy 33 %).  Splitting it into two (2 x 4) jobs over the output rows re-reads the B tiles once more
+    // but halves the registers, so twice as many workgroups hide each other's HBM latency.
+    int m = n;
+    for (int i = 0; i < n; ++i) {
+        if (jobs[i].a_tiles == 4 && jobs[i].b_tiles == 4) {
+            DwJob hi = jobs[i];
+            jobs[i].a_tiles = 2; jobs[i].out_rows = 64;
+            hi.a_tiles = 2; hi.a_t0 += 2; hi.out_rows = 64;
+            hi.dW += (size_t)64 * hi.ldw; hi.db += 64;
+            jobs[m++] = hi;
+        }
+    }
+    return m;
 }
 
 int launch_dw(const DwArgs& args, int B, hipStream_t s) {

@@ -33,7 +33,7 @@ struct DwJob {
     int D, B;
 };
 
-constexpr int kMaxDwJobs = 12;
+constexpr int kMaxDwJobs = 16;
 
 struct DwArgs {
     DwJob job[kMaxDwJobs];
