@@ -41,6 +41,10 @@ int64_t ppo_workspace_floats(int, int, int);
 inline int stash_tiles_of(int kind, int md) { return (kind == 2 ? 6 : 5) * (md / 32); }
 int launch_pack_bwd(int, int, int, int, const float* const*, float*, hipStream_t);
 int launch_ppo_net(int, int, const PpoArgs&, hipStream_t);
+int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
+int64_t fused_stash_floats(int, int);
+int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, float* const*, float* const*, float*, float*,
+                       double*, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
 int launch_dw(const DwArgs&, int, hipStream_t);
 int launch_critic_scale(int, int, float* const*, const double*, int, float*, hipStream_t);
@@ -609,7 +613,15 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
     hipStream_t s = static_cast<hipStream_t>(stream);
     PIME_HIP_TRY(hipMemsetAsync(moments, 0, 2 * sizeof(double), s));
     DwArgs dw{};
+    static const bool split = std::getenv("PIME_PPO_SPLIT") != nullptr;  // A/B knob: the older net + dW kernel pipeline
+    static const bool tracing = std::getenv("PIME_FUSED_TRACE") != nullptr;  // tuning aid: phase marks of workgroup 0
+    static long long* trace_dev = nullptr;
+    if (tracing && !trace_dev) {
+        PIME_HIP_TRY(hipMalloc(&trace_dev, 2 * 32 * sizeof(long long)));
+    }
+    if (tracing) PIME_HIP_TRY(hipMemsetAsync(trace_dev, 0, 2 * 32 * sizeof(long long), s));
     const pime_ppo_net* nets[2] = {critic, actor};
+    PpoArgs fused_args[2];
     for (int k = 0; k < 2; ++k) {
         const pime_ppo_net* n = nets[k];
         PpoArgs a{};
@@ -624,12 +636,40 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         a.loss_sums = loss_sums; a.g_std = n->g_a_std_log;
         a.stagger = 3;  // measured best of 0..4 on MI355X (532 -> 522 us per minibatch gradient)
         if (const char* e = std::getenv("PIME_STAGGER")) a.stagger = std::atoi(e);  // tuning knob
+        const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
+        for (int i = 0; i < np; ++i) a.grad[i] = n->grads[i];
+        if (!split) {
+            int psize[12];
+            a.slab = n->workspace + fused_stash_floats(b->B, n->md);
+            a.slab_stride = slab_layout(n->kind, n->D, n->Di, n->md, a.poff, psize);
+            fused_args[k] = a;
+            a.trace = tracing ? trace_dev + 32 * k : nullptr;
+            a.trace_wg = tracing ? std::atoi(std::getenv("PIME_FUSED_TRACE")) : 0;
+            if (int rc = launch_ppo_fused(n->kind, n->md, a, s)) return rc;
+            continue;
+        }
         if (int rc = launch_ppo_net(n->kind, n->md, a, s)) return rc;
         dw.njobs += build_dw_jobs(n->kind, n->md, a, n->params, n->grads, dw.job + dw.njobs);
     }
-    dw.tiles_per_wg = 16;
-    if (const char* e = std::getenv("PIME_DW_DEBUG")) dw.debug_skip = std::atoi(e);  // timing ablations only
-    if (int rc = launch_dw(dw, b->B, s)) return rc;
+    if (split) {
+        dw.tiles_per_wg = 16;
+        if (const char* e = std::getenv("PIME_DW_DEBUG")) dw.debug_skip = std::atoi(e);  // timing ablations only
+        if (int rc = launch_dw(dw, b->B, s)) return rc;
+    }
+    if (tracing && !split) {
+        long long t[64];
+        PIME_HIP_TRY(hipStreamSynchronize(s));
+        PIME_HIP_TRY(hipMemcpy(t, trace_dev, sizeof(t), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 2; ++k) {
+            std::fprintf(stderr, "[pime trace] %s:", k ? "actor " : "critic");
+            for (int i = 1; i < 32; ++i)
+                if (t[32 * k + i]) std::fprintf(stderr, " m%d=%.1f", i, (double)(t[32 * k + i] - t[32 * k]) * 0.01);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    if (!split)
+        return launch_grad_reduce(fused_args[0], fused_args[1], critic->kind, critic->md, actor->kind, actor->md,
+                                  critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, s);
     return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, s);
 }
 

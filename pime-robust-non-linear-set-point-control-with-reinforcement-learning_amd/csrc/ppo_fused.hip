@@ -1,0 +1,757 @@
+// PPO minibatch gradients, one launch per net: forward, loss gradient, backward chain AND the weight gradients of a
+// 256-sample group are formed by one 8-wave workgroup without the dZ tensors ever leaving the CU.
+//
+// replaces (reference, /root/reference/elegantrl/agent.py:629-657): minibatch gather, compute_logprob
+// (net_residual.py:48-54,182-190), clipped surrogate + entropy proxy (:637-645), CriticAdv forward + SmoothL1
+// (:648-649) and `obj_united.backward()` (:654-655) for one net.
+//
+// Why: the split design (ppo_train.hip) stashes every dZ_l and H_l in HBM (2.5-3 KB per sample and net) and re-reads
+// them in a separate TN-GEMM kernel; profiles/r01_c_pmc_hbm_traffic.json shows ~1 GB of HBM traffic per minibatch and
+// the matrix pipe 33-47 % busy, i.e. the pipeline sits on the MFMA/HBM ridge.  Here only the two hidden activations
+// the backward needs (1 KB per sample and net) round-trip through HBM/L2, and they are read back by the wave that
+// wrote them.
+//
+// Workgroup = 8 waves = 8 tiles of 32 samples.  LDS map: S (first-layer images, biases, head, the group's states),
+// W (one md x md MFMA image), X (2 x 2T transposition blocks of [32][33]; during the forward it holds the second
+// MFMA image).  Per layer l of the backward:
+//   dW_l = dZ_l^T H_{l-1}: eight rounds, round t multiplies tile t.  The owning wave writes dZ_l / H_{l-1} (sample on
+//          the lane) into X feature-major with a 33-float pitch, so all eight waves can read them back as MFMA operands
+//          with the SAMPLE index on k (conflict-free both ways); every wave owns 1/8 of the output blocks and keeps
+//          them in accumulators for the eight rounds, then adds them into the gradient tensor with float atomics.
+//          X is double buffered (one barrier per round); the next layer's transposed weight image is copied into W
+//          one slice per round, behind the MFMAs.  The bias gradient is the sum of the A operands a wave reads anyway.
+//   dH_{l-1} = W_l^T dZ_l: the forward chain code with the transposed image (mlp_device.hpp).
+// First-layer and head gradients (fan-in / fan-out of a few floats) are row reductions over the same X tiles.
+#include "ppo_device.hpp"
+#include "ppo_train.hpp"
+
+namespace pime {
+
+constexpr int kFusedThreads = 512;
+constexpr int kFusedWaves = kFusedThreads / 64;
+constexpr int kPitch = 33;              // 32 samples + 1: conflict-free for sample-major writes and k-major reads
+constexpr int kBlk = 32 * kPitch;       // one [32 features][33] block
+
+struct FusedLds {
+    int first0, first1, bias[3], headw, headb, xs, dv, red, wbuf, x, total;
+};
+
+__host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
+    FusedLds F{};
+    int o = 0;
+    auto seg = [&](int& f, int floats) { f = o; o = align4(o + floats); };
+    const int md = T * 32;
+    if (kind == MLP_MODULAR_ACTOR) {
+        const int Do = D - Di, H = T / 2;
+        seg(F.first0, md * (Do + 1));
+        seg(F.first1, md * (Di + 1));
+        seg(F.bias[0], H * 32);
+        seg(F.bias[1], H * 32);
+        seg(F.bias[2], md);
+    } else {
+        seg(F.first0, md * (D + 1));
+        F.first1 = 0;
+        seg(F.bias[0], md);
+        seg(F.bias[1], md);
+        F.bias[2] = 0;
+    }
+    seg(F.headw, md);
+    seg(F.headb, 4);
+    seg(F.xs, kFusedWaves * 32 * D);   // the group's gathered states [wave][sample][D]
+    seg(F.dv, kFusedWaves * 32);       // d(loss)/d(net output) per sample
+    seg(F.red, md * (D + 1));          // row-reduction accumulators
+    seg(F.wbuf, T * T * 1024);
+    seg(F.x, 4 * T * kBlk);
+    F.total = o;
+    return F;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global operation
+// (vmcnt(0)), i.e. for the gradient atomics of the previous job to come back from L2 - 10-15 us per job when all 256
+// workgroups flush the same tensor.  The rounds only exchange data through LDS.
+#define PIME_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Accumulator-layout tile (sample on the lane) -> feature-major rows [t*32 + feat][sample], pitch 33.
+template <int NTL>
+__device__ __forceinline__ void put_tile(float* __restrict__ dst, int lane, const f32x16 (&v)[NTL]) {
+    float* p = dst + (lane >> 5) * 4 * kPitch + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(t * 32 + (r & 3) + 8 * (r >> 2)) * kPitch] = v[t][r];
+}
+
+// Stash tiles through a wave-uniform base: one 32-bit lane offset + immediates instead of a 64-bit address per row
+// (which the compiler hoists out of the group loop and spills).
+template <int NTL>
+__device__ __forceinline__ void stash_put(float* __restrict__ base, int lane, const f32x16 (&a)[NTL]) {
+    int off = lane;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) base[(t * 16 + r) * 64 + off] = a[t][r];
+}
+template <int NTL>
+__device__ __forceinline__ void stash_get(const float* __restrict__ base, int lane, f32x16 (&a)[NTL]) {
+    int off = lane;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[t][r] = base[(t * 16 + r) * 64 + off];
+}
+
+// ---- B-operand sources: element (tile t, register r) of the accumulator-layout tile of wave `ow`, for this lane.
+// Any wave can produce any tile's element, so the eight waves share the work of publishing a tile.
+struct StashB {   // a hidden activation stashed by the forward: [wave tile][t][16][64]
+    const float* base;   // stash of the group's first tile, at the wanted activation
+    int tile_stride;     // floats between consecutive tiles
+    __device__ __forceinline__ float operator()(int ow, int t, int r, int lane) const {
+        return base[(size_t)ow * tile_stride + (t * 16 + r) * 64 + lane];
+    }
+};
+template <int ACT>
+struct FirstB {   // a first-layer activation, recomputed from the group's states in LDS (same arithmetic as layer_first)
+    const float* w0;   // FIRST image [Din+1][OT][16][2]
+    const float* xs;   // [wave][32][D]
+    int Din, D, col0, ot32;
+    __device__ __forceinline__ float operator()(int ow, int t, int r, int lane) const {
+        const float* x = xs + (ow * 32 + (lane & 31)) * D + col0;
+        const float* w = w0 + (t * 16 + r) * 2 + (lane >> 5);
+        float s = w[Din * ot32];
+        for (int j = 0; j < Din; ++j) s = fmaf(x[j], w[j * ot32], s);
+        return activate<ACT>(s);
+    }
+};
+struct StateB {   // the raw state columns [col0, col0+Din) padded with zeros to one 32-feature tile
+    const float* xs;
+    int Din, D, col0;
+    __device__ __forceinline__ float operator()(int ow, int, int r, int lane) const {
+        const int f = feat32(r, lane >> 5);
+        return f < Din ? xs[(ow * 32 + (lane & 31)) * D + col0 + f] : 0.f;
+    }
+};
+
+// Work split of a (AT x BT)-block weight gradient over the eight waves.
+template <int AT, int BT>
+struct DwPlan {
+    static constexpr int NBLK = AT * BT;
+    static constexpr int PER = NBLK >= kFusedWaves ? NBLK / kFusedWaves : 1;       // output blocks per wave
+    static constexpr int NKS = 16;
+    static_assert(BT % PER == 0, "a wave's blocks must share the A tile");
+    int ao, bi0;
+    bool active;  // with fewer blocks than waves the spare waves only help publishing (every output element has ONE
+                  // owner lane, so the partial gradients can be plain stores)
+    __device__ __forceinline__ explicit DwPlan(int wave) {
+        const int b0 = wave * PER;
+        active = b0 < NBLK;
+        ao = active ? b0 / BT : 0; bi0 = active ? b0 % BT : 0;
+    }
+};
+
+// acc[n] (+)= sum over the group's 256 samples of A[s][a-block ao] (x) B[s][b-block bi0+n];  bsum = sum_s A[s][ao*32 + li]
+// (this lane's k parity).  az: this wave's A tile (AT feature tiles, accumulator layout), published by the wave
+// itself; the B tile of every round is produced by all eight waves (BT*2 elements per lane each, fetched two rounds
+// ahead).  While the rounds run, stage_n4 float4s are copied from stage_src into LDS at stage_dst.
+template <int AT, int BT, class BSrc>
+__device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int wave, const f32x16 (&az)[AT],
+                                          const BSrc& bsrc, f32x16 (&acc)[DwPlan<AT, BT>::PER], float& bsum,
+                                          float* __restrict__ stage_dst, const float* __restrict__ stage_src,
+                                          int stage_n4, long long* tr = nullptr) {
+    using Plan = DwPlan<AT, BT>;
+    constexpr int PER = Plan::PER, NKS = Plan::NKS;
+    constexpr int BUF = (AT + BT) * kBlk;
+    constexpr int NP = BT * 16 / kFusedWaves;                               // B elements this wave publishes per round
+    const Plan pl(wave);
+    const int tid = wave * 64 + lane, h = lane >> 5, li = lane & 31;
+    const int pt = (wave * NP) / 16, pr0 = (wave * NP) % 16;                // published elements: tile pt, regs pr0..pr0+NP
+#pragma unroll
+    for (int n = 0; n < PER; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    bsum = 0.f;
+    const int per4 = stage_n4 / kFusedWaves;
+    const float4* src4 = reinterpret_cast<const float4*>(stage_src);
+    float4* dst4 = reinterpret_cast<float4*>(stage_dst);
+    float pv[NP], pv2[NP];
+    auto b_fetch = [&](int ow, float (&v)[NP]) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) v[i] = bsrc(ow, pt, pr0 + i, lane);
+    };
+    auto b_publish = [&](float* buf) {
+        float* p = buf + AT * kBlk + (pt * 32 + 4 * h) * kPitch + li;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) p[(((pr0 + i) & 3) + 8 * ((pr0 + i) >> 2)) * kPitch] = pv[i];
+    };
+
+    PIME_LDS_BARRIER();  // X free
+    b_fetch(0, pv);
+    if (wave == 0) put_tile<AT>(X, lane, az);
+    b_publish(X);
+    b_fetch(1, pv);
+#pragma unroll 1
+    for (int t = 0; t < kFusedWaves; ++t) {
+        PIME_LDS_BARRIER();  // buffer t&1 published; buffer (t+1)&1 no longer read
+        if (tr && tid == 0) tr[t] = wall_clock64();
+        const float* cur = X + (t & 1) * BUF;
+        float* nxt = X + ((t + 1) & 1) * BUF;
+        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < per4) sv = src4[t * per4 + tid];
+        if (t + 2 < kFusedWaves) b_fetch(t + 2, pv2);       // two rounds ahead: a whole round to land
+        if (wave == t + 1) put_tile<AT>(nxt, lane, az);
+        PIME_NO_HOIST();
+        if (pl.active) {
+            const float* Ap = cur + (pl.ao * 32 + li) * kPitch + h;
+            const float* Bp = cur + AT * kBlk + (pl.bi0 * 32 + li) * kPitch + h;
+            float av[NKS], bv[PER][NKS];
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                av[s] = Ap[2 * s];
+#pragma unroll
+                for (int n = 0; n < PER; ++n) bv[n][s] = Bp[n * kBlk + 2 * s];
+            }
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+#pragma unroll
+                for (int n = 0; n < PER; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[n][s], acc[n], 0, 0, 0);
+                bsum += av[s];
+            }
+        }
+        PIME_NO_HOIST();
+        if (t + 1 < kFusedWaves) b_publish(nxt);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pv[i] = pv2[i];
+        if (tid < per4) dst4[t * per4 + tid] = sv;
+    }
+    if (tr && tid == 0) tr[8] = wall_clock64();
+}
+
+// Element offset of accumulator register 0 of a wave's first output block (D[i = a feature][j = b feature]: column on
+// the lane, rows in the registers).  Made opaque: otherwise every row address of every job is hoisted to the kernel
+// prologue as a 64-bit pointer and spilled.
+template <int AT, int BT>
+__device__ __forceinline__ int dw_base(int lane, int wave, int ldw) {
+    const DwPlan<AT, BT> pl(wave);
+    int base = (pl.ao * 32 + 4 * (lane >> 5)) * ldw + pl.bi0 * 32 + (lane & 31);
+    asm volatile("" : "+v"(base));
+    return base;
+}
+
+// Writes a finished job into the workgroup's gradient slab (plain stores: every element has one owner lane).  Rows >=
+// nrows and columns >= ncols of the product are dropped; accum: add to what an earlier sample group of this workgroup
+// stored.  gb: slab position of the bias gradient (sum of the A operands).
+template <int AT, int BT>
+__device__ __forceinline__ void dw_store(int lane, int wave, const f32x16 (&acc)[DwPlan<AT, BT>::PER], float bsum,
+                                         float* __restrict__ gW, int ldw, int nrows, int ncols, float* __restrict__ gb,
+                                         bool accum) {
+    const DwPlan<AT, BT> pl(wave);
+    if (!pl.active) return;
+    const int h = lane >> 5, li = lane & 31;
+    const int base = dw_base<AT, BT>(lane, wave, ldw);
+#pragma unroll
+    for (int n = 0; n < DwPlan<AT, BT>::PER; ++n)
+        if ((pl.bi0 + n) * 32 + li < ncols) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (pl.ao * 32 + feat32(r, h) < nrows) {
+                    float* q = &gW[base + n * 32 + ((r & 3) + 8 * (r >> 2)) * ldw];
+                    *q = accum ? *q + acc[n][r] : acc[n][r];
+                }
+        }
+    bsum += __shfl_xor(bsum, 32);  // the two k parities
+    if (gb && pl.bi0 == 0 && h == 0) {
+        float* q = &gb[pl.ao * 32 + li];
+        *q = accum ? *q + bsum : bsum;
+    }
+}
+
+// Sum of v over the 32 lanes of this lane's half; valid in lanes 31 and 63.
+__device__ __forceinline__ float half_sum_dpp(float v) {
+#define PIME_DPP_ADD(x, ctrl, row_mask) \
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, row_mask, 0xf, true))
+    PIME_DPP_ADD(v, 0x111, 0xf);  // row_shr:1
+    PIME_DPP_ADD(v, 0x112, 0xf);  // row_shr:2
+    PIME_DPP_ADD(v, 0x114, 0xf);  // row_shr:4
+    PIME_DPP_ADD(v, 0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds the row sum
+    PIME_DPP_ADD(v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the half sums
+#undef PIME_DPP_ADD
+    return v;
+}
+
+#define PIME_MARK(i)                                                             \
+    do {                                                                         \
+        if (a.trace && blockIdx.x == a.trace_wg && threadIdx.x == 0) a.trace[i] = wall_clock64(); \
+    } while (0)
+
+template <int T, int KIND>
+__global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool MODULAR = KIND == MLP_MODULAR_ACTOR;
+    constexpr bool CRITIC = KIND == MLP_CRITIC;
+    constexpr int ACT = CRITIC ? 0 : 1;
+    constexpr int H = T / 2 > 0 ? T / 2 : 1;
+    constexpr int md = T * 32;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = (a.B + 31) / 32, ngroups = (ntiles + kFusedWaves - 1) / kFusedWaves;
+    const float invB = 1.0f / (float)a.B;
+    const FusedLds F = fused_lds(KIND, a.D, a.Di, T);
+    const MlpLayout L = mlp_layout(KIND, a.D, a.Di, md);
+    const BwdLayout Lb = bwd_layout(KIND, a.D, a.Di, md);
+    float* const wbuf = lds + F.wbuf;
+    float* const X = lds + F.x;
+    float* const xs = lds + F.xs;
+    float* const hacc = lds + F.red;   // head weight gradient of the workgroup
+    const int Do = a.D - a.Di;
+
+    PIME_MARK(0);
+    for (int e = tid; e < md; e += kFusedThreads) hacc[e] = 0.f;
+    // small segments live in LDS for the whole kernel
+    if constexpr (MODULAR) {
+        stage_image(lds + F.first0, a.img_fwd + L.off[0], md * (Do + 1) / 4);
+        stage_image(lds + F.first1, a.img_fwd + L.off[3], md * (a.Di + 1) / 4);
+        stage_image(lds + F.bias[0], a.img_fwd + L.off[2], H * 32 / 4);
+        stage_image(lds + F.bias[1], a.img_fwd + L.off[5], H * 32 / 4);
+        stage_image(lds + F.bias[2], a.img_fwd + L.off[7], md / 4);
+        stage_image(lds + F.headw, a.img_fwd + L.off[8], md / 4);
+        stage_image(lds + F.headb, a.img_fwd + L.off[9], 1);
+    } else {
+        stage_image(lds + F.first0, a.img_fwd + L.off[0], md * (a.D + 1) / 4);
+        stage_image(lds + F.bias[0], a.img_fwd + L.off[2], md / 4);
+        stage_image(lds + F.bias[1], a.img_fwd + L.off[4], md / 4);
+        stage_image(lds + F.headw, a.img_fwd + L.off[5], md / 4);
+        stage_image(lds + F.headb, a.img_fwd + L.off[6], 1);
+    }
+    float s0 = 0.f, s1 = 0.f, gstd = 0.f, ghb = 0.f;
+    double m1 = 0.0, m2 = 0.0;
+
+#pragma unroll 1
+    for (int group = blockIdx.x; group < ngroups; group += gridDim.x) {
+        // Lane-derived offsets are made loop-variant on purpose: hipcc otherwise hoists ~100 per-lane LDS / global
+        // offsets of the whole body out of this (usually single-trip) loop and spills them.
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        const int h = lane >> 5, li = lane & 31;
+        __syncthreads();  // the previous group's backward is done with W / X
+        if constexpr (MODULAR) {
+            stage_image(wbuf, a.img_fwd + L.off[6], T * T * 256);
+            stage_image(X, a.img_fwd + L.off[1], T * H * 256);
+            stage_image(X + T * H * 1024, a.img_fwd + L.off[4], T * H * 256);
+        } else {
+            stage_image(wbuf, a.img_fwd + L.off[1], T * T * 256);
+            stage_image(X, a.img_fwd + L.off[3], T * T * 256);
+        }
+        const int tile = group * kFusedWaves + wave;  // tiles past the batch run on clamped rows with dOut = 0
+        const int pos = tile * 32 + li;
+        const bool valid = pos < a.B;
+        const long long row = a.indices[valid ? pos : a.B - 1];
+        const float* xrow = a.state + (size_t)row * a.D;
+        float* st = a.stash + (size_t)tile * T * 1024;
+        const float* st0 = a.stash + (size_t)group * kFusedWaves * T * 1024;  // the group's first tile
+        const float in_rsum = CRITIC ? a.r_sum[row] : 0.f;
+        const float in_action = CRITIC ? 0.f : a.action[row];
+        const float in_logprob = CRITIC ? 0.f : a.logprob[row];
+        const float in_adv = CRITIC ? 0.f : a.adv[row];
+        if (h == 0)
+            for (int c = 0; c < a.D; ++c) xs[(wave * 32 + li) * a.D + c] = xrow[c];
+        __syncthreads();
+        PIME_MARK(1);
+
+        // ---------------------------------------------------------------------------------- forward + loss gradient
+        float y;
+        f32x16 hl[T];  // last hidden activation; afterwards dZ of the last hidden layer
+        if constexpr (MODULAR) {
+            f32x16 cat[T];
+            {
+                f32x16 a0[T];
+                layer_first<T, 1>(lds + F.first0, xrow, Do, h, a0);
+                PIME_NO_HOIST();
+                layer_mfma<T, H, 1>(X, lds + F.bias[0], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
+            }
+            {
+                f32x16 a0[T];
+                PIME_NO_HOIST();
+                layer_first<T, 1>(lds + F.first1, xrow + Do, a.Di, h, a0);
+                PIME_NO_HOIST();
+                layer_mfma<T, H, 1>(X + T * H * 1024, lds + F.bias[1], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
+            }
+            stash_put<T>(st, lane, cat);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 1>(wbuf, lds + F.bias[2], lane, cat, hl);
+            PIME_NO_HOIST();
+            y = layer_head<T>(lds + F.headw, lds[F.headb], lane, hl);
+        } else {
+            f32x16 a1[T];
+            {
+                f32x16 a0[T];
+                layer_first<T, ACT>(lds + F.first0, xrow, a.D, h, a0);
+                PIME_NO_HOIST();
+                layer_mfma<T, T, ACT>(wbuf, lds + F.bias[0], lane, a0, a1);
+            }
+            stash_put<T>(st, lane, a1);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, ACT>(X, lds + F.bias[1], lane, a1, hl);
+            PIME_NO_HOIST();
+            y = layer_head<T>(lds + F.headw, lds[F.headb], lane, hl);
+        }
+        PIME_MARK(2);
+        float dout = 0.f;
+        if (valid) {
+            if constexpr (CRITIC) {
+                const float d = y - in_rsum, ad = fabsf(d);         // SmoothL1, beta = 1 (agent.py:567,649)
+                const float l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+                const float g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+                dout = g * invB;  // unscaled: critic_scale_kernel applies 1/(std+1e-5) to the finished gradients
+                if (h == 0) {
+                    s0 += l;
+                    m1 += (double)in_rsum;
+                    m2 += (double)in_rsum * (double)in_rsum;
+                }
+            } else {
+                const float asl = a.a_std_log[0], inv_sigma = __expf(-asl);
+                const float z = (y - in_action) * inv_sigma;
+                const float logp = -(asl + kLogSqrt2Pi + 0.5f * z * z);           // compute_logprob
+                const float ratio = __expf(logp - in_logprob);
+                const float lo = 1.f - a.ratio_clip, hi = 1.f + a.ratio_clip;
+                const float clamped = fminf(fmaxf(ratio, lo), hi);
+                const float adv = in_adv;
+                const float u = adv * ratio, c = adv * clamped;                   // agent.py:639-641
+                const float w_u = u < c ? 1.f : (u == c ? 0.5f : 0.f);            // torch.min backward (ties split)
+                const float w_c = c < u ? 1.f : (u == c ? 0.5f : 0.f);
+                const bool in_range = ratio >= lo && ratio <= hi;
+                const float g_sur = w_u * u + (in_range ? w_c * u : 0.f);
+                const float p = __expf(logp);
+                const float ent = p * logp;                                       // entropy proxy (:643)
+                const float g_logp = (-g_sur + a.lambda_entropy * p * (logp + 1.f)) * invB;
+                dout = g_logp * (-z * inv_sigma);
+                if (h == 0) {
+                    gstd += g_logp * (z * z - 1.f);
+                    s0 += -fminf(u, c);
+                    s1 += ent;
+                }
+            }
+        }
+        if (h == 0) ghb += dout;  // head bias gradient
+        // Head: dZ of the last hidden layer, and the head weight gradient gW[f] += sum_s dOut[s] * H_last[s][f].  H_last
+        // is still in registers; the sum over the tile's samples is a DPP reduction over the lanes.
+        {
+            f32x16 dl[T];
+            head_backward<T>(lds + F.headw, lane, dout, dl);
+            times_act_grad<T, ACT>(dl, hl);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hl[t][r] = half_sum_dpp(dout * hl[t][r]);
+            if (li == 31) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) atomicAdd(&hacc[t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h], hl[t][r]);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) hl[t] = dl[t];
+        }
+        // ---------------------------------------------------------------------------------- backward + weight gradients
+        __syncthreads();  // forward images dead, stash visible to the whole workgroup
+        PIME_MARK(3);
+        float* const sl = a.slab + (size_t)blockIdx.x * a.slab_stride;   // this workgroup's partial gradients
+        const bool accum = group != (int)blockIdx.x;                      // a later sample group of the same workgroup
+        if constexpr (MODULAR) {
+            f32x16(&dn0)[T] = hl;                                                                   // dZn0
+            f32x16 dcat[T];
+            PIME_MARK(4);
+            {
+                f32x16 acc[DwPlan<T, T>::PER];
+                float bsum;
+                PIME_NO_HOIST();
+                dw_rounds<T, T>(X, lane, wave, dn0, StashB{st0, T * 1024}, acc, bsum, wbuf, a.img_bwd + Lb.off[3],
+                                T * T * 256, (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
+                dw_store<T, T>(lane, wave, acc, bsum, sl + a.poff[8], md, md, md, sl + a.poff[9], accum);   // net.0
+            }
+            PIME_LDS_BARRIER();
+            PIME_MARK(5);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 2, false>(wbuf, nullptr, lane, dn0, dcat);
+            {
+                f32x16 cat[T];
+                stash_get<T>(st, lane, cat);
+                times_act_grad<T, 1>(dcat, cat);                                                    // [dZo2 | dZi2]
+            }
+            PIME_MARK(6);
+            {
+                f32x16 acc[DwPlan<H, T>::PER];
+                float bsum;
+                PIME_NO_HOIST();
+                dw_rounds<H, T>(X, lane, wave, *reinterpret_cast<f32x16(*)[H]>(&dcat[0]),
+                                FirstB<1>{lds + F.first0, xs, Do, a.D, 0, md}, acc, bsum, wbuf, a.img_bwd + Lb.off[4],
+                                2 * H * T * 256);                                                   // (+ both images)
+                dw_store<H, T>(lane, wave, acc, bsum, sl + a.poff[2], md, H * 32, md, sl + a.poff[3], accum);  // other_net.2
+                PIME_MARK(7);
+                PIME_NO_HOIST();
+                dw_rounds<H, T>(X, lane, wave, *reinterpret_cast<f32x16(*)[H]>(&dcat[H]),
+                                FirstB<1>{lds + F.first1, xs, a.Di, a.D, Do, md}, acc, bsum, nullptr, nullptr, 0);
+                dw_store<H, T>(lane, wave, acc, bsum, sl + a.poff[6], md, H * 32, md, sl + a.poff[7], accum);  // integrator_net.2
+            }
+            PIME_LDS_BARRIER();
+            PIME_MARK(8);
+            {
+                f32x16 d1[T], h1[T];
+                PIME_NO_HOIST();
+                layer_mfma<H, T, 2, false>(wbuf, nullptr, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[0]), d1);
+                PIME_NO_HOIST();
+                layer_first<T, 1>(lds + F.first0, xrow, Do, h, h1);
+                times_act_grad<T, 1>(d1, h1);                                                       // dZo1
+                PIME_MARK(9);
+                f32x16 acc[DwPlan<T, 1>::PER];
+                float bsum;
+                dw_rounds<T, 1>(X, lane, wave, d1, StateB{xs, Do, a.D, 0}, acc, bsum, nullptr, nullptr, 0);
+                dw_store<T, 1>(lane, wave, acc, bsum, sl + a.poff[0], Do, md, Do, sl + a.poff[1], accum);     // other_net.0
+                PIME_MARK(10);
+            }
+            {
+                f32x16 d1[T], h1[T];
+                PIME_NO_HOIST();
+                layer_mfma<H, T, 2, false>(wbuf + H * T * 1024, nullptr, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[H]), d1);
+                PIME_NO_HOIST();
+                layer_first<T, 1>(lds + F.first1, xrow + Do, a.Di, h, h1);
+                times_act_grad<T, 1>(d1, h1);                                                       // dZi1
+                PIME_MARK(11);
+                f32x16 acc[DwPlan<T, 1>::PER];
+                float bsum;
+                dw_rounds<T, 1>(X, lane, wave, d1, StateB{xs, a.Di, a.D, Do}, acc, bsum, nullptr, nullptr, 0);
+                dw_store<T, 1>(lane, wave, acc, bsum, sl + a.poff[4], a.Di, md, a.Di, sl + a.poff[5], accum); // integrator_net.0
+            }
+        } else {
+            f32x16(&d)[T] = hl;                                                                     // dZ3
+            f32x16 d2[T];
+            PIME_MARK(4);
+            {
+                f32x16 acc[DwPlan<T, T>::PER];
+                float bsum;
+                PIME_NO_HOIST();
+                dw_rounds<T, T>(X, lane, wave, d, StashB{st0, T * 1024}, acc, bsum, wbuf, a.img_bwd + Lb.off[2],
+                                T * T * 256, (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
+                dw_store<T, T>(lane, wave, acc, bsum, sl + a.poff[4], md, md, md, sl + a.poff[5], accum);      // net.4
+            }
+            PIME_LDS_BARRIER();
+            PIME_MARK(5);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 2, false>(wbuf, nullptr, lane, d, d2);
+            {
+                f32x16 hh[T];
+                stash_get<T>(st, lane, hh);                                                        // H2
+                times_act_grad<T, ACT>(d2, hh);                                                     // dZ2
+            }
+            PIME_MARK(6);
+            {
+                f32x16 acc[DwPlan<T, T>::PER];
+                float bsum;
+                PIME_NO_HOIST();
+                dw_rounds<T, T>(X, lane, wave, d2, FirstB<ACT>{lds + F.first0, xs, a.D, a.D, 0, md}, acc, bsum, wbuf,
+                                a.img_bwd + Lb.off[3], T * T * 256);
+                dw_store<T, T>(lane, wave, acc, bsum, sl + a.poff[2], md, md, md, sl + a.poff[3], accum);      // net.2
+            }
+            PIME_LDS_BARRIER();
+            PIME_MARK(7);
+            PIME_NO_HOIST();
+            layer_mfma<T, T, 2, false>(wbuf, nullptr, lane, d2, d);
+            {
+                f32x16 hh[T];
+                PIME_NO_HOIST();
+                layer_first<T, ACT>(lds + F.first0, xrow, a.D, h, hh);                              // H1 again
+                times_act_grad<T, ACT>(d, hh);                                                      // dZ1
+            }
+            PIME_MARK(8);
+            f32x16 acc[DwPlan<T, 1>::PER];
+            float bsum;
+            dw_rounds<T, 1>(X, lane, wave, d, StateB{xs, a.D, a.D, 0}, acc, bsum, nullptr, nullptr, 0);
+            dw_store<T, 1>(lane, wave, acc, bsum, sl + a.poff[0], a.D, md, a.D, sl + a.poff[1], accum);        // net.0
+        }
+    }
+
+    PIME_MARK(12);
+    // ---- workgroup totals of the scalar sums, combined in a fixed order (the slabs make the gradients reproducible
+    // bit for bit; only the loss sums, which are for logging, use atomics)
+    s0 = wave_sum(s0); s1 = wave_sum(s1); gstd = wave_sum(gstd); ghb = wave_sum(ghb);
+    if constexpr (CRITIC) {
+        for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+    }
+    double* const wsum = reinterpret_cast<double*>(X);  // [wave][6]
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        double* w = wsum + wave * 6;
+        w[0] = s0; w[1] = s1; w[2] = gstd; w[3] = ghb; w[4] = m1; w[5] = m2;
+    }
+    __syncthreads();
+    float* const sl = a.slab + (size_t)blockIdx.x * a.slab_stride;
+    constexpr int NP = MODULAR ? 12 : 8;
+    if (tid < md) sl[a.poff[NP - 2] + tid] = hacc[tid];   // head weight
+    if (tid == 0) {
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < kFusedWaves; ++w)
+            for (int k = 0; k < 6; ++k) t[k] += wsum[w * 6 + k];
+        sl[a.poff[NP - 1]] = (float)t[3];                 // head bias
+        if constexpr (CRITIC) {
+            atomicAdd(&a.loss_sums[2], (float)t[0]);
+            double* mo = reinterpret_cast<double*>(sl + a.poff[NP]);
+            mo[0] = t[4]; mo[1] = t[5];
+        } else {
+            atomicAdd(&a.loss_sums[0], (float)t[0]);
+            atomicAdd(&a.loss_sums[1], (float)t[1]);
+            sl[a.poff[NP]] = (float)t[2];                 // d loss / d a_std_log
+        }
+    }
+}
+
+// ==================================================================================================== slab reduction
+// grad[e] += scale * sum over the workgroups' slabs, in slab order (reproducible), for both nets in one launch.  The
+// critic's scale 1/(std(targets)+1e-5) (agent.py:652) comes from the float64 target moments the critic kernel left in
+// its slabs.  Workgroup = 64 consecutive float4 of one parameter; wave w sums slabs w, w+8, ...; LDS combines the waves.
+struct ReduceSeg {
+    float* dst;
+    int off, n, net;   // slab offset (floats), element count, 0 = critic / 1 = actor
+};
+struct ReduceArgs {
+    ReduceSeg seg[24];
+    int nseg, nslabs, B, moments_off;
+    const float* slab[2];
+    int stride[2];
+    float* scale_out;
+    double* moments_out;
+};
+
+__global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
+    __shared__ float4 part[8][64];
+    __shared__ float scale_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // which segment / chunk
+    int c = blockIdx.x, si = 0;
+    for (; si < a.nseg; ++si) {
+        const int chunks = ((a.seg[si].n + 3) / 4 + 63) / 64;
+        if (c < chunks) break;
+        c -= chunks;
+    }
+    if (si >= a.nseg) return;
+    const ReduceSeg sg = a.seg[si];
+    if (wave == 0) {  // critic scale from the moments (every workgroup: same slabs, same order, same value)
+        double m1 = 0.0, m2 = 0.0;
+        for (int s = lane; s < a.nslabs; s += 64) {
+            const double* mo = reinterpret_cast<const double*>(a.slab[0] + (size_t)s * a.stride[0] + a.moments_off);
+            m1 += mo[0]; m2 += mo[1];
+        }
+        for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+        const double B = (double)a.B;
+        const double var = a.B > 1 ? fmax((m2 - m1 * m1 / B) / (B - 1.0), 0.0) : 0.0;
+        const float scale = (float)(1.0 / ((double)(float)sqrt(var) + 1e-5));
+        if (lane == 0) {
+            scale_sh = scale;
+            if (blockIdx.x == 0) { a.scale_out[0] = scale; a.moments_out[0] = m1; a.moments_out[1] = m2; }
+        }
+    }
+    const int unit = c * 64 + lane, n4 = (sg.n + 3) / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (unit < n4) {
+        const float* base = a.slab[sg.net] + sg.off + unit * 4;
+        const size_t stride = (size_t)a.stride[sg.net];
+        int s = wave;
+        for (; s + 24 < a.nslabs; s += 32) {   // four loads in flight
+            const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
+            const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(s + 8) * stride);
+            const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(s + 16) * stride);
+            const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(s + 24) * stride);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        }
+        for (; s < a.nslabs; s += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && unit < n4) {
+        float4 t = part[0][lane];
+        for (int w = 1; w < 8; ++w) { const float4 v = part[w][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        const float sc = sg.net == 0 ? scale_sh : 1.0f;
+        const float o[4] = {t.x * sc, t.y * sc, t.z * sc, t.w * sc};
+        for (int k = 0; k < 4; ++k)
+            if (unit * 4 + k < sg.n) sg.dst[unit * 4 + k] += o[k];
+    }
+}
+
+int fused_grid(int B) {
+    const int ntiles = (B + 31) / 32;
+    int grid = (ntiles + kFusedWaves - 1) / kFusedWaves;
+    return grid > 256 ? 256 : grid;
+}
+
+int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
+                       float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
+                       double* moments_out, hipStream_t s) {
+    ReduceArgs r{};
+    int poff[13], psize[12], chunks = 0;
+    auto add = [&](float* dst, int off, int n, int net) {
+        r.seg[r.nseg++] = ReduceSeg{dst, off, n, net};
+        chunks += ((n + 3) / 4 + 63) / 64;
+    };
+    const int np_c = 8;
+    slab_layout(kind_c, critic.D, critic.Di, md_c, poff, psize);
+    for (int i = 0; i < np_c; ++i) add(grads_c[i], poff[i], psize[i], 0);
+    r.moments_off = poff[np_c];
+    const int np_a = kind_a == MLP_MODULAR_ACTOR ? 12 : 8;
+    slab_layout(kind_a, actor.D, actor.Di, md_a, poff, psize);
+    for (int i = 0; i < np_a; ++i) add(grads_a[i], poff[i], psize[i], 1);
+    add(g_std, poff[np_a], 1, 1);
+    r.nslabs = fused_grid(critic.B); r.B = critic.B;
+    r.slab[0] = critic.slab; r.slab[1] = actor.slab;
+    r.stride[0] = critic.slab_stride; r.stride[1] = actor.slab_stride;
+    r.scale_out = scale_out; r.moments_out = moments_out;
+    hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3(chunks), dim3(512), 0, s, r);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+// Floats of workspace the fused kernel needs: activation stash (one hidden activation per sample) + gradient slabs.
+int64_t fused_stash_floats(int B, int md) {
+    const int64_t ngroups = ((B + 31) / 32 + kFusedWaves - 1) / kFusedWaves;
+    return ngroups * kFusedWaves * (md / 32) * 1024;
+}
+int64_t fused_workspace_floats(int kind, int B, int D, int Di, int md) {
+    int poff[13], psize[12];
+    return fused_stash_floats(B, md) + (int64_t)fused_grid(B) * slab_layout(kind, D, Di, md, poff, psize);
+}
+
+template <int T, int KIND>
+static int launch_fused(const PpoArgs& a, hipStream_t s) {
+    const FusedLds F = fused_lds(KIND, a.D, a.Di, T);
+    const size_t lds_bytes = sizeof(float) * (size_t)F.total;
+    PIME_REQUIRE(lds_bytes <= 160 * 1024, "fused PPO kernel needs %zu B of LDS (> 160 KB) for state_dim %d", lds_bytes, a.D);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_fused_kernel<T, KIND>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int grid = fused_grid(a.B);
+    hipLaunchKernelGGL((ppo_fused_kernel<T, KIND>), dim3(grid), dim3(kFusedThreads), lds_bytes, s, a);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+int launch_ppo_fused(int kind, int md, const PpoArgs& a, hipStream_t s) {
+    const int T = md / 32;
+#define PIME_NET(TT, KK) \
+    if (T == TT && kind == KK) return launch_fused<TT, KK>(a, s);
+    PIME_NET(2, MLP_CRITIC) PIME_NET(4, MLP_CRITIC)
+    PIME_NET(2, MLP_PLAIN_ACTOR) PIME_NET(4, MLP_PLAIN_ACTOR)
+    PIME_NET(2, MLP_MODULAR_ACTOR) PIME_NET(4, MLP_MODULAR_ACTOR)
+#undef PIME_NET
+    set_error("no fused PPO instantiation for kind %d width %d", kind, md);
+    return PIME_ERR_ARG;
+}
+
+}  // namespace pime

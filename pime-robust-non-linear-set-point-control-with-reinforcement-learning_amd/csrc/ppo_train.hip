@@ -17,41 +17,11 @@
 //     the MFMA operands need feature-on-lane, so each 32x32 tile is transposed through a 33-float-pitch LDS image
 //     (conflict-free both ways).  First-layer activations are recomputed from the 3-float state instead of stashed.
 //     Partial products are combined with float atomics into the (zeroed) gradient tensors.
-#include "mlp_device.hpp"
+#include "ppo_device.hpp"
 #include "ppo_train.hpp"
 
 namespace pime {
 
-constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
-
-// ---- backward image ------------------------------------------------------------------------------------------------
-struct BwdLayout {
-    int T, off[8], total;
-};
-
-__host__ __device__ inline BwdLayout bwd_layout(int kind, int D, int Di, int md) {
-    BwdLayout L{};
-    const int T = md / 32;
-    L.T = T;
-    int o = 0;
-    auto seg = [&](int idx, int floats) { L.off[idx] = o; o = align4(o + floats); };
-    if (kind == MLP_MODULAR_ACTOR) {
-        const int Do = D - Di, H = T / 2;
-        seg(0, T * 32 * (Do + 1));   // other_net.0 (FIRST, recomputed for act')
-        seg(1, T * 32 * (Di + 1));   // integrator_net.0 (FIRST)
-        seg(2, T * 32);              // net.2 weights (head, VEC)
-        seg(3, T * 16 * 64 * T);     // net.0 transposed: dZn0 (T tiles) -> dcat (T tiles)
-        seg(4, H * 16 * 64 * T);     // other_net.2 transposed: dZo2 (H tiles) -> dh_o1 (T tiles)
-        seg(5, H * 16 * 64 * T);     // integrator_net.2 transposed
-    } else {
-        seg(0, T * 32 * (D + 1));    // net.0 (FIRST)
-        seg(1, T * 32);              // net.6 weights (head, VEC)
-        seg(2, T * 16 * 64 * T);     // net.4 transposed: dZ3 -> dH2
-        seg(3, T * 16 * 64 * T);     // net.2 transposed: dZ2 -> dH1
-    }
-    L.total = o;
-    return L;
-}
 
 struct PackBwdArgs {
     const float* p[12];
@@ -77,56 +47,6 @@ __global__ void mlp_pack_bwd_kernel(PackBwdArgs a, float* __restrict__ out) {
     }
 }
 
-// ---- workspace ------------------------------------------------------------------------------------------------------
-// stash[(tile * NT + t) * 1024 + r * 64 + lane]: register r of lane `lane` of stashed tile t of sample-tile `tile`.
-// critic / plain actor, NT = 5T:  H2 [0,T)  H3 [T,2T)  dZ3 [2T,3T)  dZ2 [3T,4T)  dZ1 [4T,5T)
-// modular actor,        NT = 6T:  cat [0,T) n0 [T,2T)  dZn0 [2T,3T) dZcat [3T,4T) dZo1 [4T,5T) dZi1 [5T,6T)
-__host__ __device__ inline int stash_tiles(int kind, int T) { return kind == MLP_MODULAR_ACTOR ? 6 * T : 5 * T; }
-
-template <int NTL>
-__device__ __forceinline__ void stash_store(float* __restrict__ base, int lane, const f32x16 (&a)[NTL]) {
-#pragma unroll
-    for (int t = 0; t < NTL; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) base[(t * 16 + r) * 64 + lane] = a[t][r];
-}
-template <int NTL>
-__device__ __forceinline__ void stash_load(const float* __restrict__ base, int lane, f32x16 (&a)[NTL]) {
-#pragma unroll
-    for (int t = 0; t < NTL; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[t][r] = base[(t * 16 + r) * 64 + lane];
-}
-
-template <int ACT>
-__device__ __forceinline__ float act_grad_from_output(float h) {
-    if constexpr (ACT == 0) return h > 0.f ? 1.f : 0.f;  // ReLU'
-    else return 1.f - h * h;                              // tanh'
-}
-
-template <int NTL, int ACT>
-__device__ __forceinline__ void times_act_grad(f32x16 (&d)[NTL], const f32x16 (&h)[NTL]) {
-#pragma unroll
-    for (int t = 0; t < NTL; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d[t][r] *= act_grad_from_output<ACT>(h[t][r]);
-}
-
-// dH_L = w_head (x) dOut in accumulator layout
-template <int NTL>
-__device__ __forceinline__ void head_backward(const float* __restrict__ w, int lane, float dout, f32x16 (&d)[NTL]) {
-    const int h = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < NTL; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d[t][r] = w[(t * 16 + r) * 2 + h] * dout;
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 
 constexpr int kTrainThreads = 512;
 
@@ -568,9 +488,13 @@ int mlp_check(int kind, int D, int Di, int md);
 
 int64_t ppo_bwd_image_floats(int kind, int D, int Di, int md) { return bwd_layout(kind, D, Di, md).total; }
 
+int64_t fused_workspace_floats(int kind, int B, int D, int Di, int md);
+
 int64_t ppo_workspace_floats(int kind, int B, int md) {
-    const int64_t ntiles = (B + 31) / 32;
-    return ntiles * stash_tiles(kind, md / 32) * 1024 + ntiles * 32 + ntiles * 32 * kMaxObsDim;
+    const int64_t ntiles = ((B + 31) / 32 + 7) / 8 * 8;
+    const int64_t split = ntiles * stash_tiles(kind, md / 32) * 1024 + ntiles * 32 + ntiles * 32 * kMaxObsDim;
+    const int64_t fused = fused_workspace_floats(kind, B, kMaxObsDim, 1, md);  // slab size bound: widest state
+    return split > fused ? split : fused;
 }
 
 int launch_pack_bwd(int kind, int D, int Di, int md, const float* const* params, float* out, hipStream_t s) {

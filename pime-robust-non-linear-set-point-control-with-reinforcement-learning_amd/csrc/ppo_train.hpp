@@ -16,6 +16,11 @@ struct PpoArgs {
     float* loss_sums;  // [4]: sum(-surrogate), sum(entropy proxy), sum(smooth-l1), unused
     float* g_std;      // actor: gradient of a_std_log (accumulated)
     int stagger;       // start delay of waves 4-7 in units of s_sleep(127) (8128 cycles)
+    int trace_wg;      // workgroup whose marks are recorded
+    long long* trace;  // tuning aid (PIME_FUSED_TRACE): wall-clock marks of workgroup 0 / wave 0, NULL in production
+    float* grad[12];   // split pipeline: gradient tensors in nn.Linear (W, b) order, accumulated with atomics
+    float* slab;       // fused kernel: per-workgroup partial gradients [gridDim.x][slab_stride] (slab_layout order)
+    int slab_stride, poff[13];  // float offsets of the params inside a slab; poff[np] = scalar slot (g_std / moments)
 };
 
 struct DwJob {
@@ -32,6 +37,25 @@ struct DwJob {
     const float* xg;       // [tiles*32][D] gathered minibatch states (written by the net kernel)
     int D, B;
 };
+
+// Slab layout of one net: every parameter padded to a multiple of 4 floats, then a 4-float scalar slot
+// (actor: d loss / d a_std_log; critic: the two float64 target moments).  Returns the stride (floats).
+inline int slab_layout(int kind, int D, int Di, int md, int* poff, int* psize) {
+    int np;
+    if (kind == 2) {
+        const int Do = D - Di, s[12] = {md * Do, md, (md / 2) * md, md / 2, md * Di, md, (md / 2) * md, md / 2, md * md, md, md, 1};
+        np = 12;
+        for (int i = 0; i < np; ++i) psize[i] = s[i];
+    } else {
+        const int s[8] = {md * D, md, md * md, md, md * md, md, md, 1};
+        np = 8;
+        for (int i = 0; i < np; ++i) psize[i] = s[i];
+    }
+    int o = 0;
+    for (int i = 0; i < np; ++i) { poff[i] = o; o += (psize[i] + 3) & ~3; }
+    poff[np] = o;
+    return o + 4;
+}
 
 constexpr int kMaxDwJobs = 16;
 

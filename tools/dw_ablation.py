@@ -1,5 +1,5 @@
 import sys, os, time, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pime_amd import ops
 from pime_amd.elegantrl.net import CriticAdv
