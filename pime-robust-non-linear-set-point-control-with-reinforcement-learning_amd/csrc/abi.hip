@@ -43,6 +43,7 @@ int launch_pack_bwd(int, int, int, int, const float* const*, float*, hipStream_t
 int launch_ppo_net(int, int, const PpoArgs&, hipStream_t);
 int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
 int64_t fused_stash_floats(int, int);
+bool fused_fits(int, int, int, int);
 int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, float* const*, float* const*, float*, float*,
                        double*, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
@@ -613,13 +614,15 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
     hipStream_t s = static_cast<hipStream_t>(stream);
     PIME_HIP_TRY(hipMemsetAsync(moments, 0, 2 * sizeof(double), s));
     DwArgs dw{};
-    static const bool split = std::getenv("PIME_PPO_SPLIT") != nullptr;  // A/B knob: the older net + dW kernel pipeline
+    static const bool force_split = std::getenv("PIME_PPO_SPLIT") != nullptr;  // A/B knob: the net + dW kernel pipeline
+    const bool split = force_split || !fused_fits(actor->kind, actor->D, actor->Di, actor->md) ||
+                       !fused_fits(critic->kind, critic->D, critic->Di, critic->md);
     static const bool tracing = std::getenv("PIME_FUSED_TRACE") != nullptr;  // tuning aid: phase marks of workgroup 0
     static long long* trace_dev = nullptr;
     if (tracing && !trace_dev) {
-        PIME_HIP_TRY(hipMalloc(&trace_dev, 2 * 32 * sizeof(long long)));
+        PIME_HIP_TRY(hipMalloc(&trace_dev, 2 * 64 * sizeof(long long)));
     }
-    if (tracing) PIME_HIP_TRY(hipMemsetAsync(trace_dev, 0, 2 * 32 * sizeof(long long), s));
+    if (tracing) PIME_HIP_TRY(hipMemsetAsync(trace_dev, 0, 2 * 64 * sizeof(long long), s));
     const pime_ppo_net* nets[2] = {critic, actor};
     PpoArgs fused_args[2];
     for (int k = 0; k < 2; ++k) {
@@ -643,7 +646,7 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
             a.slab = n->workspace + fused_stash_floats(b->B, n->md);
             a.slab_stride = slab_layout(n->kind, n->D, n->Di, n->md, a.poff, psize);
             fused_args[k] = a;
-            a.trace = tracing ? trace_dev + 32 * k : nullptr;
+            a.trace = tracing ? trace_dev + 64 * k : nullptr;
             a.trace_wg = tracing ? std::atoi(std::getenv("PIME_FUSED_TRACE")) : 0;
             if (int rc = launch_ppo_fused(n->kind, n->md, a, s)) return rc;
             continue;
@@ -657,13 +660,15 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         if (int rc = launch_dw(dw, b->B, s)) return rc;
     }
     if (tracing && !split) {
-        long long t[64];
+        long long t[128];
         PIME_HIP_TRY(hipStreamSynchronize(s));
         PIME_HIP_TRY(hipMemcpy(t, trace_dev, sizeof(t), hipMemcpyDeviceToHost));
         for (int k = 0; k < 2; ++k) {
             std::fprintf(stderr, "[pime trace] %s:", k ? "actor " : "critic");
             for (int i = 1; i < 32; ++i)
-                if (t[32 * k + i]) std::fprintf(stderr, " m%d=%.1f", i, (double)(t[32 * k + i] - t[32 * k]) * 0.01);
+                if (t[64 * k + i]) std::fprintf(stderr, " m%d=%.1f", i, (double)(t[64 * k + i] - t[64 * k]) * 0.01);
+            for (int i = 32; i < 40; ++i)
+                if (t[64 * k + i]) std::fprintf(stderr, " c%d=%lld", i - 32, t[64 * k + i]);
             std::fprintf(stderr, "\n");
         }
     }

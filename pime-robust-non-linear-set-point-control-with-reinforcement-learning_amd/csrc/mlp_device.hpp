@@ -117,7 +117,15 @@ __device__ __forceinline__ void stage_image(float* __restrict__ lds, const float
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) dst[i + k * nthr] = v[k];
     }
-    for (; i < n4; i += nthr) dst[i] = src[i];
+    if (i < n4) {  // last, partial batch: same idea with guards (a plain loop would expose one round trip per element)
+        float4 v[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k)
+            if (i + k * nthr < n4) v[k] = src[i + k * nthr];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k)
+            if (i + k * nthr < n4) dst[i + k * nthr] = v[k];
+    }
 }
 
 // tanh in ~12 VALU ops with few live temporaries (ocml's tanhf inlined 64x per layer drove the kernel to the

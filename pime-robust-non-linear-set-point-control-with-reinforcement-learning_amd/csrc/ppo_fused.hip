@@ -33,7 +33,7 @@ constexpr int kPitch = 33;              // 32 samples + 1: conflict-free for sam
 constexpr int kBlk = 32 * kPitch;       // one [32 features][33] block
 
 struct FusedLds {
-    int first0, first1, bias[3], headw, headb, xs, dv, red, wbuf, x, total;
+    int first0, first1, bias[3], headw, headb, xs, hacc, wbuf, x, total;
 };
 
 __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
@@ -58,10 +58,14 @@ __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
     seg(F.headw, md);
     seg(F.headb, 4);
     seg(F.xs, kFusedWaves * 32 * D);   // the group's gathered states [wave][sample][D]
-    seg(F.dv, kFusedWaves * 32);       // d(loss)/d(net output) per sample
-    seg(F.red, md * (D + 1));          // row-reduction accumulators
+    seg(F.hacc, kFusedWaves * md);     // per-wave head weight gradients (summed in wave order at the end)
     seg(F.wbuf, T * T * 1024);
-    seg(F.x, 4 * T * kBlk);
+    // X: two (A+B) buffers of the widest job that keeps W alive (2T blocks each); the merged modular jobs (3T and 2T+1
+    // blocks per buffer) run while W is dead and use W and X as one region
+    int xf = 4 * T * kBlk;
+    const int need3 = 2 * 3 * T * kBlk - T * T * 1024, need1 = 2 * (2 * T + 1) * kBlk - T * T * 1024;
+    if (kind == MLP_MODULAR_ACTOR) xf = xf > need3 ? (xf > need1 ? xf : need1) : (need3 > need1 ? need3 : need1);
+    seg(F.x, xf);
     F.total = o;
     return F;
 }
@@ -102,34 +106,52 @@ __device__ __forceinline__ void stash_get(const float* __restrict__ base, int la
         for (int r = 0; r < 16; ++r) a[t][r] = base[(t * 16 + r) * 64 + off];
 }
 
-// ---- B-operand sources: element (tile t, register r) of the accumulator-layout tile of wave `ow`, for this lane.
-// Any wave can produce any tile's element, so the eight waves share the work of publishing a tile.
+// ---- B-operand sources: NP consecutive registers r0..r0+NP-1 of tile t of the accumulator-layout activation tile of
+// wave `ow`, for this lane.  Any wave can produce any tile's elements, so the eight waves share the publishing work.
 struct StashB {   // a hidden activation stashed by the forward: [wave tile][t][16][64]
+    static constexpr bool kLate = false;  // global loads: issue early, they land behind the MFMAs
     const float* base;   // stash of the group's first tile, at the wanted activation
     int tile_stride;     // floats between consecutive tiles
-    __device__ __forceinline__ float operator()(int ow, int t, int r, int lane) const {
-        return base[(size_t)ow * tile_stride + (t * 16 + r) * 64 + lane];
+    template <int NP>
+    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, float (&v)[NP]) const {
+        const float* p = base + (size_t)ow * tile_stride + (t * 16 + r0) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) v[i] = p[i * 64];
     }
 };
 template <int ACT>
 struct FirstB {   // a first-layer activation, recomputed from the group's states in LDS (same arithmetic as layer_first)
+    static constexpr bool kLate = true;   // VALU / LDS work: waves 4-7 do it after their MFMAs (see dw_rounds)
     const float* w0;   // FIRST image [Din+1][OT][16][2]
     const float* xs;   // [wave][32][D]
     int Din, D, col0, ot32;
-    __device__ __forceinline__ float operator()(int ow, int t, int r, int lane) const {
+    template <int NP>
+    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, float (&v)[NP]) const {
         const float* x = xs + (ow * 32 + (lane & 31)) * D + col0;
-        const float* w = w0 + (t * 16 + r) * 2 + (lane >> 5);
-        float s = w[Din * ot32];
-        for (int j = 0; j < Din; ++j) s = fmaf(x[j], w[j * ot32], s);
-        return activate<ACT>(s);
+        const float* w = w0 + (t * 16 + r0) * 2 + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) v[i] = w[Din * ot32 + 2 * i];
+        for (int j = 0; j < Din; ++j) {   // j outermost: one wait per input column, not one per element
+            const float xj = x[j];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) v[i] = fmaf(xj, w[j * ot32 + 2 * i], v[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) v[i] = activate<ACT>(v[i]);
     }
 };
 struct StateB {   // the raw state columns [col0, col0+Din) padded with zeros to one 32-feature tile
+    static constexpr bool kLate = false;
     const float* xs;
     int Din, D, col0;
-    __device__ __forceinline__ float operator()(int ow, int, int r, int lane) const {
-        const int f = feat32(r, lane >> 5);
-        return f < Din ? xs[(ow * 32 + (lane & 31)) * D + col0 + f] : 0.f;
+    template <int NP>
+    __device__ __forceinline__ void fetch(int ow, int, int r0, int lane, float (&v)[NP]) const {
+        const float* x = xs + (ow * 32 + (lane & 31)) * D + col0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int f = feat32(r0 + i, lane >> 5);
+            v[i] = f < Din ? x[f] : 0.f;
+        }
     }
 };
 
@@ -154,13 +176,12 @@ struct DwPlan {
 // (this lane's k parity).  az: this wave's A tile (AT feature tiles, accumulator layout), published by the wave
 // itself; the B tile of every round is produced by all eight waves (BT*2 elements per lane each, fetched two rounds
 // ahead).  While the rounds run, stage_n4 float4s are copied from stage_src into LDS at stage_dst.
-template <int AT, int BT, class BSrc>
+template <int AT, int BT, class BSrc, class Plan = DwPlan<AT, BT>>
 __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int wave, const f32x16 (&az)[AT],
-                                          const BSrc& bsrc, f32x16 (&acc)[DwPlan<AT, BT>::PER], float& bsum,
+                                          const BSrc& bsrc, f32x16 (&acc)[Plan::PER], float& bsum,
                                           float* __restrict__ stage_dst, const float* __restrict__ stage_src,
                                           int stage_n4, long long* tr = nullptr) {
-    using Plan = DwPlan<AT, BT>;
-    constexpr int PER = Plan::PER, NKS = Plan::NKS;
+    constexpr int PER = Plan::PER, NKS = 16;
     constexpr int BUF = (AT + BT) * kBlk;
     constexpr int NP = BT * 16 / kFusedWaves;                               // B elements this wave publishes per round
     const Plan pl(wave);
@@ -175,16 +196,22 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
     const float4* src4 = reinterpret_cast<const float4*>(stage_src);
     float4* dst4 = reinterpret_cast<float4*>(stage_dst);
     float pv[NP], pv2[NP];
-    auto b_fetch = [&](int ow, float (&v)[NP]) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) v[i] = bsrc(ow, pt, pr0 + i, lane);
-    };
+    auto b_fetch = [&](int ow, float (&v)[NP]) { bsrc.template fetch<NP>(ow, pt, pr0, lane, v); };
     auto b_publish = [&](float* buf) {
         float* p = buf + AT * kBlk + (pt * 32 + 4 * h) * kPitch + li;
 #pragma unroll
         for (int i = 0; i < NP; ++i) p[(((pr0 + i) & 3) + 8 * ((pr0 + i) >> 2)) * kPitch] = pv[i];
     };
 
+    unsigned long long tsum[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    const bool stamping = tr != nullptr && wave == 0;
+#define PIME_STAMP(k)                                                                           \
+    if (stamping) {                                                                             \
+        unsigned long long tnow;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");            \
+        tsum[k] += tnow - tprev;                                                                \
+        tprev = tnow;                                                                           \
+    }
     PIME_LDS_BARRIER();  // X free
     b_fetch(0, pv);
     if (wave == 0) put_tile<AT>(X, lane, az);
@@ -194,12 +221,17 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
     for (int t = 0; t < kFusedWaves; ++t) {
         PIME_LDS_BARRIER();  // buffer t&1 published; buffer (t+1)&1 no longer read
         if (tr && tid == 0) tr[t] = wall_clock64();
+        PIME_STAMP(4);   // barrier wait (the first one also absorbs the time before the loop)
         const float* cur = X + (t & 1) * BUF;
         float* nxt = X + ((t + 1) & 1) * BUF;
         float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < per4) sv = src4[t * per4 + tid];
-        if (t + 2 < kFusedWaves) b_fetch(t + 2, pv2);       // two rounds ahead: a whole round to land
+        // B elements for round t+2.  Recomputed sources are VALU / LDS work: waves 0-3 do it before their MFMAs and
+        // waves 4-7 (their SIMD partners) after, so that one partner's MFMAs run while the other computes.
+        const bool late = BSrc::kLate && wave >= kFusedWaves / 2;
+        if (!late && t + 2 < kFusedWaves) b_fetch(t + 2, pv2);
         if (wave == t + 1) put_tile<AT>(nxt, lane, az);
+        PIME_STAMP(0);   // fetch (+ A publish on the owner)
         PIME_NO_HOIST();
         if (pl.active) {
             const float* Ap = cur + (pl.ao * 32 + li) * kPitch + h;
@@ -211,6 +243,7 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
 #pragma unroll
                 for (int n = 0; n < PER; ++n) bv[n][s] = Bp[n * kBlk + 2 * s];
             }
+            PIME_STAMP(1);   // operand reads back
 #pragma unroll
             for (int s = 0; s < NKS; ++s) {
 #pragma unroll
@@ -218,14 +251,26 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
                     acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[n][s], acc[n], 0, 0, 0);
                 bsum += av[s];
             }
+            if (stamping) {
+                float sink;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(sink) : "v"(acc[PER - 1][0]));   // waits for the last MFMA
+            }
+            PIME_STAMP(2);   // MFMAs
         }
+        PIME_NO_HOIST();
+        if (late && t + 2 < kFusedWaves) b_fetch(t + 2, pv2);
         PIME_NO_HOIST();
         if (t + 1 < kFusedWaves) b_publish(nxt);
 #pragma unroll
         for (int i = 0; i < NP; ++i) pv[i] = pv2[i];
         if (tid < per4) dst4[t * per4 + tid] = sv;
+        PIME_STAMP(3);   // B publish, staging write
     }
-    if (tr && tid == 0) tr[8] = wall_clock64();
+#undef PIME_STAMP
+    if (tr && tid == 0) {
+        tr[8] = wall_clock64();
+        for (int k = 0; k < 5; ++k) tr[16 + k] = (long long)tsum[k];
+    }
 }
 
 // Element offset of accumulator register 0 of a wave's first output block (D[i = a feature][j = b feature]: column on
@@ -267,6 +312,79 @@ __device__ __forceinline__ void dw_store(int lane, int wave, const f32x16 (&acc)
     }
 }
 
+// ---- modular actor: the two branch layers of a level share one set of rounds ---------------------------------------
+// Level 2 (other_net.2 | integrator_net.2): A = [dZo2 | dZi2] (T tiles), B = [h_o1 | h_i1] (2T tiles).  Only the
+// block-diagonal products are wanted: A tiles [0,H) x B tiles [0,T) and A tiles [H,T) x B tiles [T,2T).
+template <int T>
+struct CatPlan {
+    static constexpr int H = T / 2 > 0 ? T / 2 : 1;
+    static constexpr int NBLK = 2 * H * T;
+    static constexpr int PER = NBLK >= kFusedWaves ? NBLK / kFusedWaves : 1;
+    int ao, bi0;
+    bool active;
+    __device__ __forceinline__ explicit CatPlan(int wave) {
+        const int b0 = wave * PER;
+        active = b0 < NBLK;
+        const int branch = active ? b0 / (H * T) : 0, within = active ? b0 % (H * T) : 0;
+        ao = branch * H + within / T;
+        bi0 = branch * T + within % T;
+    }
+};
+template <int T>
+struct CatB {   // tiles [0,T): other branch, [T,2T): integrator branch
+    static constexpr bool kLate = true;
+    FirstB<1> o, i;
+    template <int NP>
+    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, float (&v)[NP]) const {
+        if (t < T) o.template fetch<NP>(ow, t, r0, lane, v);
+        else i.template fetch<NP>(ow, t - T, r0, lane, v);
+    }
+};
+
+// One 32x32 accumulator block -> rows row0.. of a row-major [.. x ldw] slab tensor at column `col` (this lane's).
+__device__ __forceinline__ void block_store(const f32x16& acc, float* __restrict__ gW, int ldw, int row0, int col,
+                                            bool col_ok, int lane, bool accum) {
+    int base = (row0 + 4 * (lane >> 5)) * ldw + col;
+    asm volatile("" : "+v"(base));
+    if (col_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* q = &gW[base + ((r & 3) + 8 * (r >> 2)) * ldw];
+            *q = accum ? *q + acc[r] : acc[r];
+        }
+    }
+}
+__device__ __forceinline__ void bias_store(float bsum, float* __restrict__ gb, int lane, bool accum) {
+    bsum += __shfl_xor(bsum, 32);  // the two k parities
+    if (lane < 32) {
+        float* q = &gb[lane];
+        *q = accum ? *q + bsum : bsum;
+    }
+}
+
+// d[ot] *= act'(h1[ot]) with the first-layer activation h1 recomputed one 32-feature tile at a time (16 live registers
+// instead of a whole T-tile activation; same arithmetic as layer_first).
+template <int OT, int ACT>
+__device__ __forceinline__ void first_times_act_grad(const float* __restrict__ w0, const float* __restrict__ x, int Din,
+                                                     int h, f32x16 (&d)[OT]) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        PIME_NO_HOIST();
+        f32x16 v;
+        const float* wb = w0 + Din * (OT * 32) + ot * 32 + h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = wb[r * 2];
+        for (int j = 0; j < Din; ++j) {
+            const float xj = x[j];
+            const float* wj = w0 + j * (OT * 32) + ot * 32 + h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaf(xj, wj[r * 2], v[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[ot][r] *= act_grad_from_output<ACT>(activate<ACT>(v[r]));
+    }
+}
+
 // Sum of v over the 32 lanes of this lane's half; valid in lanes 31 and 63.
 __device__ __forceinline__ float half_sum_dpp(float v) {
 #define PIME_DPP_ADD(x, ctrl, row_mask) \
@@ -303,26 +421,44 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     float* const wbuf = lds + F.wbuf;
     float* const X = lds + F.x;
     float* const xs = lds + F.xs;
-    float* const hacc = lds + F.red;   // head weight gradient of the workgroup
+    float* const hacc = lds + F.hacc;   // head weight gradient of the workgroup
     const int Do = a.D - a.Di;
 
     PIME_MARK(0);
-    for (int e = tid; e < md; e += kFusedThreads) hacc[e] = 0.f;
-    // small segments live in LDS for the whole kernel
-    if constexpr (MODULAR) {
-        stage_image(lds + F.first0, a.img_fwd + L.off[0], md * (Do + 1) / 4);
-        stage_image(lds + F.first1, a.img_fwd + L.off[3], md * (a.Di + 1) / 4);
-        stage_image(lds + F.bias[0], a.img_fwd + L.off[2], H * 32 / 4);
-        stage_image(lds + F.bias[1], a.img_fwd + L.off[5], H * 32 / 4);
-        stage_image(lds + F.bias[2], a.img_fwd + L.off[7], md / 4);
-        stage_image(lds + F.headw, a.img_fwd + L.off[8], md / 4);
-        stage_image(lds + F.headb, a.img_fwd + L.off[9], 1);
-    } else {
-        stage_image(lds + F.first0, a.img_fwd + L.off[0], md * (a.D + 1) / 4);
-        stage_image(lds + F.bias[0], a.img_fwd + L.off[2], md / 4);
-        stage_image(lds + F.bias[1], a.img_fwd + L.off[4], md / 4);
-        stage_image(lds + F.headw, a.img_fwd + L.off[5], md / 4);
-        stage_image(lds + F.headb, a.img_fwd + L.off[6], 1);
+    for (int e = tid; e < kFusedWaves * md; e += kFusedThreads) hacc[e] = 0.f;
+    // small segments live in LDS for the whole kernel.  All their loads are issued before the first LDS write: one
+    // L2 round trip instead of one per segment (7 segments cost the modular actor 10 us).
+    {
+        constexpr int NS = MODULAR ? 7 : 5;
+        const float* src[NS];
+        float* dst[NS];
+        int n4[NS];
+        auto seg = [&](int k, int ldsoff, int imgoff, int floats) { dst[k] = lds + ldsoff; src[k] = a.img_fwd + imgoff; n4[k] = floats / 4; };
+        if constexpr (MODULAR) {
+            seg(0, F.first0, L.off[0], md * (Do + 1));
+            seg(1, F.first1, L.off[3], md * (a.Di + 1));
+            seg(2, F.bias[0], L.off[2], H * 32);
+            seg(3, F.bias[1], L.off[5], H * 32);
+            seg(4, F.bias[2], L.off[7], md);
+            seg(5, F.headw, L.off[8], md);
+            seg(6, F.headb, L.off[9], 4);
+        } else {
+            seg(0, F.first0, L.off[0], md * (a.D + 1));
+            seg(1, F.bias[0], L.off[2], md);
+            seg(2, F.bias[1], L.off[4], md);
+            seg(3, F.headw, L.off[5], md);
+            seg(4, F.headb, L.off[6], 4);
+        }
+        float4 v[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (tid < n4[k]) v[k] = reinterpret_cast<const float4*>(src[k])[tid];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (tid < n4[k]) reinterpret_cast<float4*>(dst[k])[tid] = v[k];
+            for (int i = tid + kFusedThreads; i < n4[k]; i += kFusedThreads)   // wide first layers only
+                reinterpret_cast<float4*>(dst[k])[i] = reinterpret_cast<const float4*>(src[k])[i];
+        }
     }
     float s0 = 0.f, s1 = 0.f, gstd = 0.f, ghb = 0.f;
     double m1 = 0.0, m2 = 0.0;
@@ -334,15 +470,8 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));
         const int h = lane >> 5, li = lane & 31;
-        __syncthreads();  // the previous group's backward is done with W / X
-        if constexpr (MODULAR) {
-            stage_image(wbuf, a.img_fwd + L.off[6], T * T * 256);
-            stage_image(X, a.img_fwd + L.off[1], T * H * 256);
-            stage_image(X + T * H * 1024, a.img_fwd + L.off[4], T * H * 256);
-        } else {
-            stage_image(wbuf, a.img_fwd + L.off[1], T * T * 256);
-            stage_image(X, a.img_fwd + L.off[3], T * T * 256);
-        }
+        // the minibatch gather (index -> row -> per-sample inputs) is two dependent HBM round trips: start it before
+        // the weight staging so that the two overlap
         const int tile = group * kFusedWaves + wave;  // tiles past the batch run on clamped rows with dOut = 0
         const int pos = tile * 32 + li;
         const bool valid = pos < a.B;
@@ -354,10 +483,31 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
         const float in_action = CRITIC ? 0.f : a.action[row];
         const float in_logprob = CRITIC ? 0.f : a.logprob[row];
         const float in_adv = CRITIC ? 0.f : a.adv[row];
-        if (h == 0)
-            for (int c = 0; c < a.D; ++c) xs[(wave * 32 + li) * a.D + c] = xrow[c];
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;   // the first state columns ride along (all of them for the pH / tank envs)
+        if (a.D > 0) x0 = xrow[0];
+        if (a.D > 1) x1 = xrow[1];
+        if (a.D > 2) x2 = xrow[2];
+        if (a.D > 3) x3 = xrow[3];
+        __syncthreads();  // the previous group's backward is done with W / X
+        if constexpr (MODULAR) {
+            stage_image(wbuf, a.img_fwd + L.off[6], T * T * 256);
+            stage_image(X, a.img_fwd + L.off[1], T * H * 256);
+            stage_image(X + T * H * 1024, a.img_fwd + L.off[4], T * H * 256);
+        } else {
+            stage_image(wbuf, a.img_fwd + L.off[1], T * T * 256);
+            stage_image(X, a.img_fwd + L.off[3], T * T * 256);
+        }
+        if (h == 0) {
+            float* xw = xs + (wave * 32 + li) * a.D;
+            if (a.D > 0) xw[0] = x0;
+            if (a.D > 1) xw[1] = x1;
+            if (a.D > 2) xw[2] = x2;
+            if (a.D > 3) xw[3] = x3;
+            for (int c = 4; c < a.D; ++c) xw[c] = xrow[c];
+        }
         __syncthreads();
         PIME_MARK(1);
+        const float* xl = xs + (wave * 32 + li) * a.D;   // this lane's state row
 
         // ---------------------------------------------------------------------------------- forward + loss gradient
         float y;
@@ -366,14 +516,14 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             f32x16 cat[T];
             {
                 f32x16 a0[T];
-                layer_first<T, 1>(lds + F.first0, xrow, Do, h, a0);
+                layer_first<T, 1>(lds + F.first0, xl, Do, h, a0);
                 PIME_NO_HOIST();
                 layer_mfma<T, H, 1>(X, lds + F.bias[0], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
             }
             {
                 f32x16 a0[T];
                 PIME_NO_HOIST();
-                layer_first<T, 1>(lds + F.first1, xrow + Do, a.Di, h, a0);
+                layer_first<T, 1>(lds + F.first1, xl + Do, a.Di, h, a0);
                 PIME_NO_HOIST();
                 layer_mfma<T, H, 1>(X + T * H * 1024, lds + F.bias[1], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
             }
@@ -386,7 +536,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             f32x16 a1[T];
             {
                 f32x16 a0[T];
-                layer_first<T, ACT>(lds + F.first0, xrow, a.D, h, a0);
+                layer_first<T, ACT>(lds + F.first0, xl, a.D, h, a0);
                 PIME_NO_HOIST();
                 layer_mfma<T, T, ACT>(wbuf, lds + F.bias[0], lane, a0, a1);
             }
@@ -444,11 +594,11 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hl[t][r] = half_sum_dpp(dout * hl[t][r]);
-            if (li == 31) {
+            if (li == 31) {   // this wave's own slots: no atomics, the sums stay reproducible
 #pragma unroll
                 for (int t = 0; t < T; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) atomicAdd(&hacc[t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h], hl[t][r]);
+                    for (int r = 0; r < 16; ++r) hacc[wave * md + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] += hl[t][r];
             }
 #pragma unroll
             for (int t = 0; t < T; ++t) hl[t] = dl[t];
@@ -467,7 +617,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 float bsum;
                 PIME_NO_HOIST();
                 dw_rounds<T, T>(X, lane, wave, dn0, StashB{st0, T * 1024}, acc, bsum, wbuf, a.img_bwd + Lb.off[3],
-                                T * T * 256, (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
+                                T * T * 256);
                 dw_store<T, T>(lane, wave, acc, bsum, sl + a.poff[8], md, md, md, sl + a.poff[9], accum);   // net.0
             }
             PIME_LDS_BARRIER();
@@ -480,48 +630,56 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 times_act_grad<T, 1>(dcat, cat);                                                    // [dZo2 | dZi2]
             }
             PIME_MARK(6);
-            {
-                f32x16 acc[DwPlan<H, T>::PER];
+            {   // other_net.2 and integrator_net.2: one set of rounds over the W+X region (W is dead until the next dX)
+                f32x16 acc[CatPlan<T>::PER];
                 float bsum;
                 PIME_NO_HOIST();
-                dw_rounds<H, T>(X, lane, wave, *reinterpret_cast<f32x16(*)[H]>(&dcat[0]),
-                                FirstB<1>{lds + F.first0, xs, Do, a.D, 0, md}, acc, bsum, wbuf, a.img_bwd + Lb.off[4],
-                                2 * H * T * 256);                                                   // (+ both images)
-                dw_store<H, T>(lane, wave, acc, bsum, sl + a.poff[2], md, H * 32, md, sl + a.poff[3], accum);  // other_net.2
-                PIME_MARK(7);
-                PIME_NO_HOIST();
-                dw_rounds<H, T>(X, lane, wave, *reinterpret_cast<f32x16(*)[H]>(&dcat[H]),
-                                FirstB<1>{lds + F.first1, xs, a.Di, a.D, Do, md}, acc, bsum, nullptr, nullptr, 0);
-                dw_store<H, T>(lane, wave, acc, bsum, sl + a.poff[6], md, H * 32, md, sl + a.poff[7], accum);  // integrator_net.2
+                dw_rounds<T, 2 * T, CatB<T>, CatPlan<T>>(
+                    wbuf, lane, wave, dcat,
+                    CatB<T>{FirstB<1>{lds + F.first0, xs, Do, a.D, 0, md}, FirstB<1>{lds + F.first1, xs, a.Di, a.D, Do, md}},
+                    acc, bsum, nullptr, nullptr, 0, (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
+                const CatPlan<T> pl(wave);
+                if (pl.active) {
+                    const int br = pl.ao >= H ? 1 : 0;
+                    float* gW = sl + a.poff[br ? 6 : 2];
+#pragma unroll
+                    for (int n = 0; n < CatPlan<T>::PER; ++n)
+                        block_store(acc[n], gW, md, (pl.ao - br * H) * 32, (pl.bi0 + n - br * T) * 32 + li, true, lane, accum);
+                    if (pl.bi0 % T == 0) bias_store(bsum, sl + a.poff[br ? 7 : 3] + (pl.ao - br * H) * 32, lane, accum);
+                }
             }
+            PIME_LDS_BARRIER();   // the rounds are done with the region
+            PIME_MARK(7);
+            stage_image(wbuf, a.img_bwd + Lb.off[4], 2 * H * T * 256);   // other_net.2^T | integrator_net.2^T
             PIME_LDS_BARRIER();
             PIME_MARK(8);
             {
-                f32x16 d1[T], h1[T];
+                f32x16 d1[2 * T];   // [dZo1 | dZi1]
                 PIME_NO_HOIST();
-                layer_mfma<H, T, 2, false>(wbuf, nullptr, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[0]), d1);
-                PIME_NO_HOIST();
-                layer_first<T, 1>(lds + F.first0, xrow, Do, h, h1);
-                times_act_grad<T, 1>(d1, h1);                                                       // dZo1
+                layer_mfma<H, T, 2, false>(wbuf, nullptr, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[0]),
+                                           *reinterpret_cast<f32x16(*)[T]>(&d1[0]));
+                first_times_act_grad<T, 1>(lds + F.first0, xl, Do, h, *reinterpret_cast<f32x16(*)[T]>(&d1[0]));  // dZo1
                 PIME_MARK(9);
-                f32x16 acc[DwPlan<T, 1>::PER];
-                float bsum;
-                dw_rounds<T, 1>(X, lane, wave, d1, StateB{xs, Do, a.D, 0}, acc, bsum, nullptr, nullptr, 0);
-                dw_store<T, 1>(lane, wave, acc, bsum, sl + a.poff[0], Do, md, Do, sl + a.poff[1], accum);     // other_net.0
+                PIME_NO_HOIST();
+                layer_mfma<H, T, 2, false>(wbuf + H * T * 1024, nullptr, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[H]),
+                                           *reinterpret_cast<f32x16(*)[T]>(&d1[T]));
+                first_times_act_grad<T, 1>(lds + F.first1, xl + Do, a.Di, h, *reinterpret_cast<f32x16(*)[T]>(&d1[T]));  // dZi1
                 PIME_MARK(10);
-            }
-            {
-                f32x16 d1[T], h1[T];
-                PIME_NO_HOIST();
-                layer_mfma<H, T, 2, false>(wbuf + H * T * 1024, nullptr, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[H]), d1);
-                PIME_NO_HOIST();
-                layer_first<T, 1>(lds + F.first1, xrow + Do, a.Di, h, h1);
-                times_act_grad<T, 1>(d1, h1);                                                       // dZi1
+                {
+                    // matrix form: A = [dZo1 | dZi1], B = the state columns (one tile); wave w owns A tile w; its
+                    // product's columns [0,Do) or [Do,D) are the wanted gradient
+                    f32x16 acc[DwPlan<2 * T, 1>::PER];
+                    float bsum;
+                    dw_rounds<2 * T, 1>(wbuf, lane, wave, d1, StateB{xs, a.D, a.D, 0}, acc, bsum, nullptr, nullptr, 0);
+                    const DwPlan<2 * T, 1> pl(wave);
+                    if (pl.active) {
+                        const int br = pl.ao >= T ? 1 : 0;
+                        const int ldw = br ? a.Di : Do, col = li - (br ? Do : 0);
+                        block_store(acc[0], sl + a.poff[br ? 4 : 0], ldw, (pl.ao - br * T) * 32, col, col >= 0 && col < ldw, lane, accum);
+                        bias_store(bsum, sl + a.poff[br ? 5 : 1] + (pl.ao - br * T) * 32, lane, accum);
+                    }
+                }
                 PIME_MARK(11);
-                f32x16 acc[DwPlan<T, 1>::PER];
-                float bsum;
-                dw_rounds<T, 1>(X, lane, wave, d1, StateB{xs, a.Di, a.D, Do}, acc, bsum, nullptr, nullptr, 0);
-                dw_store<T, 1>(lane, wave, acc, bsum, sl + a.poff[4], a.Di, md, a.Di, sl + a.poff[5], accum); // integrator_net.0
             }
         } else {
             f32x16(&d)[T] = hl;                                                                     // dZ3
@@ -532,7 +690,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 float bsum;
                 PIME_NO_HOIST();
                 dw_rounds<T, T>(X, lane, wave, d, StashB{st0, T * 1024}, acc, bsum, wbuf, a.img_bwd + Lb.off[2],
-                                T * T * 256, (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
+                                T * T * 256);
                 dw_store<T, T>(lane, wave, acc, bsum, sl + a.poff[4], md, md, md, sl + a.poff[5], accum);      // net.4
             }
             PIME_LDS_BARRIER();
@@ -550,19 +708,15 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 float bsum;
                 PIME_NO_HOIST();
                 dw_rounds<T, T>(X, lane, wave, d2, FirstB<ACT>{lds + F.first0, xs, a.D, a.D, 0, md}, acc, bsum, wbuf,
-                                a.img_bwd + Lb.off[3], T * T * 256);
+                                a.img_bwd + Lb.off[3], T * T * 256,
+                                (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
                 dw_store<T, T>(lane, wave, acc, bsum, sl + a.poff[2], md, md, md, sl + a.poff[3], accum);      // net.2
             }
             PIME_LDS_BARRIER();
             PIME_MARK(7);
             PIME_NO_HOIST();
             layer_mfma<T, T, 2, false>(wbuf, nullptr, lane, d2, d);
-            {
-                f32x16 hh[T];
-                PIME_NO_HOIST();
-                layer_first<T, ACT>(lds + F.first0, xrow, a.D, h, hh);                              // H1 again
-                times_act_grad<T, ACT>(d, hh);                                                      // dZ1
-            }
+            first_times_act_grad<T, ACT>(lds + F.first0, xl, a.D, h, d);                            // dZ1 (H1 again)
             PIME_MARK(8);
             f32x16 acc[DwPlan<T, 1>::PER];
             float bsum;
@@ -587,7 +741,11 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     __syncthreads();
     float* const sl = a.slab + (size_t)blockIdx.x * a.slab_stride;
     constexpr int NP = MODULAR ? 12 : 8;
-    if (tid < md) sl[a.poff[NP - 2] + tid] = hacc[tid];   // head weight
+    if (tid < md) {   // head weight
+        float t = hacc[tid];
+        for (int w = 1; w < kFusedWaves; ++w) t += hacc[w * md + tid];
+        sl[a.poff[NP - 2] + tid] = t;
+    }
     if (tid == 0) {
         double t[6] = {0, 0, 0, 0, 0, 0};
         for (int w = 0; w < kFusedWaves; ++w)
@@ -740,6 +898,12 @@ static int launch_fused(const PpoArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((ppo_fused_kernel<T, KIND>), dim3(grid), dim3(kFusedThreads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
+}
+
+// Does the kernel's LDS map fit?  (wide observations, e.g. the stacked water tank, do not: the caller then uses the
+// split net + dW pipeline of ppo_train.hip)
+bool fused_fits(int kind, int D, int Di, int md) {
+    return sizeof(float) * (size_t)fused_lds(kind, D, Di, md / 32).total <= 160 * 1024;
 }
 
 int launch_ppo_fused(int kind, int md, const PpoArgs& a, hipStream_t s) {
