@@ -29,8 +29,11 @@ namespace pime {
 
 constexpr int kFusedThreads = 512;
 constexpr int kFusedWaves = kFusedThreads / 64;
-constexpr int kPitch = 33;              // 32 samples + 1: conflict-free for sample-major writes and k-major reads
-constexpr int kBlk = 32 * kPitch;       // one [32 features][33] block
+// Transposition buffers are SAMPLE-major: row s = the NT*32 features of sample s, padded by 4 floats.  A lane (sample)
+// writes its accumulator registers four features at a time (ds_write_b128; registers 4g..4g+3 of a tile are four
+// consecutive features), the MFMA operand reads take consecutive features on consecutive lanes: both conflict-free.
+__host__ __device__ constexpr int tpitch(int nt) { return nt * 32 + 4; }
+__host__ __device__ constexpr int tsize(int nt) { return 32 * tpitch(nt); }   // floats of one 32-sample tile image
 
 struct FusedLds {
     int first0, first1, bias[3], headw, headb, xs, hacc, wbuf, x, total;
@@ -62,8 +65,8 @@ __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
     seg(F.wbuf, T * T * 1024);
     // X: two (A+B) buffers of the widest job that keeps W alive (2T blocks each); the merged modular jobs (3T and 2T+1
     // blocks per buffer) run while W is dead and use W and X as one region
-    int xf = 4 * T * kBlk;
-    const int need3 = 2 * 3 * T * kBlk - T * T * 1024, need1 = 2 * (2 * T + 1) * kBlk - T * T * 1024;
+    int xf = 2 * (tsize(T) + tsize(T));
+    const int need3 = 2 * (tsize(T) + tsize(2 * T)) - T * T * 1024, need1 = 2 * (tsize(2 * T) + tsize(1)) - T * T * 1024;
     if (kind == MLP_MODULAR_ACTOR) xf = xf > need3 ? (xf > need1 ? xf : need1) : (need3 > need1 ? need3 : need1);
     seg(F.x, xf);
     F.total = o;
@@ -78,11 +81,12 @@ __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
 // Accumulator-layout tile (sample on the lane) -> feature-major rows [t*32 + feat][sample], pitch 33.
 template <int NTL>
 __device__ __forceinline__ void put_tile(float* __restrict__ dst, int lane, const f32x16 (&v)[NTL]) {
-    float* p = dst + (lane >> 5) * 4 * kPitch + (lane & 31);
+    float* p = dst + (lane & 31) * tpitch(NTL) + 4 * (lane >> 5);
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[(t * 32 + (r & 3) + 8 * (r >> 2)) * kPitch] = v[t][r];
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(p + t * 32 + 8 * g) = make_float4(v[t][4 * g], v[t][4 * g + 1], v[t][4 * g + 2], v[t][4 * g + 3]);
 }
 
 // Stash tiles through a wave-uniform base: one 32-bit lane offset + immediates instead of a 64-bit address per row
@@ -182,7 +186,7 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
                                           float* __restrict__ stage_dst, const float* __restrict__ stage_src,
                                           int stage_n4, long long* tr = nullptr) {
     constexpr int PER = Plan::PER, NKS = 16;
-    constexpr int BUF = (AT + BT) * kBlk;
+    constexpr int BUF = tsize(AT) + tsize(BT);
     constexpr int NP = BT * 16 / kFusedWaves;                               // B elements this wave publishes per round
     const Plan pl(wave);
     const int tid = wave * 64 + lane, h = lane >> 5, li = lane & 31;
@@ -198,9 +202,15 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
     float pv[NP], pv2[NP];
     auto b_fetch = [&](int ow, float (&v)[NP]) { bsrc.template fetch<NP>(ow, pt, pr0, lane, v); };
     auto b_publish = [&](float* buf) {
-        float* p = buf + AT * kBlk + (pt * 32 + 4 * h) * kPitch + li;
+        float* p = buf + tsize(AT) + li * tpitch(BT) + pt * 32 + 4 * h + 8 * (pr0 >> 2) + (pr0 & 3);
+        if constexpr (NP >= 4) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) p[(((pr0 + i) & 3) + 8 * ((pr0 + i) >> 2)) * kPitch] = pv[i];
+            for (int g = 0; g < NP / 4; ++g)
+                *reinterpret_cast<float4*>(p + 8 * g) = make_float4(pv[4 * g], pv[4 * g + 1], pv[4 * g + 2], pv[4 * g + 3]);
+        } else {
+            static_assert(NP == 2, "publish slice");
+            *reinterpret_cast<float2*>(p) = make_float2(pv[0], pv[1]);
+        }
     };
 
     unsigned long long tsum[5] = {0, 0, 0, 0, 0}, tprev = 0;
@@ -234,14 +244,14 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
         PIME_STAMP(0);   // fetch (+ A publish on the owner)
         PIME_NO_HOIST();
         if (pl.active) {
-            const float* Ap = cur + (pl.ao * 32 + li) * kPitch + h;
-            const float* Bp = cur + AT * kBlk + (pl.bi0 * 32 + li) * kPitch + h;
+            const float* Ap = cur + h * tpitch(AT) + pl.ao * 32 + li;                  // k-step s: samples 2s + h
+            const float* Bp = cur + tsize(AT) + h * tpitch(BT) + pl.bi0 * 32 + li;
             float av[NKS], bv[PER][NKS];
 #pragma unroll
             for (int s = 0; s < NKS; ++s) {
-                av[s] = Ap[2 * s];
+                av[s] = Ap[2 * s * tpitch(AT)];
 #pragma unroll
-                for (int n = 0; n < PER; ++n) bv[n][s] = Bp[n * kBlk + 2 * s];
+                for (int n = 0; n < PER; ++n) bv[n][s] = Bp[2 * s * tpitch(BT) + n * 32];
             }
             PIME_STAMP(1);   // operand reads back
 #pragma unroll

@@ -64,7 +64,10 @@ def _torch_grads(act, cri, state, action, logprob, adv, r_sum, idx, clip, lam):
 
 @pytest.mark.parametrize("kind,md,D,B", [("modular", 128, 3, 4096), ("modular", 128, 3, 1000), ("modular", 64, 4, 2048),
                                          ("resid", 128, 3, 4096), ("resid", 64, 12, 777), ("ppo", 128, 3, 2048),
-                                         ("modular", 128, 3, 65536)])
+                                         ("modular", 128, 3, 65536),
+                                         ("modular", 128, 3, 70000),   # > 256 sample groups: workgroups accumulate a 2nd group
+                                         ("resid", 128, 30, 2048),     # stacked-tank width: LDS map does not fit -> split pipeline
+                                         ("modular", 128, 6, 3000)])
 def test_fused_gradients_match_autograd(kind, md, D, B):
     from pime_amd import ops
     act, cri = _make(kind, md, D, seed=B + md)
@@ -93,6 +96,30 @@ def test_fused_gradients_match_autograd(kind, md, D, B):
     np.testing.assert_allclose(sums[0], s_sur, rtol=2e-4, atol=1e-3 * B ** 0.5)
     np.testing.assert_allclose(sums[1], s_ent, rtol=2e-4, atol=1e-3 * B ** 0.5)
     np.testing.assert_allclose(sums[2], s_cri, rtol=2e-4)
+
+
+def test_fused_gradients_are_reproducible_and_accumulate():
+    """The per-workgroup gradient slabs are summed in a fixed order: two calls give bit-identical gradients; and the
+    ABI contract is ACCUMULATE (include/pime_hip.h): a second call without zeroing doubles them."""
+    from pime_amd import ops
+    B = 8192
+    act, cri = _make("modular", 128, 3, seed=5)
+    state, action, logprob, adv, r_sum = _data(3 * B, 3, act, seed=3)
+    idx = torch.randint(3 * B, (B,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    fused = ops.FusedPPOGrad(act, cri, B)
+    scale = torch.zeros(1, device=DEV)
+
+    def run(zero):
+        if zero:
+            fused.zero_grad()
+        fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, 0.2, 0.02, scale)
+        torch.cuda.synchronize()
+        return fused.flat_grad.clone()
+
+    g1, g2 = run(True), run(True)
+    assert torch.equal(g1, g2), "gradients differ between two identical calls"
+    g3 = run(False)
+    torch.testing.assert_close(g3, 2 * g1, rtol=1e-6, atol=1e-9)
 
 
 def test_fused_update_net_matches_torch_update():
