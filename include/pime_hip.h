@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 4
+#define PIME_ABI_VERSION 5
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -222,6 +222,9 @@ int64_t pime_ppo_bwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t m
 int64_t pime_ppo_workspace_floats(int32_t kind, int32_t B, int32_t md);
 int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const float* const* params, float* image,
                       pime_stream stream);
+/* Re-packs img_fwd and img_bwd of both nets from their `params` in ONE launch (after every optimizer step; the four
+ * separate pack launches cost ~20 us of a ~400 us step). */
+int pime_ppo_repack(const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream);
 /* critic_scale: [dev] float32[1], WRITTEN: 1 / (r_sum[indices].std() + 1e-5) with torch's unbiased std (agent.py:652);
  *               the critic's gradients are multiplied by it (fourth, tiny launch)
  * moments:      [dev] float64[2] scratch (zeroed by the call)

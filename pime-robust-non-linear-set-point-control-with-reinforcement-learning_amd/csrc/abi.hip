@@ -44,6 +44,7 @@ int launch_ppo_net(int, int, const PpoArgs&, hipStream_t);
 int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
 int64_t fused_stash_floats(int, int);
 bool fused_fits(int, int, int, int);
+int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
 int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, float* const*, float* const*, float*, float*,
                        double*, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
@@ -602,6 +603,23 @@ static int check_net(const pime_ppo_net* n, bool actor) {
     return PIME_OK;
 }
 
+int pime_ppo_repack(const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream) {
+    if (int rc = check_net(actor, true)) return rc;
+    if (int rc = check_net(critic, false)) return rc;
+    PackArgs pa[2];
+    const pime_ppo_net* nets[2] = {critic, actor};
+    for (int k = 0; k < 2; ++k) {
+        const pime_ppo_net* n = nets[k];
+        pa[k] = PackArgs{};
+        const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
+        for (int i = 0; i < np; ++i) pa[k].p[i] = n->params[i];
+        pa[k].kind = n->kind; pa[k].D = n->D; pa[k].Di = n->Di; pa[k].md = n->md;
+    }
+    return launch_repack(pa[0], pa[1], const_cast<float*>(critic->img_fwd), const_cast<float*>(critic->img_bwd),
+                         const_cast<float*>(actor->img_fwd), const_cast<float*>(actor->img_bwd),
+                         static_cast<hipStream_t>(stream));
+}
+
 int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b,
                             float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
                             float* loss_sums, pime_stream stream) {
@@ -612,7 +630,6 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
     PIME_REQUIRE(critic_scale && moments && loss_sums, "pime_ppo_minibatch_grad: NULL critic_scale / moments / loss_sums");
     PIME_REQUIRE(actor->D == critic->D, "actor and critic state_dim differ");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    PIME_HIP_TRY(hipMemsetAsync(moments, 0, 2 * sizeof(double), s));
     DwArgs dw{};
     static const bool force_split = std::getenv("PIME_PPO_SPLIT") != nullptr;  // A/B knob: the net + dW kernel pipeline
     const bool split = force_split || !fused_fits(actor->kind, actor->D, actor->Di, actor->md) ||
@@ -623,6 +640,7 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         PIME_HIP_TRY(hipMalloc(&trace_dev, 2 * 64 * sizeof(long long)));
     }
     if (tracing) PIME_HIP_TRY(hipMemsetAsync(trace_dev, 0, 2 * 64 * sizeof(long long), s));
+    if (split) PIME_HIP_TRY(hipMemsetAsync(moments, 0, 2 * sizeof(double), s));  // atomics accumulate into it
     const pime_ppo_net* nets[2] = {critic, actor};
     PpoArgs fused_args[2];
     for (int k = 0; k < 2; ++k) {

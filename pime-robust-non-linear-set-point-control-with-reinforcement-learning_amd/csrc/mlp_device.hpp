@@ -2,6 +2,7 @@
 // gradient kernels (ppo_train.hip): packed-image layout, MFMA layer chain, first layer / head, tanh.
 #pragma once
 #include "pime_common.hpp"
+#include "ppo_train.hpp"
 
 namespace pime {
 
@@ -92,6 +93,33 @@ __device__ inline void pack_vec(float* dst, const float* v, int OT, int tid, int
     for (int idx = tid; idx < OT * 32; idx += nthr) {
         const int h = idx & 1, r = (idx >> 1) & 15, ot = idx >> 5;
         dst[idx] = v[ot * 32 + feat32(r, h)];
+    }
+}
+
+// nn.Linear layout -> forward image (mlp_layout order)
+__device__ inline void pack_forward_image(const PackArgs& a, float* __restrict__ out, int tid, int nthr) {
+    const MlpLayout L = mlp_layout(a.kind, a.D, a.Di, a.md);
+    const int T = L.T;
+    if (a.kind == MLP_MODULAR_ACTOR) {
+        const int Do = a.D - a.Di, H = T / 2;
+        pack_first(out + L.off[0], a.p[0], a.p[1], Do, Do, 0, T, tid, nthr);
+        pack_mfma(out + L.off[1], a.p[2], T, H, tid, nthr);
+        pack_vec(out + L.off[2], a.p[3], H, tid, nthr);
+        pack_first(out + L.off[3], a.p[4], a.p[5], a.Di, a.Di, 0, T, tid, nthr);
+        pack_mfma(out + L.off[4], a.p[6], T, H, tid, nthr);
+        pack_vec(out + L.off[5], a.p[7], H, tid, nthr);
+        pack_mfma(out + L.off[6], a.p[8], T, T, tid, nthr);
+        pack_vec(out + L.off[7], a.p[9], T, tid, nthr);
+        pack_vec(out + L.off[8], a.p[10], T, tid, nthr);
+        if (tid == 0) out[L.off[9]] = a.p[11][0];
+    } else {
+        pack_first(out + L.off[0], a.p[0], a.p[1], a.D, a.D, 0, T, tid, nthr);
+        pack_mfma(out + L.off[1], a.p[2], T, T, tid, nthr);
+        pack_vec(out + L.off[2], a.p[3], T, tid, nthr);
+        pack_mfma(out + L.off[3], a.p[4], T, T, tid, nthr);
+        pack_vec(out + L.off[4], a.p[5], T, tid, nthr);
+        pack_vec(out + L.off[5], a.p[6], T, tid, nthr);
+        if (tid == 0) out[L.off[6]] = a.p[7][0];
     }
 }
 

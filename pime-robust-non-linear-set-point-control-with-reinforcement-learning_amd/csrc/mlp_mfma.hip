@@ -21,35 +21,8 @@
 namespace pime {
 
 // ---- pack: nn.Linear layout -> packed image -------------------------------------------------------------------
-struct PackArgs {
-    const float* p[12];
-    int kind, D, Di, md;
-};
-
 __global__ void mlp_pack_kernel(PackArgs a, float* __restrict__ out) {
-    const MlpLayout L = mlp_layout(a.kind, a.D, a.Di, a.md);
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x, T = L.T;
-    if (a.kind == MLP_MODULAR_ACTOR) {
-        const int Do = a.D - a.Di, H = T / 2;
-        pack_first(out + L.off[0], a.p[0], a.p[1], Do, Do, 0, T, tid, nthr);
-        pack_mfma(out + L.off[1], a.p[2], T, H, tid, nthr);
-        pack_vec(out + L.off[2], a.p[3], H, tid, nthr);
-        pack_first(out + L.off[3], a.p[4], a.p[5], a.Di, a.Di, 0, T, tid, nthr);
-        pack_mfma(out + L.off[4], a.p[6], T, H, tid, nthr);
-        pack_vec(out + L.off[5], a.p[7], H, tid, nthr);
-        pack_mfma(out + L.off[6], a.p[8], T, T, tid, nthr);
-        pack_vec(out + L.off[7], a.p[9], T, tid, nthr);
-        pack_vec(out + L.off[8], a.p[10], T, tid, nthr);
-        if (tid == 0) out[L.off[9]] = a.p[11][0];
-    } else {
-        pack_first(out + L.off[0], a.p[0], a.p[1], a.D, a.D, 0, T, tid, nthr);
-        pack_mfma(out + L.off[1], a.p[2], T, T, tid, nthr);
-        pack_vec(out + L.off[2], a.p[3], T, tid, nthr);
-        pack_mfma(out + L.off[3], a.p[4], T, T, tid, nthr);
-        pack_vec(out + L.off[4], a.p[5], T, tid, nthr);
-        pack_vec(out + L.off[5], a.p[6], T, tid, nthr);
-        if (tid == 0) out[L.off[6]] = a.p[7][0];
-    }
+    pack_forward_image(a, out, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 constexpr int kMlpThreads = 512;  // 8 waves: two per SIMD so one wave's tanh/VALU overlaps the other's MFMAs

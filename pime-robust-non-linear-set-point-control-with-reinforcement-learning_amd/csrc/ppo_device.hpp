@@ -36,6 +36,26 @@ __host__ __device__ inline BwdLayout bwd_layout(int kind, int D, int Di, int md)
     return L;
 }
 
+// nn.Linear layout -> backward image (bwd_layout order)
+__device__ inline void pack_backward_image(const PackArgs& a, float* __restrict__ out, int tid, int nthr) {
+    const BwdLayout L = bwd_layout(a.kind, a.D, a.Di, a.md);
+    const int T = L.T;
+    if (a.kind == MLP_MODULAR_ACTOR) {
+        const int Do = a.D - a.Di, H = T / 2;
+        pack_first(out + L.off[0], a.p[0], a.p[1], Do, Do, 0, T, tid, nthr);
+        pack_first(out + L.off[1], a.p[4], a.p[5], a.Di, a.Di, 0, T, tid, nthr);
+        pack_vec(out + L.off[2], a.p[10], T, tid, nthr);
+        pack_mfma_t(out + L.off[3], a.p[8], T, T, tid, nthr);
+        pack_mfma_t(out + L.off[4], a.p[2], H, T, tid, nthr);
+        pack_mfma_t(out + L.off[5], a.p[6], H, T, tid, nthr);
+    } else {
+        pack_first(out + L.off[0], a.p[0], a.p[1], a.D, a.D, 0, T, tid, nthr);
+        pack_vec(out + L.off[1], a.p[6], T, tid, nthr);
+        pack_mfma_t(out + L.off[2], a.p[4], T, T, tid, nthr);
+        pack_mfma_t(out + L.off[3], a.p[2], T, T, tid, nthr);
+    }
+}
+
 // ---- workspace ------------------------------------------------------------------------------------------------------
 // stash[(tile * NT + t) * 1024 + r * 64 + lane]: register r of lane `lane` of stashed tile t of sample-tile `tile`.
 // critic / plain actor, NT = 5T:  H2 [0,T)  H3 [T,2T)  dZ3 [2T,3T)  dZ2 [3T,4T)  dZ1 [4T,5T)

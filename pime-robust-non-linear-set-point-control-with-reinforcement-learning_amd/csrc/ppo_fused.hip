@@ -851,6 +851,31 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
     }
 }
 
+// ==================================================================================================== re-pack
+// After an optimizer step both nets' forward and transposed images are stale: one launch re-lays all four
+// (blockIdx.y: critic fwd, critic bwd, actor fwd, actor bwd) instead of four ~5 us launches per step.
+struct RepackArgs {
+    PackArgs net[2];
+    float* img[4];
+};
+
+__global__ void ppo_repack_kernel(RepackArgs a) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+    const PackArgs& n = a.net[blockIdx.y >> 1];
+    if (blockIdx.y & 1) pack_backward_image(n, a.img[blockIdx.y], tid, nthr);
+    else pack_forward_image(n, a.img[blockIdx.y], tid, nthr);
+}
+
+int launch_repack(const PackArgs& critic, const PackArgs& actor, float* c_fwd, float* c_bwd, float* a_fwd, float* a_bwd,
+                  hipStream_t s) {
+    RepackArgs r{};
+    r.net[0] = critic; r.net[1] = actor;
+    r.img[0] = c_fwd; r.img[1] = c_bwd; r.img[2] = a_fwd; r.img[3] = a_bwd;
+    hipLaunchKernelGGL(ppo_repack_kernel, dim3(32, 4), dim3(256), 0, s, r);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
 int fused_grid(int B) {
     const int ntiles = (B + 31) / 32;
     int grid = (ntiles + kFusedWaves - 1) / kFusedWaves;

@@ -23,30 +23,11 @@
 namespace pime {
 
 
-struct PackBwdArgs {
-    const float* p[12];
-    int kind, D, Di, md;
-};
+using PackBwdArgs = PackArgs;
 
 __global__ void mlp_pack_bwd_kernel(PackBwdArgs a, float* __restrict__ out) {
-    const BwdLayout L = bwd_layout(a.kind, a.D, a.Di, a.md);
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x, T = L.T;
-    if (a.kind == MLP_MODULAR_ACTOR) {
-        const int Do = a.D - a.Di, H = T / 2;
-        pack_first(out + L.off[0], a.p[0], a.p[1], Do, Do, 0, T, tid, nthr);
-        pack_first(out + L.off[1], a.p[4], a.p[5], a.Di, a.Di, 0, T, tid, nthr);
-        pack_vec(out + L.off[2], a.p[10], T, tid, nthr);
-        pack_mfma_t(out + L.off[3], a.p[8], T, T, tid, nthr);
-        pack_mfma_t(out + L.off[4], a.p[2], H, T, tid, nthr);
-        pack_mfma_t(out + L.off[5], a.p[6], H, T, tid, nthr);
-    } else {
-        pack_first(out + L.off[0], a.p[0], a.p[1], a.D, a.D, 0, T, tid, nthr);
-        pack_vec(out + L.off[1], a.p[6], T, tid, nthr);
-        pack_mfma_t(out + L.off[2], a.p[4], T, T, tid, nthr);
-        pack_mfma_t(out + L.off[3], a.p[2], T, T, tid, nthr);
-    }
+    pack_backward_image(a, out, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
-
 
 constexpr int kTrainThreads = 512;
 

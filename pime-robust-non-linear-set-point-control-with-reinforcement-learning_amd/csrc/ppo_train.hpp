@@ -4,6 +4,11 @@
 
 namespace pime {
 
+struct PackArgs {
+    const float* p[12];   // nn.Linear (W, b) pairs in module order
+    int kind, D, Di, md;
+};
+
 struct PpoArgs {
     const float *state, *action, *logprob, *adv, *r_sum;  // flat trajectory buffers, rows = transitions
     const int64_t* indices;                               // [B] minibatch rows

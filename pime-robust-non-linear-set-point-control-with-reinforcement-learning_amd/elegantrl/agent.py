@@ -325,9 +325,11 @@ class AgentPPO(AgentBase):
             self._log_losses(*mean)
         return float(obj_actor.detach()), float(obj_critic.detach())
 
-    def _minibatch_indices(self, step, buf_len, batch_size, dev):
+    def _minibatch_indices(self, step, buf_len, batch_size, dev, out=None):
         if self.index_hook is not None:
             return self.index_hook(step, buf_len, batch_size).to(dev)
+        if out is not None:   # same draws, written where the captured graph reads them (saves a copy launch per step)
+            return torch.randint(buf_len, size=(batch_size,), device=dev, out=out)
         return torch.randint(buf_len, size=(batch_size,), device=dev)              # agent.py:630
 
     @staticmethod
@@ -384,7 +386,8 @@ class AgentPPO(AgentBase):
         st.scale_sum.zero_()
         last = None
         for step in range(n_steps):
-            indices = self._minibatch_indices(step, buf_len, batch_size, dev)
+            replaying = self.use_hip_graphs and st.warm and st.graph_a is not None
+            indices = self._minibatch_indices(step, buf_len, batch_size, dev, out=st.idx if replaying else None)
             if step == n_steps - 1:
                 last = fused.loss_sums.clone()
             use_graph = self.use_hip_graphs and st.warm
@@ -403,7 +406,8 @@ class AgentPPO(AgentBase):
                     self.use_hip_graphs = use_graph = False
                     torch.cuda.synchronize(dev)
             if use_graph:
-                st.idx.copy_(indices)
+                if indices is not st.idx:
+                    st.idx.copy_(indices)
                 run = st.graph_a.replay
             else:
                 run = lambda: grads(indices)  # noqa: E731

@@ -187,14 +187,13 @@ class FusedPPOGrad:
         return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
     def repack(self):
-        """Re-lay both nets' weights into the forward / transposed LDS images (after every optimizer step)."""
-        L = native.lib()
+        """Re-lay both nets' weights into the forward / transposed LDS images (after every optimizer step): one launch."""
+        if self._structs is None:
+            self._build_structs()
+        actor, critic, _ = self._structs
         with torch.cuda.device(self.device):
-            s = _stream(self.flat_grad)
-            for net in self.nets:
-                arr = self._ptr_array([p.detach() for p in net["plist"]])
-                native.check(L.pime_mlp_pack(net["kind"], net["D"], net["Di"], net["md"], arr, native.ptr(net["img_fwd"]), s))
-                native.check(L.pime_ppo_pack_bwd(net["kind"], net["D"], net["Di"], net["md"], arr, native.ptr(net["img_bwd"]), s))
+            native.check(native.lib().pime_ppo_repack(C.byref(actor), C.byref(critic), _stream(self.flat_grad)),
+                         "pime_ppo_repack")
 
     def _build_structs(self):
         out = []
