@@ -81,9 +81,10 @@ class KernelTimer:
 
 def pmc_traffic_bytes(kernel_prefixes):
     """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/
-    r01_c_pmc_hbm_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters
-    cannot be read from inside the process, so this is the measured figure of the same command, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
+    r01_h_pmc_hbm_traffic.json, produced by tools/pmc_traffic.sh on this bench; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read from inside the process, so this is the
+    measured figure of the same command, or None."""
+    path = os.path.join(ROOT, "profiles", "r01_h_pmc_hbm_traffic.json")
     if not os.path.exists(path):
         return None
     data = json.load(open(path))
@@ -280,13 +281,13 @@ def main():
     n_dom, ms_dom = ks[dominant]
     if dominant == "ppo_minibatch_grad":
         achieved = GRAD_FLOPS_PER_SAMPLE * BATCH / (ms_dom * 1e-3) / 1e12
-        roofline = {"kernel": "ppo_minibatch_grad = ppo_fwd_bwd_kernel<critic> + ppo_fwd_bwd_kernel<modular_actor> + "
-                              "ppo_dw_kernel + critic_scale_kernel (one minibatch of 65536; per-kernel split in "
-                              "profiles/)", "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                    "traffic": pmc_traffic_bytes(["ppo_fwd_bwd_kernel<4, 0>", "ppo_fwd_bwd_kernel<4, 2>", "ppo_dw_kernel",
-                                                  "critic_scale_kernel"]),
-                    "traffic_source": "profiles/r01_c_pmc_hbm_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2)",
+        roofline = {"kernel": "ppo_minibatch_grad = ppo_fused_kernel<critic> + ppo_fused_kernel<modular_actor> + "
+                              "ppo_grad_reduce_kernel (one minibatch of 65536: forward, loss, backward and weight "
+                              "gradients; per-kernel split in profiles/)", "bound": "mfma", "achieved": achieved,
+                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                    "traffic": pmc_traffic_bytes(["ppo_fused_kernel<4, 0>", "ppo_fused_kernel<4, 2>",
+                                                  "ppo_grad_reduce_kernel"]),
+                    "traffic_source": "profiles/r01_h_pmc_hbm_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2)",
                     "launches_per_step": n_dom / args.steps, "avg_launch_ms": ms_dom,
                     "algorithmic_flops_per_launch": GRAD_FLOPS_PER_SAMPLE * BATCH}
     elif "critic" in dominant or "actor" in dominant:

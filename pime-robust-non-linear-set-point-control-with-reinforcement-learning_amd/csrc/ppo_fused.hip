@@ -36,7 +36,7 @@ __host__ __device__ constexpr int tpitch(int nt) { return nt * 32 + 4; }
 __host__ __device__ constexpr int tsize(int nt) { return 32 * tpitch(nt); }   // floats of one 32-sample tile image
 
 struct FusedLds {
-    int first0, first1, bias[3], headw, headb, xs, hacc, wbuf, x, total;
+    int first0, first1, bias[3], headw, headb, xs, hacc, wsum, wbuf, x, total;
 };
 
 __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
@@ -62,6 +62,7 @@ __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
     seg(F.headb, 4);
     seg(F.xs, kFusedWaves * 32 * D);   // the group's gathered states [wave][sample][D]
     seg(F.hacc, kFusedWaves * md);     // per-wave head weight gradients (summed in wave order at the end)
+    seg(F.wsum, kFusedWaves * 6 * 2);  // per-wave float64 totals of the scalar sums
     seg(F.wbuf, T * T * 1024);
     // X: two (A+B) buffers of the widest job that keeps W alive (2T blocks each); the merged modular jobs (3T and 2T+1
     // blocks per buffer) run while W is dead and use W and X as one region
@@ -470,8 +471,10 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 reinterpret_cast<float4*>(dst[k])[i] = reinterpret_cast<const float4*>(src[k])[i];
         }
     }
-    float s0 = 0.f, s1 = 0.f, gstd = 0.f, ghb = 0.f;
-    double m1 = 0.0, m2 = 0.0;
+    // scalar sums (losses, d/d a_std_log, head bias gradient, target moments): reduced over the wave right where they
+    // are produced and kept in LDS, not in loop-carried registers (which hipcc spills around the MFMA phases)
+    double* const wsum = reinterpret_cast<double*>(lds + F.wsum);   // [wave][6]
+    if (tid < kFusedWaves * 6) wsum[tid] = 0.0;
 
 #pragma unroll 1
     for (int group = blockIdx.x; group < ngroups; group += gridDim.x) {
@@ -558,6 +561,8 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
         }
         PIME_MARK(2);
         float dout = 0.f;
+        float s0 = 0.f, s1 = 0.f, gstd = 0.f;
+        double m1 = 0.0, m2 = 0.0;
         if (valid) {
             if constexpr (CRITIC) {
                 const float d = y - in_rsum, ad = fabsf(d);         // SmoothL1, beta = 1 (agent.py:567,649)
@@ -565,9 +570,9 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 const float g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
                 dout = g * invB;  // unscaled: critic_scale_kernel applies 1/(std+1e-5) to the finished gradients
                 if (h == 0) {
-                    s0 += l;
-                    m1 += (double)in_rsum;
-                    m2 += (double)in_rsum * (double)in_rsum;
+                    s0 = l;
+                    m1 = (double)in_rsum;
+                    m2 = (double)in_rsum * (double)in_rsum;
                 }
             } else {
                 const float asl = a.a_std_log[0], inv_sigma = __expf(-asl);
@@ -587,13 +592,23 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 const float g_logp = (-g_sur + a.lambda_entropy * p * (logp + 1.f)) * invB;
                 dout = g_logp * (-z * inv_sigma);
                 if (h == 0) {
-                    gstd += g_logp * (z * z - 1.f);
-                    s0 += -fminf(u, c);
-                    s1 += ent;
+                    gstd = g_logp * (z * z - 1.f);
+                    s0 = -fminf(u, c);
+                    s1 = ent;
                 }
             }
         }
-        if (h == 0) ghb += dout;  // head bias gradient
+        {
+            float ghb = h == 0 ? dout : 0.f;   // head bias gradient
+            s0 = wave_sum(s0); s1 = wave_sum(s1); gstd = wave_sum(gstd); ghb = wave_sum(ghb);
+            if constexpr (CRITIC) {
+                for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+            }
+            if (lane == 0) {
+                double* w = wsum + wave * 6;
+                w[0] += s0; w[1] += s1; w[2] += gstd; w[3] += ghb; w[4] += m1; w[5] += m2;
+            }
+        }
         // Head: dZ of the last hidden layer, and the head weight gradient gW[f] += sum_s dOut[s] * H_last[s][f].  H_last
         // is still in registers; the sum over the tile's samples is a DPP reduction over the lanes.
         {
@@ -738,16 +753,6 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     PIME_MARK(12);
     // ---- workgroup totals of the scalar sums, combined in a fixed order (the slabs make the gradients reproducible
     // bit for bit; only the loss sums, which are for logging, use atomics)
-    s0 = wave_sum(s0); s1 = wave_sum(s1); gstd = wave_sum(gstd); ghb = wave_sum(ghb);
-    if constexpr (CRITIC) {
-        for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
-    }
-    double* const wsum = reinterpret_cast<double*>(X);  // [wave][6]
-    __syncthreads();
-    if ((tid & 63) == 0) {
-        double* w = wsum + wave * 6;
-        w[0] = s0; w[1] = s1; w[2] = gstd; w[3] = ghb; w[4] = m1; w[5] = m2;
-    }
     __syncthreads();
     float* const sl = a.slab + (size_t)blockIdx.x * a.slab_stride;
     constexpr int NP = MODULAR ? 12 : 8;
