@@ -190,11 +190,14 @@ int pime_mlp_forward(int32_t kind, const float* x, int32_t M, int32_t D, int32_t
  * replaces, per optimizer step of AgentPPO.update_net (elegantrl/agent.py:629-657): the minibatch gather (:632-636),
  * compute_logprob of the residual actors (net_residual.py:48-54,182-190), the clipped surrogate + entropy proxy
  * (:637-645), CriticAdv forward + SmoothL1 (:648-649), the united loss (:652) and `obj_united.backward()` (:654-655)
- * -- i.e. everything between drawing the indices and `optimizer.step()`, which stays in PyTorch.
- * Four launches: critic fwd+bwd, actor fwd+bwd, one weight-gradient kernel, critic-gradient scaling (csrc/ppo_train.hip).
+ * -- i.e. everything between drawing the indices and `optimizer.step()` (pime_adam_step or torch.optim.Adam).
+ * Three launches (csrc/ppo_fused.hip): one kernel per net that forms forward, loss gradient, backward chain and the
+ * weight gradients of a 256-sample group per workgroup and stores them as a per-workgroup slab, and one reduction of the
+ * slabs in a fixed order (bit-for-bit reproducible gradients) that also applies the critic scale.  Observations too wide
+ * for that kernel's LDS map use the older net + dW + scale kernels (csrc/ppo_train.hip, float atomics).
  *
  * pime_ppo_net describes one net: the same (kind, D, Di, md, params) as pime_mlp_pack; `grads` are the .grad tensors in
- * the same order and are ACCUMULATED into with float atomics (zero them first); img_fwd = pime_mlp_pack image,
+ * the same order and are ACCUMULATED into (zero them first); img_fwd = pime_mlp_pack image,
  * img_bwd = pime_ppo_pack_bwd image (both must be re-packed after the weights change); workspace =
  * pime_ppo_workspace_floats(kind, B, md) floats.  action_dim must be 1. */
 typedef struct pime_ppo_net {
@@ -227,7 +230,7 @@ int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const flo
 int pime_ppo_repack(const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream);
 /* critic_scale: [dev] float32[1], WRITTEN: 1 / (r_sum[indices].std() + 1e-5) with torch's unbiased std (agent.py:652);
  *               the critic's gradients are multiplied by it (fourth, tiny launch)
- * moments:      [dev] float64[2] scratch (zeroed by the call)
+ * moments:      [dev] float64[2], WRITTEN: sum and sum of squares of the minibatch targets r_sum[indices]
  * loss_sums:    [dev] float32[4], ACCUMULATED: sum(-min(surr1,surr2)), sum(exp(logp)*logp), sum(smooth_l1), unused */
 int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* batch,
                             float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
