@@ -111,6 +111,9 @@ class OraclePH:
             _lib.oracle_ph_destroy(self._h)
             self._h = None
 
+    def set_ranges(self, qww_V, qc_V):
+        lib().oracle_ph_set_ranges(self._h, *(C.c_double(v) for v in (*qww_V, *qc_V)))
+
     def set_punish(self, integral=0.0, action=0.0, action_change=0.0):
         lib().oracle_ph_set_punish(self._h, C.c_double(integral), C.c_double(action), C.c_double(action_change))
 
@@ -156,6 +159,9 @@ class OracleWT:
         if getattr(self, "_h", None) and lib is not None and _lib is not None:
             _lib.oracle_wt_destroy(self._h)
             self._h = None
+
+    def set_ranges(self, a1, a2, Kp):
+        lib().oracle_wt_set_ranges(self._h, *(C.c_double(v) for v in (*a1, *a2, *Kp)))
 
     def set_punish(self, integral=0.0):
         lib().oracle_wt_set_punish(self._h, C.c_double(integral))

@@ -145,6 +145,11 @@ ORACLE_API oracle_ph* oracle_ph_create(int n, int max_steps, int reward_type, in
     return e;
 }
 
+/* ensemble ranges of sample_parameters (ph.py:409-411): gym.make kwargs qww_V / qc_V (gym_control/__init__.py) */
+ORACLE_API void oracle_ph_set_ranges(oracle_ph* e, double qww_lo, double qww_hi, double qc_lo, double qc_hi) {
+    e->qww_lo = qww_lo; e->qww_hi = qww_hi; e->qc_lo = qc_lo; e->qc_hi = qc_hi;
+}
+
 ORACLE_API void oracle_ph_set_punish(oracle_ph* e, double integral_punish, double action_punish,
                                      double action_change_punish) {
     e->integral_punish = integral_punish; e->action_punish = action_punish;
@@ -283,6 +288,12 @@ ORACLE_API oracle_wt* oracle_wt_create(int n, int max_steps, int reward_type, in
     e->episode = (int32_t*)calloc((size_t)n, sizeof(int32_t));
     for (int i = 0; i < n; ++i) e->episode[i] = -1;
     return e;
+}
+
+/* ensemble ranges of sample_parameters (nonlinear_watertank.py:890-895): gym.make kwargs a1 / a2 / Kp */
+ORACLE_API void oracle_wt_set_ranges(oracle_wt* e, double a1_lo, double a1_hi, double a2_lo, double a2_hi, double kp_lo,
+                                     double kp_hi) {
+    e->a1_lo = a1_lo; e->a1_hi = a1_hi; e->a2_lo = a2_lo; e->a2_hi = a2_hi; e->kp_lo = kp_lo; e->kp_hi = kp_hi;
 }
 
 ORACLE_API void oracle_wt_destroy(oracle_wt* e) {

@@ -341,3 +341,55 @@ def test_ragged_lane_counts_and_masked_reset(table, N):
     w_obs, _, w_rew, _ = rw.step(a)
     np.testing.assert_allclose(_np(obs), w_obs, rtol=2e-7)
     wt.close()
+
+
+def test_mixed_ph_and_tank_batch_wide_ensemble(table):
+    """BASELINE.json config 5 as a parity case (cfg 5): a pH batch and a water-tank batch advanced
+    side by side on two HIP streams, ensemble ranges 1.5x wider than the registered ones (domain-randomised sweep), in-kernel
+    Philox resets and per-episode resampling, against the oracle with the same ranges.  State storage is float32
+    (PIME_STATE_MIXED); the float16 storage of that config is not built.  The pH range keeps
+    C*x inside the 100 000-entry titration table (the reference raises IndexError beyond it)."""
+    from pime_amd.vec_env import VecPH, VecWaterTank
+    N, seed = 2048, 4242
+    qww, qc = (0.0045, 0.0165), (0.00125, 0.00275)
+    a1 = a2 = (0.0012, 0.0027)
+    kp = (0.045, 0.195)
+    s_ph, s_wt = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
+    with torch.cuda.stream(s_ph):
+        ph = VecPH(N, device=DEV, state_mode="mixed", seed=seed, qww_V=qww, qc_V=qc)
+        o_ph = ph.reset()
+    with torch.cuda.stream(s_wt):
+        wt = VecWaterTank(N, device=DEV, state_mode="mixed", seed=seed + 1, reward_type="distance", max_step=30, a1=a1, a2=a2,
+                          Kp=kp)
+        o_wt = wt.reset()
+    r_ph = oracle.OraclePH(N, table, seed=seed)
+    r_ph.set_ranges(qww, qc)
+    r_wt = oracle.OracleWT(N, max_steps=30, reward_type="distance", seed=seed + 1)
+    r_wt.set_ranges(a1, a2, kp)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_np(o_ph), r_ph.reset())
+    np.testing.assert_allclose(_np(o_wt), r_wt.reset(), rtol=0, atol=0)
+    for f, rng_ in (("qww_V", qww), ("qc_V", qc)):
+        v = ph.get_field(f)
+        np.testing.assert_array_equal(v, r_ph.get(f))
+        assert v.min() >= rng_[0] and v.max() <= rng_[1] and v.max() - v.min() > 0.9 * (rng_[1] - rng_[0])
+    rng = np.random.RandomState(11)
+    for t in range(110):   # > 2 pH episodes, > 3 tank episodes: resampled plants on every lane
+        a_ph, a_wt = rng.uniform(-1.2, 1.2, N), rng.uniform(-1.5, 1.5, N)
+        with torch.cuda.stream(s_ph):
+            g_ph = ph.step(_t(a_ph), auto_reset=True)
+        with torch.cuda.stream(s_wt):
+            g_wt = wt.step(_t(a_wt), auto_reset=True)
+        torch.cuda.synchronize()
+        w_obs, _, w_rew, w_done = r_ph.step(a_ph, auto_reset=True)
+        np.testing.assert_array_equal(_np(g_ph[2]).astype(bool), w_done)
+        np.testing.assert_allclose(ph.get_field("x"), r_ph.get("x"), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(_np(g_ph[0]), w_obs, rtol=3e-5, atol=3e-5)
+        np.testing.assert_allclose(_np(g_ph[1]), w_rew, rtol=3e-5, atol=3e-5)
+        w_obs, _, w_rew, w_done = r_wt.step(a_wt, auto_reset=True)
+        np.testing.assert_array_equal(_np(g_wt[2]).astype(bool), w_done)
+        np.testing.assert_allclose(_np(g_wt[0]), w_obs, rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(_np(g_wt[1]), w_rew, rtol=2e-4, atol=2e-4)
+    np.testing.assert_array_equal(ph.get_field("qww_V"), r_ph.get("qww_V"))
+    np.testing.assert_allclose(wt.get_field("Kp"), r_wt.get("Kp"), rtol=1e-7)
+    ph.close(); wt.close()
