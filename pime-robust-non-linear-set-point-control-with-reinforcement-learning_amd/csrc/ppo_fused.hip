@@ -396,6 +396,52 @@ __device__ __forceinline__ void first_times_act_grad(const float* __restrict__ w
     }
 }
 
+// First-layer weight / bias gradient for a fan-in of a few columns, on the vector ALUs:
+//   gW[f][j] = sum over the group's 256 samples of dZ[s][f] * x[s][j],   gb[f] = sum_s dZ[s][f].
+// As a matrix job this is a 32-column product of which Din columns are real (90 % wasted MFMA work in eight
+// barrier-separated rounds).  Here four waves at a time publish their dZ tiles (two super-rounds), thread (f, q) reads
+// its feature's column for a quarter of each tile's samples, and the 2*Q partial sums per element are combined in a fixed
+// order (reproducible).  part: 2*Q*R*(Din+1) floats of scratch LDS.
+constexpr int kFirstValuMaxD = 8;
+template <int T>
+__device__ __forceinline__ void first_grad_valu(float* __restrict__ X, float* __restrict__ part, int lane, int wave,
+                                                const f32x16 (&dz)[T], const float* __restrict__ xs, int D, int col0,
+                                                int Din, float* __restrict__ gW, float* __restrict__ gb, bool accum) {
+    constexpr int R = T * 32, Q = kFusedThreads / R, SPQ = 32 / Q, TSZ = tsize(T);
+    const int tid = wave * 64 + lane, o = tid % R, q = tid / R;
+#pragma unroll 1
+    for (int sr = 0; sr < 2; ++sr) {
+        PIME_LDS_BARRIER();  // X free
+        if ((wave >> 2) == sr) put_tile<T>(X + (wave & 3) * TSZ, lane, dz);
+        PIME_LDS_BARRIER();
+        float av[4 * SPQ];
+#pragma unroll
+        for (int slot = 0; slot < 4; ++slot)
+#pragma unroll
+            for (int i = 0; i < SPQ; ++i) av[slot * SPQ + i] = X[slot * TSZ + (q * SPQ + i) * tpitch(T) + o];
+#pragma unroll 1
+        for (int j = 0; j <= Din; ++j) {   // j == Din: the bias (x = 1)
+            float acc = 0.f;
+#pragma unroll
+            for (int slot = 0; slot < 4; ++slot)
+#pragma unroll
+                for (int i = 0; i < SPQ; ++i) {
+                    const float xv = j < Din ? xs[((sr * 4 + slot) * 32 + q * SPQ + i) * D + col0 + j] : 1.0f;
+                    acc = fmaf(av[slot * SPQ + i], xv, acc);
+                }
+            part[((sr * Q + q) * (Din + 1) + j) * R + o] = acc;
+        }
+    }
+    PIME_LDS_BARRIER();
+    for (int e = tid; e < R * (Din + 1); e += kFusedThreads) {
+        const int j = e / R, f = e % R;
+        float t = 0.f;
+        for (int p = 0; p < 2 * Q; ++p) t += part[(p * (Din + 1) + j) * R + f];
+        float* qd = j < Din ? &gW[f * Din + j] : &gb[f];
+        *qd = accum ? *qd + t : t;
+    }
+}
+
 // Sum of v over the 32 lanes of this lane's half; valid in lanes 31 and 63.
 __device__ __forceinline__ float half_sum_dpp(float v) {
 #define PIME_DPP_ADD(x, ctrl, row_mask) \
@@ -690,7 +736,12 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                                            *reinterpret_cast<f32x16(*)[T]>(&d1[T]));
                 first_times_act_grad<T, 1>(lds + F.first1, xl + Do, a.Di, h, *reinterpret_cast<f32x16(*)[T]>(&d1[T]));  // dZi1
                 PIME_MARK(10);
-                {
+                if (a.D <= kFirstValuMaxD) {   // other_net.0, integrator_net.0 on the vector ALUs
+                    first_grad_valu<T>(X, wbuf, lane, wave, *reinterpret_cast<f32x16(*)[T]>(&d1[0]), xs, a.D, 0, Do,
+                                       sl + a.poff[0], sl + a.poff[1], accum);
+                    first_grad_valu<T>(X, wbuf, lane, wave, *reinterpret_cast<f32x16(*)[T]>(&d1[T]), xs, a.D, Do, a.Di,
+                                       sl + a.poff[4], sl + a.poff[5], accum);
+                } else {
                     // matrix form: A = [dZo1 | dZi1], B = the state columns (one tile); wave w owns A tile w; its
                     // product's columns [0,Do) or [Do,D) are the wanted gradient
                     f32x16 acc[DwPlan<2 * T, 1>::PER];
@@ -743,10 +794,14 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             layer_mfma<T, T, 2, false>(wbuf, nullptr, lane, d2, d);
             first_times_act_grad<T, ACT>(lds + F.first0, xl, a.D, h, d);                            // dZ1 (H1 again)
             PIME_MARK(8);
-            f32x16 acc[DwPlan<T, 1>::PER];
-            float bsum;
-            dw_rounds<T, 1>(X, lane, wave, d, StateB{xs, a.D, a.D, 0}, acc, bsum, nullptr, nullptr, 0);
-            dw_store<T, 1>(lane, wave, acc, bsum, sl + a.poff[0], a.D, md, a.D, sl + a.poff[1], accum);        // net.0
+            if (a.D <= kFirstValuMaxD) {   // net.0 on the vector ALUs (W is dead: its LDS holds the partial sums)
+                first_grad_valu<T>(X, wbuf, lane, wave, d, xs, a.D, 0, a.D, sl + a.poff[0], sl + a.poff[1], accum);
+            } else {
+                f32x16 acc[DwPlan<T, 1>::PER];
+                float bsum;
+                dw_rounds<T, 1>(X, lane, wave, d, StateB{xs, a.D, a.D, 0}, acc, bsum, nullptr, nullptr, 0);
+                dw_store<T, 1>(lane, wave, acc, bsum, sl + a.poff[0], a.D, md, a.D, sl + a.poff[1], accum);    // net.0
+            }
         }
     }
 
