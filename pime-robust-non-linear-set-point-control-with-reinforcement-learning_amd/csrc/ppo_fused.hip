@@ -7,21 +7,25 @@
 //
 // Why: the split design (ppo_train.hip) stashes every dZ_l and H_l in HBM (2.5-3 KB per sample and net) and re-reads
 // them in a separate TN-GEMM kernel; profiles/r01_c_pmc_hbm_traffic.json shows ~1 GB of HBM traffic per minibatch and
-// the matrix pipe 33-47 % busy, i.e. the pipeline sits on the MFMA/HBM ridge.  Here only the two hidden activations
-// the backward needs (1 KB per sample and net) round-trip through HBM/L2, and they are read back by the wave that
-// wrote them.
+// the matrix pipe 33-47 % busy, i.e. the pipeline sits on the MFMA/HBM ridge.  Here only ONE hidden activation per
+// sample and net (1 KB) round-trips through HBM/L2, read back by the workgroup that wrote it (0.5 GB per minibatch,
+// profiles/r01_h_pmc_hbm_traffic.json).
 //
-// Workgroup = 8 waves = 8 tiles of 32 samples.  LDS map: S (first-layer images, biases, head, the group's states),
-// W (one md x md MFMA image), X (2 x 2T transposition blocks of [32][33]; during the forward it holds the second
-// MFMA image).  Per layer l of the backward:
-//   dW_l = dZ_l^T H_{l-1}: eight rounds, round t multiplies tile t.  The owning wave writes dZ_l / H_{l-1} (sample on
-//          the lane) into X feature-major with a 33-float pitch, so all eight waves can read them back as MFMA operands
-//          with the SAMPLE index on k (conflict-free both ways); every wave owns 1/8 of the output blocks and keeps
-//          them in accumulators for the eight rounds, then adds them into the gradient tensor with float atomics.
-//          X is double buffered (one barrier per round); the next layer's transposed weight image is copied into W
-//          one slice per round, behind the MFMAs.  The bias gradient is the sum of the A operands a wave reads anyway.
+// Workgroup = 8 waves = 8 tiles of 32 samples.  LDS map: S (first-layer images, biases, head, the group's states,
+// per-wave partial sums), W (one md x md MFMA image), X (two sample-major transposition buffers; during the forward it
+// holds the second MFMA image).  The last hidden layer stays in registers across the loss: its dZ is formed in place and
+// the head weight gradient is a DPP lane reduction.  Per earlier layer l of the backward:
+//   dW_l = dZ_l^T H_{l-1}: eight rounds, round t multiplies tile t (dw_rounds).  The owning wave publishes its dZ_l tile,
+//          ALL waves publish 1/8 of the matching H_{l-1} tile each (from the stash, fetched two rounds ahead, or
+//          recomputed from the group's states for a first-layer activation); every wave owns 1/8 of the output blocks
+//          in accumulators for the eight rounds.  X is double buffered (one LDS-only barrier per round); the next
+//          layer's transposed weight image is copied into W one slice per round, behind the MFMAs.  The bias gradient
+//          is the sum of the A operands a wave reads anyway.
 //   dH_{l-1} = W_l^T dZ_l: the forward chain code with the transposed image (mlp_device.hpp).
-// First-layer and head gradients (fan-in / fan-out of a few floats) are row reductions over the same X tiles.
+// First-layer gradients (fan-in of a few floats) run on the vector ALUs from the same transposed tiles.
+// Every workgroup stores its partial gradient into its own slab (no atomics: memory-side float atomics cost 0.5 TB/s
+// here); ppo_grad_reduce_kernel sums the slabs in slab order, so gradients are reproducible bit for bit.
+// PIME_FUSED_TRACE=<workgroup> prints wall-clock phase marks of that workgroup (tuning aid, not a production path).
 #include "ppo_device.hpp"
 #include "ppo_train.hpp"
 
