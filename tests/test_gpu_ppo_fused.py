@@ -67,7 +67,9 @@ def _torch_grads(act, cri, state, action, logprob, adv, r_sum, idx, clip, lam):
                                          ("modular", 128, 3, 65536),
                                          ("modular", 128, 3, 70000),   # > 256 sample groups: workgroups accumulate a 2nd group
                                          ("resid", 128, 30, 2048),     # stacked-tank width: LDS map does not fit -> split pipeline
-                                         ("modular", 128, 6, 3000)])
+                                         ("modular", 128, 6, 3000),
+                                         ("modular", 128, 10, 2048),   # first-layer gradients in matrix form (fan-in > 8)
+                                         ("resid", 128, 10, 1500)])
 def test_fused_gradients_match_autograd(kind, md, D, B):
     from pime_amd import ops
     act, cri = _make(kind, md, D, seed=B + md)
