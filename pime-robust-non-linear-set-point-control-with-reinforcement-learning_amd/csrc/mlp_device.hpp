@@ -156,17 +156,16 @@ __device__ __forceinline__ void stage_image(float* __restrict__ lds, const float
     }
 }
 
-// tanh in ~12 VALU ops with few live temporaries (ocml's tanhf inlined 64x per layer drove the kernel to the
-// 256-VGPR cap).  |x| >= 0.25: 1 - 2/(e^{2|x|}+1) via v_exp_f32/v_rcp_f32 (abs err < 1.5e-7); below that the
-// cancellation is avoided with the odd Taylor polynomial to x^9 (rel err < 1e-7 at 0.25).
+// tanh for the hidden layers in 7 VALU ops, two of them transcendental (ocml's tanhf inlined 64x per layer drove the
+// kernel to the 256-VGPR cap and is ~40 ops): 1 - 2/(e^{2|x|}+1) via v_exp_f32 / v_rcp_f32, sign restored.  Absolute
+// error < 1.5e-7 everywhere; the RELATIVE error grows below |x| ~ 1e-3 (cancellation against 1), which is immaterial
+// for a hidden unit that feeds a dot product (an earlier version avoided it with a 9th-order polynomial branch for
+// |x| < 0.25: +6 VALU ops per activation, ~10 us per actor gradient kernel, no measurable change in any parity test).
+// The ENV action tanh (agent_residual.py:61) does not use this: it is ocml tanhf, as numpy's within 1 ulp.
 __device__ __forceinline__ float fast_tanh(float x) {
     const float ax = fabsf(x);
-    const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);  // e^{2|x|}
-    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    const float x2 = x * x;
-    const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.021869488536155203f, -0.053968253968253971f),
-                                                   0.13333333333333333f), -0.33333333333333331f), 1.0f);
-    const float t = ax < 0.25f ? small : big;
+    const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);  // e^{2|x|}  (inf for |x| > 44: rcp -> 0, t -> 1)
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
     return copysignf(t, x);
 }
 
