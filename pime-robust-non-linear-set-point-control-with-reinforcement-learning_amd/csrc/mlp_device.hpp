@@ -241,6 +241,50 @@ __device__ __forceinline__ void layer_mfma(const float* __restrict__ wp, const f
         for (int r = 0; r < 16; ++r) out[ot][r] = activate<ACT>(out[ot][r]);
 }
 
+// out = act_out( W * act_in(in) + b ): the same layer with the INPUT's activation applied inside the k-loop, in place
+// (afterwards `in` holds the activated values).  A tanh costs ~50 VALU cycles; done in the producing layer's epilogue
+// the 64 of them are exposed, done here each one runs in the shadow of the previous k-step's OT MFMAs (64 cycles each).
+template <int KT, int OT, int ACT_OUT, int ACT_IN, bool HAS_BIAS = true>
+__device__ __forceinline__ void layer_mfma_in(const float* __restrict__ wp, const float* __restrict__ bp, int lane,
+                                              f32x16 (&in)[KT], f32x16 (&out)[OT]) {
+    using Frag = typename WFrag<OT>::type;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = HAS_BIAS ? bp[(ot * 16 + r) * 2 + h] : 0.f;
+    const Frag* wl = reinterpret_cast<const Frag*>(wp) + lane;
+    in[0][0] = activate<ACT_IN>(in[0][0]);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if ((s & 3) == 0) PIME_NO_HOIST();  // bound the W-fragment prefetch depth to 4 k-steps (<= 16 VGPRs)
+            const Frag w = wl[(kt * 16 + s) * 64];
+            const float b = in[kt][s];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+                out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfrag_get(w, ot), b, out[ot], 0, 0, 0);
+            // the next k-step's input, activated while this k-step's MFMAs run
+            constexpr int kLast = KT * 16 - 1;
+            const int nx = kt * 16 + s + 1;
+            if (nx <= kLast) in[nx >> 4][nx & 15] = activate<ACT_IN>(in[nx >> 4][nx & 15]);
+        }
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = activate<ACT_OUT>(out[ot][r]);
+}
+
+template <int NT, int ACT>
+__device__ __forceinline__ void activate_tiles(f32x16 (&v)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[t][r] = activate<ACT>(v[t][r]);
+}
+
 template <int KT>
 __device__ __forceinline__ float layer_head(const float* __restrict__ w, float bias, int lane, const f32x16 (&in)[KT]) {
     const int h = lane >> 5;

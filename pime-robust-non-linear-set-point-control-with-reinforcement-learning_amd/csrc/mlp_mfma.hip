@@ -48,30 +48,30 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const float* _
             f32x16 cat[T];  // torch.cat([other_net(..), integrator_net(..)], -1): tiles [0,H) and [H,T)
             {
                 f32x16 a0[T];
-                layer_first<T, 1>(lds + L.off[0], xrow, Do, h, a0);
+                layer_first<T, 2>(lds + L.off[0], xrow, Do, h, a0);   // activations are applied by the consuming layer
                 PIME_NO_HOIST();
-                layer_mfma<T, H, 1>(lds + L.off[1], lds + L.off[2], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
+                layer_mfma_in<T, H, 2, 1>(lds + L.off[1], lds + L.off[2], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
             }
             {
                 f32x16 a0[T];
                 PIME_NO_HOIST();
-                layer_first<T, 1>(lds + L.off[3], xrow + Do, Di, h, a0);
+                layer_first<T, 2>(lds + L.off[3], xrow + Do, Di, h, a0);
                 PIME_NO_HOIST();
-                layer_mfma<T, H, 1>(lds + L.off[4], lds + L.off[5], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
+                layer_mfma_in<T, H, 2, 1>(lds + L.off[4], lds + L.off[5], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
             }
             f32x16 n0[T];
             PIME_NO_HOIST();
-            layer_mfma<T, T, 1>(lds + L.off[6], lds + L.off[7], lane, cat, n0);
+            layer_mfma_in<T, T, 1, 1>(lds + L.off[6], lds + L.off[7], lane, cat, n0);
             PIME_NO_HOIST();
             y = layer_head<T>(lds + L.off[8], lds[L.off[9]], lane, n0);
         } else {
             constexpr int ACT = KIND == MLP_CRITIC ? 0 : 1;
             f32x16 a0[T], a1[T];
-            layer_first<T, ACT>(lds + L.off[0], xrow, D, h, a0);
+            layer_first<T, 2>(lds + L.off[0], xrow, D, h, a0);
             PIME_NO_HOIST();
-            layer_mfma<T, T, ACT>(lds + L.off[1], lds + L.off[2], lane, a0, a1);
+            layer_mfma_in<T, T, 2, ACT>(lds + L.off[1], lds + L.off[2], lane, a0, a1);
             PIME_NO_HOIST();
-            layer_mfma<T, T, ACT>(lds + L.off[3], lds + L.off[4], lane, a1, a0);
+            layer_mfma_in<T, T, ACT, ACT>(lds + L.off[3], lds + L.off[4], lane, a1, a0);
             PIME_NO_HOIST();
             y = layer_head<T>(lds + L.off[5], lds[L.off[6]], lane, a0);
         }

@@ -579,33 +579,33 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             f32x16 cat[T];
             {
                 f32x16 a0[T];
-                layer_first<T, 1>(lds + F.first0, xl, Do, h, a0);
+                layer_first<T, 2>(lds + F.first0, xl, Do, h, a0);   // activations are applied by the consuming layer
                 PIME_NO_HOIST();
-                layer_mfma<T, H, 1>(X, lds + F.bias[0], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
+                layer_mfma_in<T, H, 2, 1>(X, lds + F.bias[0], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
             }
             {
                 f32x16 a0[T];
                 PIME_NO_HOIST();
-                layer_first<T, 1>(lds + F.first1, xl + Do, a.Di, h, a0);
+                layer_first<T, 2>(lds + F.first1, xl + Do, a.Di, h, a0);
                 PIME_NO_HOIST();
-                layer_mfma<T, H, 1>(X + T * H * 1024, lds + F.bias[1], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
+                layer_mfma_in<T, H, 2, 1>(X + T * H * 1024, lds + F.bias[1], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
             }
-            stash_put<T>(st, lane, cat);
             PIME_NO_HOIST();
-            layer_mfma<T, T, 1>(wbuf, lds + F.bias[2], lane, cat, hl);
+            layer_mfma_in<T, T, 1, 1>(wbuf, lds + F.bias[2], lane, cat, hl);   // cat: tanh applied in place
+            stash_put<T>(st, lane, cat);
             PIME_NO_HOIST();
             y = layer_head<T>(lds + F.headw, lds[F.headb], lane, hl);
         } else {
             f32x16 a1[T];
             {
                 f32x16 a0[T];
-                layer_first<T, ACT>(lds + F.first0, xl, a.D, h, a0);
+                layer_first<T, 2>(lds + F.first0, xl, a.D, h, a0);   // activations are applied by the consuming layer
                 PIME_NO_HOIST();
-                layer_mfma<T, T, ACT>(wbuf, lds + F.bias[0], lane, a0, a1);
+                layer_mfma_in<T, T, 2, ACT>(wbuf, lds + F.bias[0], lane, a0, a1);
             }
-            stash_put<T>(st, lane, a1);
             PIME_NO_HOIST();
-            layer_mfma<T, T, ACT>(X, lds + F.bias[1], lane, a1, hl);
+            layer_mfma_in<T, T, ACT, ACT>(X, lds + F.bias[1], lane, a1, hl);     // a1 (H2): activated in place
+            stash_put<T>(st, lane, a1);
             PIME_NO_HOIST();
             y = layer_head<T>(lds + F.headw, lds[F.headb], lane, hl);
         }

@@ -73,29 +73,29 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
             f32x16 cat[T];
             {
                 f32x16 a0[T];
-                layer_first_regs<T, 1, Do>(lds + L.off[0], obs, h, a0);
+                layer_first_regs<T, 2, Do>(lds + L.off[0], obs, h, a0);   // activations are applied by the consuming layer
                 PIME_NO_HOIST();
-                layer_mfma<T, H, 1>(lds + L.off[1], lds + L.off[2], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
+                layer_mfma_in<T, H, 2, 1>(lds + L.off[1], lds + L.off[2], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
             }
             {
                 f32x16 a0[T];
                 PIME_NO_HOIST();
-                layer_first_regs<T, 1, Di>(lds + L.off[3], obs + Do, h, a0);
+                layer_first_regs<T, 2, Di>(lds + L.off[3], obs + Do, h, a0);
                 PIME_NO_HOIST();
-                layer_mfma<T, H, 1>(lds + L.off[4], lds + L.off[5], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
+                layer_mfma_in<T, H, 2, 1>(lds + L.off[4], lds + L.off[5], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
             }
             f32x16 n0[T];
             PIME_NO_HOIST();
-            layer_mfma<T, T, 1>(lds + L.off[6], lds + L.off[7], lane, cat, n0);
+            layer_mfma_in<T, T, 1, 1>(lds + L.off[6], lds + L.off[7], lane, cat, n0);
             PIME_NO_HOIST();
             a_avg = layer_head<T>(lds + L.off[8], lds[L.off[9]], lane, n0);
         } else {
             f32x16 a0[T], a1[T];
-            layer_first_regs<T, 1, D>(lds + L.off[0], obs, h, a0);
+            layer_first_regs<T, 2, D>(lds + L.off[0], obs, h, a0);
             PIME_NO_HOIST();
-            layer_mfma<T, T, 1>(lds + L.off[1], lds + L.off[2], lane, a0, a1);
+            layer_mfma_in<T, T, 2, 1>(lds + L.off[1], lds + L.off[2], lane, a0, a1);
             PIME_NO_HOIST();
-            layer_mfma<T, T, 1>(lds + L.off[3], lds + L.off[4], lane, a1, a0);
+            layer_mfma_in<T, T, 1, 1>(lds + L.off[3], lds + L.off[4], lane, a1, a0);
             PIME_NO_HOIST();
             a_avg = layer_head<T>(lds + L.off[5], lds[L.off[6]], lane, a0);
         }
