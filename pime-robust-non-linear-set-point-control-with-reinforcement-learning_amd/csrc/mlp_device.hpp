@@ -277,6 +277,45 @@ __device__ __forceinline__ void layer_mfma_in(const float* __restrict__ wp, cons
         for (int r = 0; r < 16; ++r) out[ot][r] = activate<ACT_OUT>(out[ot][r]);
 }
 
+// Backward chain step into a FIRST layer: out = (W * in) (.) act'(h1), where h1 = act(v) is the first-layer
+// activation whose pre-activations v the caller recomputed (layer_first<.., 2>).  The OT*16 activations (a tanh is ~50
+// VALU cycles) are evaluated inside the k-loop, in the shadow of the MFMAs, instead of after it.
+template <int KT, int OT, int ACT>
+__device__ __forceinline__ void layer_mfma_gate(const float* __restrict__ wp, int lane, const f32x16 (&in)[KT],
+                                                f32x16 (&out)[OT], f32x16 (&v)[OT]) {
+    using Frag = typename WFrag<OT>::type;
+    constexpr int STEPS = KT * 16, NV = OT * 16, PERK = (NV + STEPS - 1) / STEPS;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = 0.f;
+    const Frag* wl = reinterpret_cast<const Frag*>(wp) + lane;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if ((s & 3) == 0) PIME_NO_HOIST();
+            const Frag w = wl[(kt * 16 + s) * 64];
+            const float b = in[kt][s];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+                out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfrag_get(w, ot), b, out[ot], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < PERK; ++q) {
+                const int idx = (kt * 16 + s) * PERK + q;
+                if (idx < NV) {
+                    const float hq = activate<ACT>(v[idx >> 4][idx & 15]);
+                    v[idx >> 4][idx & 15] = ACT == 0 ? (hq > 0.f ? 1.f : 0.f) : 1.f - hq * hq;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] *= v[ot][r];
+}
+
 template <int NT, int ACT>
 __device__ __forceinline__ void activate_tiles(f32x16 (&v)[NT]) {
 #pragma unroll

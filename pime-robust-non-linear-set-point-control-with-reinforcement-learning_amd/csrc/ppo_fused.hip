@@ -728,6 +728,34 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             stage_image(wbuf, a.img_bwd + Lb.off[4], 2 * H * T * 256);   // other_net.2^T | integrator_net.2^T
             PIME_LDS_BARRIER();
             PIME_MARK(8);
+            if constexpr (T == 4) {
+                // One branch at a time (64 instead of 128 live dZ registers): dX with act'(h1) formed behind its MFMAs,
+                // then that branch's first-layer gradient.  The branch's transposed image (its half of W) is dead by
+                // then and holds the partial sums of the vector form.
+#pragma unroll
+                for (int br = 0; br < 2; ++br) {
+                    const int Din = br ? a.Di : Do, col0 = br ? Do : 0;
+                    float* const img = wbuf + br * H * T * 1024;
+                    f32x16 d1[T];
+                    {
+                        f32x16 v[T];   // pre-activations of h1; the layer turns them into act'(h1)
+                        layer_first<T, 2>(lds + (br ? F.first1 : F.first0), xl + col0, Din, h, v);
+                        PIME_NO_HOIST();
+                        layer_mfma_gate<H, T, 1>(img, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[br * H]), d1, v);   // dZ1
+                    }
+                    PIME_MARK(9 + br);
+                    float* gW = sl + a.poff[br ? 4 : 0], *gb = sl + a.poff[br ? 5 : 1];
+                    if (a.D <= kFirstValuMaxD) {
+                        first_grad_valu<T>(X, img, lane, wave, d1, xs, a.D, col0, Din, gW, gb, accum);
+                    } else {
+                        f32x16 acc[DwPlan<T, 1>::PER];
+                        float bsum;
+                        dw_rounds<T, 1>(X, lane, wave, d1, StateB{xs, Din, a.D, col0}, acc, bsum, nullptr, nullptr, 0);
+                        dw_store<T, 1>(lane, wave, acc, bsum, gW, Din, md, Din, gb, accum);
+                    }
+                }
+                PIME_MARK(11);
+            } else
             {
                 f32x16 d1[2 * T];   // [dZo1 | dZi1]
                 PIME_NO_HOIST();
