@@ -81,10 +81,10 @@ class KernelTimer:
 
 def pmc_traffic_bytes(kernel_prefixes):
     """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/
-    r01_h_pmc_hbm_traffic.json, produced by tools/pmc_traffic.sh on this bench; FETCH_SIZE doubled as
+    r01_j_pmc_hbm_traffic.json, produced by tools/pmc_traffic.sh on this bench; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read from inside the process, so this is the
     measured figure of the same command, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_h_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_j_pmc_hbm_traffic.json")
     if not os.path.exists(path):
         return None
     data = json.load(open(path))
@@ -287,7 +287,7 @@ def main():
                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                     "traffic": pmc_traffic_bytes(["ppo_fused_kernel<4, 0>", "ppo_fused_kernel<4, 2>",
                                                   "ppo_grad_reduce_kernel"]),
-                    "traffic_source": "profiles/r01_h_pmc_hbm_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2)",
+                    "traffic_source": "profiles/r01_j_pmc_hbm_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2)",
                     "launches_per_step": n_dom / args.steps, "avg_launch_ms": ms_dom,
                     "algorithmic_flops_per_launch": GRAD_FLOPS_PER_SAMPLE * BATCH}
     elif "critic" in dominant or "actor" in dominant:
