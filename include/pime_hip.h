@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 5
+#define PIME_ABI_VERSION 6
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -219,7 +219,10 @@ typedef struct pime_ppo_batch {
     const float* r_sum;           /* [dev] float32[L] reward sums (critic targets) */
     const int64_t* indices;       /* [dev] int64[B] minibatch rows (torch.randint) */
     int32_t B;
+    int32_t flags;                /* PIME_PPO_* bits, 0 = accumulate into the gradient tensors */
 } pime_ppo_batch;
+/* the call OVERWRITES the gradient tensors (and g_a_std_log) instead of adding to them: saves the caller's zeroing launch */
+#define PIME_PPO_OVERWRITE_GRADS 1
 
 int64_t pime_ppo_bwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t md);
 int64_t pime_ppo_workspace_floats(int32_t kind, int32_t B, int32_t md);
@@ -231,7 +234,8 @@ int pime_ppo_repack(const pime_ppo_net* actor, const pime_ppo_net* critic, pime_
 /* critic_scale: [dev] float32[1], WRITTEN: 1 / (r_sum[indices].std() + 1e-5) with torch's unbiased std (agent.py:652);
  *               the critic's gradients are multiplied by it (fourth, tiny launch)
  * moments:      [dev] float64[2], WRITTEN: sum and sum of squares of the minibatch targets r_sum[indices]
- * loss_sums:    [dev] float32[4], ACCUMULATED: sum(-min(surr1,surr2)), sum(exp(logp)*logp), sum(smooth_l1), unused */
+ * loss_sums:    [dev] float32[4], ACCUMULATED: sum(-min(surr1,surr2)), sum(exp(logp)*logp), sum(smooth_l1), and the
+ *               critic_scale of this call (a running sum over calls, for the logged united loss) */
 int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* batch,
                             float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
                             float* loss_sums, pime_stream stream);

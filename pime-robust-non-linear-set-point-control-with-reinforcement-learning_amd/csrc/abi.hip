@@ -46,10 +46,10 @@ int64_t fused_stash_floats(int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
 int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, float* const*, float* const*, float*, float*,
-                       double*, hipStream_t);
+                       double*, float*, int, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
 int launch_dw(const DwArgs&, int, hipStream_t);
-int launch_critic_scale(int, int, float* const*, const double*, int, float*, hipStream_t);
+int launch_critic_scale(int, int, float* const*, const double*, int, float*, float*, hipStream_t);
 int launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float*, hipStream_t);
 int launch_rollout(int, int, const RolloutArgs&, hipStream_t);
 
@@ -640,7 +640,19 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         PIME_HIP_TRY(hipMalloc(&trace_dev, 2 * 64 * sizeof(long long)));
     }
     if (tracing) PIME_HIP_TRY(hipMemsetAsync(trace_dev, 0, 2 * 64 * sizeof(long long), s));
-    if (split) PIME_HIP_TRY(hipMemsetAsync(moments, 0, 2 * sizeof(double), s));  // atomics accumulate into it
+    if (split) {
+        PIME_HIP_TRY(hipMemsetAsync(moments, 0, 2 * sizeof(double), s));  // atomics accumulate into it
+        if (b->flags & PIME_PPO_OVERWRITE_GRADS) {   // the atomics of this pipeline need zeroed targets
+            const pime_ppo_net* both[2] = {critic, actor};
+            for (const pime_ppo_net* n : both) {
+                int poff[13], psize[12];
+                slab_layout(n->kind, n->D, n->Di, n->md, poff, psize);
+                const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
+                for (int i = 0; i < np; ++i) PIME_HIP_TRY(hipMemsetAsync(n->grads[i], 0, sizeof(float) * psize[i], s));
+            }
+            PIME_HIP_TRY(hipMemsetAsync(actor->g_a_std_log, 0, sizeof(float), s));
+        }
+    }
     const pime_ppo_net* nets[2] = {critic, actor};
     PpoArgs fused_args[2];
     for (int k = 0; k < 2; ++k) {
@@ -692,8 +704,9 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
     }
     if (!split)
         return launch_grad_reduce(fused_args[0], fused_args[1], critic->kind, critic->md, actor->kind, actor->md,
-                                  critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, s);
-    return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, s);
+                                  critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, loss_sums + 3,
+                                  b->flags & PIME_PPO_OVERWRITE_GRADS, s);
+    return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, loss_sums + 3, s);
 }
 
 }  // extern "C"

@@ -875,7 +875,8 @@ struct ReduceSeg {
 };
 struct ReduceArgs {
     ReduceSeg seg[24];
-    int nseg, nslabs, B, moments_off;
+    int nseg, nslabs, B, moments_off, overwrite;
+    float* scale_sum;   // += scale (running sum over calls, for the logged united loss)
     const float* slab[2];
     int stride[2];
     float* scale_out;
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
         const float scale = (float)(1.0 / ((double)(float)sqrt(var) + 1e-5));
         if (lane == 0) {
             scale_sh = scale;
-            if (blockIdx.x == 0) { a.scale_out[0] = scale; a.moments_out[0] = m1; a.moments_out[1] = m2; }
+            if (blockIdx.x == 0) { a.scale_out[0] = scale; a.moments_out[0] = m1; a.moments_out[1] = m2; a.scale_sum[0] += scale; }
         }
     }
     const int unit = c * 64 + lane, n4 = (sg.n + 3) / 4;
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
         const float sc = sg.net == 0 ? scale_sh : 1.0f;
         const float o[4] = {t.x * sc, t.y * sc, t.z * sc, t.w * sc};
         for (int k = 0; k < 4; ++k)
-            if (unit * 4 + k < sg.n) sg.dst[unit * 4 + k] += o[k];
+            if (unit * 4 + k < sg.n) sg.dst[unit * 4 + k] = a.overwrite ? o[k] : sg.dst[unit * 4 + k] + o[k];
     }
 }
 
@@ -976,7 +977,7 @@ int fused_grid(int B) {
 
 int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
                        float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
-                       double* moments_out, hipStream_t s) {
+                       double* moments_out, float* scale_sum, int overwrite, hipStream_t s) {
     ReduceArgs r{};
     int poff[13], psize[12], chunks = 0;
     auto add = [&](float* dst, int off, int n, int net) {
@@ -994,7 +995,7 @@ int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, 
     r.nslabs = fused_grid(critic.B); r.B = critic.B;
     r.slab[0] = critic.slab; r.slab[1] = actor.slab;
     r.stride[0] = critic.slab_stride; r.stride[1] = actor.slab_stride;
-    r.scale_out = scale_out; r.moments_out = moments_out;
+    r.scale_out = scale_out; r.moments_out = moments_out; r.scale_sum = scale_sum; r.overwrite = overwrite;
     hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3(chunks), dim3(512), 0, s, r);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;

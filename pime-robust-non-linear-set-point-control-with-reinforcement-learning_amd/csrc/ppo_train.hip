@@ -409,23 +409,25 @@ struct ScaleArgs {
     const double* moments;
     int B;
     float* scale_out;
+    float* scale_sum;   // += scale (running sum over calls)
 };
 
 __global__ void critic_scale_kernel(ScaleArgs a) {
     const double s = a.moments[0], ss = a.moments[1], B = (double)a.B;
     const double var = a.B > 1 ? fmax((ss - s * s / B) / (B - 1.0), 0.0) : 0.0;
     const float scale = (float)(1.0 / ((double)(float)sqrt(var) + 1e-5));
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.scale_out[0] = scale;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.scale_out[0] = scale; a.scale_sum[0] += scale; }
     float* g = a.grad[blockIdx.y];
     const int n = a.n[blockIdx.y];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) g[i] *= scale;
 }
 
-int launch_critic_scale(int D, int md, float* const* grads, const double* moments, int B, float* scale_out, hipStream_t s) {
+int launch_critic_scale(int D, int md, float* const* grads, const double* moments, int B, float* scale_out,
+                        float* scale_sum, hipStream_t s) {
     ScaleArgs a{};
     const int sizes[8] = {md * D, md, md * md, md, md * md, md, md, 1};
     for (int i = 0; i < 8; ++i) { a.grad[i] = grads[i]; a.n[i] = sizes[i]; }
-    a.moments = moments; a.B = B; a.scale_out = scale_out;
+    a.moments = moments; a.B = B; a.scale_out = scale_out; a.scale_sum = scale_sum;
     hipLaunchKernelGGL(critic_scale_kernel, dim3(16, 8), dim3(256), 0, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
@@ -435,12 +437,16 @@ int launch_critic_scale(int D, int md, float* const* grads, const double* moment
 // torch.optim.Adam (no weight decay, no amsgrad; agent.py:565-566,656-657) over ONE flat parameter / gradient
 // tensor.  torch's fused multi-tensor Adam needs 27 us for the 22 small tensors of the two nets and 94 us when
 // handed the flat 67k-element tensor (one 64k chunk = one workgroup); this is a plain grid-wide elementwise pass.
-__global__ void adam_tick_kernel(float* step) { step[0] += 1.0f; }
+// One launch: every thread reads the OLD step count t0 and updates with t = t0 + 1; the workgroup that finishes last
+// (a device-side arrival counter) stores t.  No workgroup can read step[] after that store: the store waits for all of
+// them to have arrived, and they arrive after their reads.  (A separate 1-thread "tick" launch cost ~3 us per step.)
+__device__ unsigned int adam_arrivals = 0;
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                            const float* __restrict__ step) {
-    const double t = (double)step[0];
+                            float* __restrict__ step) {
+    const float t_new = step[0] + 1.0f;
+    const double t = (double)t_new;
     const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
     const float step_size = lr / bc1;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -451,11 +457,18 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         v[i] = vi;
         p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int prev = atomicAdd(&adam_arrivals, 1u);
+        if (prev == gridDim.x - 1) {
+            adam_arrivals = 0;       // ready for the next launch (launches on one stream are ordered)
+            step[0] = t_new;
+        }
+    }
 }
 
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
                 float* step, hipStream_t s) {
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step);
     const int block = 256;
     long long grid = (n + block - 1) / block;
     if (grid > 2048) grid = 2048;

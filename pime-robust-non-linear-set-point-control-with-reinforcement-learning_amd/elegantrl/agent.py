@@ -374,16 +374,14 @@ class AgentPPO(AgentBase):
         if st.key != key:
             st.key, st.graph_a, st.graph_b = key, None, None
 
-        def grads(idx):
-            fused.zero_grad()
-            fused(buf_state, action, st.logprob, st.adv, st.r_sum, idx, self.ratio_clip, self.lambda_entropy, st.scale)
-            st.scale_sum.add_(st.scale)
+        def grads(idx):   # overwrite: no zeroing launch; the running sum of the critic scale lands in loss_sums[3]
+            fused(buf_state, action, st.logprob, st.adv, st.r_sum, idx, self.ratio_clip, self.lambda_entropy, st.scale,
+                  overwrite=True)
 
         def apply():
             self.optimizer.step()
             fused.repack()
 
-        st.scale_sum.zero_()
         last = None
         for step in range(n_steps):
             replaying = self.use_hip_graphs and st.warm and st.graph_a is not None
@@ -432,7 +430,7 @@ class AgentPPO(AgentBase):
         B = float(batch_size)
         ent, cri = tot[1] / (n_steps * B), tot[2] / (n_steps * B)
         act = tot[0] / (n_steps * B) + self.lambda_entropy * ent
-        self._log_losses(act + cri * float(st.scale_sum) / n_steps, act, cri, ent)
+        self._log_losses(act + cri * tot[3] / n_steps, act, cri, ent)
         obj_a = (tot[0] - lst[0]) / B + self.lambda_entropy * (tot[1] - lst[1]) / B
         obj_c = (tot[2] - lst[2]) / B
         return obj_a, obj_c

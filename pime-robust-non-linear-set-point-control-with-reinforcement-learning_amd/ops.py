@@ -224,8 +224,10 @@ class FusedPPOGrad:
     def zero_grad(self):
         self.flat_grad.zero_()
 
-    def __call__(self, state, action, logprob, adv, r_sum, indices, ratio_clip, lambda_entropy, critic_scale):
-        """Accumulates d(obj_united)/d(theta) of the minibatch `indices` into the .grad views.  All tensors float32
+    def __call__(self, state, action, logprob, adv, r_sum, indices, ratio_clip, lambda_entropy, critic_scale,
+                 overwrite=False):
+        """Accumulates (overwrite=True: writes) d(obj_united)/d(theta) of the minibatch `indices` into the .grad views;
+        loss_sums[3] accumulates the critic scale of every call.  All tensors float32
         CUDA and contiguous; state [L, D]; action/logprob/adv/r_sum [L]; indices int64 [B]; critic_scale float32 [1]
         is WRITTEN with 1/(r_sum[indices].std()+1e-5), the factor applied to the critic's gradients (agent.py:652)."""
         B = indices.numel()
@@ -234,7 +236,8 @@ class FusedPPOGrad:
             self._build_structs()
         actor, critic, _ = self._structs
         batch = native.PpoBatch(state=state.data_ptr(), action=action.data_ptr(), logprob=logprob.data_ptr(),
-                                adv=adv.data_ptr(), r_sum=r_sum.data_ptr(), indices=indices.data_ptr(), B=B)
+                                adv=adv.data_ptr(), r_sum=r_sum.data_ptr(), indices=indices.data_ptr(), B=B,
+                                flags=native.PPO_OVERWRITE_GRADS if overwrite else 0)
         with torch.cuda.device(self.device):
             native.check(native.lib().pime_ppo_minibatch_grad(C.byref(actor), C.byref(critic), C.byref(batch),
                                                               C.c_float(ratio_clip), C.c_float(lambda_entropy),

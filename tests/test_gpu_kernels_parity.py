@@ -110,3 +110,34 @@ def test_mlp_forward_matches_torch_fp32():
     with torch.no_grad():
         np.testing.assert_allclose(ops.PackedMLP.from_module(cri)(x).cpu().numpy(), cri(x)[:, 0].cpu().numpy(), rtol=3e-5, atol=3e-5)
         np.testing.assert_allclose(ops.PackedMLP.from_module(act)(x).cpu().numpy(), act.mean(x)[:, 0].cpu().numpy(), rtol=3e-5, atol=3e-5)
+
+
+def test_flat_adam_matches_torch_adam():
+    """pime_adam_step (one launch, device-side step counter advanced by the last workgroup) against torch.optim.Adam
+    (agent.py:565-566: lr only, default betas / eps, no weight decay) over several steps, eager and from a HIP graph."""
+    from pime_amd import ops
+    torch.manual_seed(3)
+    n = 67460
+    p0 = torch.randn(n, device=DEV)
+    grads = [torch.randn(n, device=DEV) * (0.1 + k) for k in range(6)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-4)
+    mine = p0.clone()
+    g = torch.zeros(n, device=DEV)
+    adam = ops.FlatAdam(mine, g, 1e-4)
+    for k in range(3):
+        ref.grad = grads[k].clone(); opt.step()
+        g.copy_(grads[k]); adam.step()
+    torch.cuda.synchronize()
+    assert float(adam.step_count) == 3.0
+    torch.testing.assert_close(mine, ref.detach(), rtol=2e-6, atol=2e-7)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        adam.step()
+    # (capture does not execute) three replays = steps 4..6
+    for k in range(3, 6):
+        ref.grad = grads[k].clone(); opt.step()
+        g.copy_(grads[k]); graph.replay()
+    torch.cuda.synchronize()
+    assert float(adam.step_count) == 6.0
+    torch.testing.assert_close(mine, ref.detach(), rtol=2e-6, atol=2e-7)

@@ -122,6 +122,13 @@ def test_fused_gradients_are_reproducible_and_accumulate():
     assert torch.equal(g1, g2), "gradients differ between two identical calls"
     g3 = run(False)
     torch.testing.assert_close(g3, 2 * g1, rtol=1e-6, atol=1e-9)
+    # PIME_PPO_OVERWRITE_GRADS: the same gradients whatever the buffers held; loss_sums[3] keeps a running sum of the scale
+    fused.flat_grad.fill_(123.0)
+    before = float(fused.loss_sums[3])
+    fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, 0.2, 0.02, scale, overwrite=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.flat_grad, g1)
+    np.testing.assert_allclose(float(fused.loss_sums[3]) - before, float(scale), rtol=1e-6)
 
 
 def test_fused_update_net_matches_torch_update():
