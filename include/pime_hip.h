@@ -256,7 +256,8 @@ int pime_rollout(pime_env* env, int32_t kind, int32_t md, const float* packed_ac
 
 /* replaces: self.optimizer.step() of the single Adam over both nets (elegantrl/agent.py:565-566,656-657; no weight
  * decay, no amsgrad) when every parameter lives in ONE flat tensor.  All [dev] float32[n]; step [dev] float32[1] is the
- * step counter, incremented by the call (so the launch pair can be replayed from a HIP graph). */
+ * step counter, incremented by the call on the device (so the launch can be replayed from a HIP graph).  Calls on
+ * different streams must not overlap (one device-side arrival counter). */
 int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, float* step, pime_stream stream);
 

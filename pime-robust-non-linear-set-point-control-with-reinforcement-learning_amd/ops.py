@@ -248,7 +248,7 @@ class FusedPPOGrad:
 
 class FlatAdam:
     """torch.optim.Adam semantics (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad) on one flat float32
-    tensor, as two tiny HIP launches whose step counter lives on the device (graph-replayable)."""
+    tensor, as one HIP launch whose step counter lives on the device (graph-replayable)."""
 
     def __init__(self, param, grad, lr, betas=(0.9, 0.999), eps=1e-8):
         _need_cuda(param)
