@@ -232,7 +232,9 @@ def main():
     env.step_residual = timer.wrap("ph_step_kernel (fused residual)", env.step_residual)
     env.rollout = timer.wrap("rollout_ph_kernel (50 steps, one launch)", env.rollout)
     agent.backend.gae = timer.wrap("gae_scan_kernel", agent.backend.gae)
-    agent.launch_timer = timer.bracket  # "ppo_minibatch_grad": the 4 launches of one minibatch gradient
+    # "ppo_minibatch_grad" (the gradient launches of one minibatch) is timed with HIP events in ONE extra, untimed update
+    # after the measured region: bracketing it forces the two-graph step sequence, while the measured steps replay one
+    # graph per optimizer step.
 
     def sync():
         torch.cuda.synchronize()
@@ -270,6 +272,15 @@ def main():
     torch.cuda.synchronize()
     c = time.perf_counter()
     t_roll, t_upd = b - a, c - b
+    # per-launch duration of the gradient launches: one more update with HIP events around every minibatch's launches
+    grad_timer = KernelTimer()
+    grad_timer.enabled = True
+    agent.launch_timer = grad_timer.bracket
+    agent.update_net(buf, LANES * T_EP, BATCH, REPEAT)   # first use of the two-graph sequence: captures it
+    grad_timer.pairs.clear()
+    agent.update_net(buf, LANES * T_EP, BATCH, REPEAT)
+    torch.cuda.synchronize()
+    agent.launch_timer = None
 
     if rank != 0:
         if dp is not None:
@@ -277,6 +288,9 @@ def main():
         return
     ks = timer.summary()
     per_step = {k: n * ms / args.steps for k, (n, ms) in ks.items()}
+    n_g, ms_g = grad_timer.summary()["ppo_minibatch_grad"]
+    ks["ppo_minibatch_grad"] = (n_g * args.steps, ms_g)       # n_g launches per update, one update per step
+    per_step["ppo_minibatch_grad"] = n_g * ms_g
     dominant = max(per_step, key=per_step.get)
     n_dom, ms_dom = ks[dominant]
     if dominant == "ppo_minibatch_grad":

@@ -116,6 +116,7 @@ class AgentPPO(AgentBase):
         self.noise_hook = None  # tests: callable(t, shape) -> exploration noise tensor (else torch.randn)
         self.use_fused_update = True
         self.use_hip_graphs = True
+        self.use_single_graph = True     # one graph per optimizer step when nothing has to happen between its launches
         self.use_fused_rollout = True
         self.launch_timer = None  # optional callable(name, thunk) that brackets the thunk with HIP events
 
@@ -358,8 +359,11 @@ class AgentPPO(AgentBase):
         in the flat gradient buffer -> optional ONE all-reduce -> Adam -> re-pack of the kernel weight images.
 
         The launch sequence of a step is identical every time, so after one eager step (which also creates Adam's
-        state) it is captured into two HIP graphs -- [scale, zero, gradients] and [Adam, re-pack], split where the
-        data-parallel all-reduce goes -- and replayed: the update is otherwise bound by ~200 us/step of host work."""
+        state) it is captured into HIP graphs and replayed (the update is otherwise bound by ~200 us/step of host work):
+        ONE graph per step -- [index draw, gradients, Adam, re-pack] -- on a single GPU with torch's own index draw
+        (torch.randint is graph-safe: the generator's Philox offset advances per replay exactly as in eager mode), else
+        two graphs -- [gradients] and [Adam, re-pack] -- split where the data-parallel all-reduce / an injected index
+        tensor / the bench's launch timer goes.  Three launch gaps per step (~15 us of ~360) is the difference."""
         dev = buf_state.device
         fused.loss_sums.zero_()
         st = self._fused_static(fused, buf_len, batch_size, buf_state.shape[1], dev)
@@ -372,7 +376,7 @@ class AgentPPO(AgentBase):
             action, buf_state = st.action, st.state
         key = (buf_state.data_ptr(), action.data_ptr())
         if st.key != key:
-            st.key, st.graph_a, st.graph_b = key, None, None
+            st.key, st.graph_a, st.graph_b, st.graph_full = key, None, None, None
 
         def grads(idx):   # overwrite: no zeroing launch; the running sum of the critic scale lands in loss_sums[3]
             fused(buf_state, action, st.logprob, st.adv, st.r_sum, idx, self.ratio_clip, self.lambda_entropy, st.scale,
@@ -382,8 +386,29 @@ class AgentPPO(AgentBase):
             self.optimizer.step()
             fused.repack()
 
+        one_graph = (self.use_hip_graphs and self.use_single_graph and self.dp is None and self.index_hook is None
+                     and self.launch_timer is None)
         last = None
         for step in range(n_steps):
+            if one_graph and st.warm:
+                if st.graph_full is None:
+                    torch.cuda.synchronize(dev)
+                    try:
+                        gf = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gf, capture_error_mode="thread_local"):
+                            torch.randint(buf_len, size=(batch_size,), device=dev, out=st.idx)      # agent.py:630
+                            grads(st.idx)
+                            apply()
+                        st.graph_full = gf
+                    except RuntimeError as exc:
+                        print(f"| single-graph capture failed ({exc}); using the two-graph sequence")
+                        self.use_single_graph = one_graph = False
+                        torch.cuda.synchronize(dev)
+                if st.graph_full is not None:
+                    if step == n_steps - 1:
+                        last = fused.loss_sums.clone()
+                    st.graph_full.replay()
+                    continue
             replaying = self.use_hip_graphs and st.warm and st.graph_a is not None
             indices = self._minibatch_indices(step, buf_len, batch_size, dev, out=st.idx if replaying else None)
             if step == n_steps - 1:
@@ -442,7 +467,7 @@ class AgentPPO(AgentBase):
         if st is None or st.buf_len != buf_len or st.batch != batch_size:
             import types
             f32 = dict(dtype=torch.float32, device=dev)
-            st = types.SimpleNamespace(buf_len=buf_len, batch=batch_size, key=None, graph_a=None, graph_b=None, warm=False,
+            st = types.SimpleNamespace(buf_len=buf_len, batch=batch_size, key=None, graph_a=None, graph_b=None, graph_full=None, warm=False,
                                        r_sum=torch.empty(buf_len, **f32), logprob=torch.empty(buf_len, **f32),
                                        adv=torch.empty(buf_len, **f32), scale=torch.ones(1, **f32),
                                        action=torch.empty(buf_len, **f32), state=torch.empty((buf_len, state_dim), **f32),
