@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 6
+#define PIME_ABI_VERSION 7
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -220,6 +220,9 @@ typedef struct pime_ppo_batch {
     const int64_t* indices;       /* [dev] int64[B] minibatch rows (torch.randint) */
     int32_t B;
     int32_t flags;                /* PIME_PPO_* bits, 0 = accumulate into the gradient tensors */
+    int64_t* index_row;           /* [dev] int64[1] or NULL.  Not NULL: `indices` is a table int64[rows, B], this call uses
+                                   * row index_row[0] and then advances it by one -- the minibatches of a whole update can be
+                                   * drawn by one torch.randint and a captured HIP graph replayed per optimizer step */
 } pime_ppo_batch;
 /* the call OVERWRITES the gradient tensors (and g_a_std_log) instead of adding to them: saves the caller's zeroing launch */
 #define PIME_PPO_OVERWRITE_GRADS 1

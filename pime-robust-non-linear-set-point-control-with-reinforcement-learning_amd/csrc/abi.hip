@@ -46,10 +46,10 @@ int64_t fused_stash_floats(int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
 int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, float* const*, float* const*, float*, float*,
-                       double*, float*, int, hipStream_t);
+                       double*, float*, int, int64_t*, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
 int launch_dw(const DwArgs&, int, hipStream_t);
-int launch_critic_scale(int, int, float* const*, const double*, int, float*, float*, hipStream_t);
+int launch_critic_scale(int, int, float* const*, const double*, int, float*, float*, int64_t*, hipStream_t);
 int launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float*, hipStream_t);
 int launch_rollout(int, int, const RolloutArgs&, hipStream_t);
 
@@ -659,7 +659,7 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         const pime_ppo_net* n = nets[k];
         PpoArgs a{};
         a.state = b->state; a.action = b->action; a.logprob = b->logprob; a.adv = b->adv; a.r_sum = b->r_sum;
-        a.indices = b->indices; a.B = b->B; a.D = n->D; a.Di = n->Di;
+        a.indices = b->indices; a.index_row = b->index_row; a.B = b->B; a.D = n->D; a.Di = n->Di;
         a.a_std_log = n->a_std_log; a.moments = moments; a.ratio_clip = ratio_clip; a.lambda_entropy = lambda_entropy;
         a.img_fwd = n->img_fwd; a.img_bwd = n->img_bwd;
         const int64_t ntiles = (b->B + 31) / 32;
@@ -705,8 +705,9 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
     if (!split)
         return launch_grad_reduce(fused_args[0], fused_args[1], critic->kind, critic->md, actor->kind, actor->md,
                                   critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, loss_sums + 3,
-                                  b->flags & PIME_PPO_OVERWRITE_GRADS, s);
-    return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, loss_sums + 3, s);
+                                  b->flags & PIME_PPO_OVERWRITE_GRADS, b->index_row, s);
+    return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, loss_sums + 3,
+                               b->index_row, s);
 }
 
 }  // extern "C"

@@ -538,7 +538,8 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
         const int tile = group * kFusedWaves + wave;  // tiles past the batch run on clamped rows with dOut = 0
         const int pos = tile * 32 + li;
         const bool valid = pos < a.B;
-        const long long row = a.indices[valid ? pos : a.B - 1];
+        const int64_t* const idx = a.indices + (a.index_row ? (size_t)a.index_row[0] * a.B : 0);
+        const long long row = idx[valid ? pos : a.B - 1];
         const float* xrow = a.state + (size_t)row * a.D;
         float* st = a.stash + (size_t)tile * T * 1024;
         const float* st0 = a.stash + (size_t)group * kFusedWaves * T * 1024;  // the group's first tile
@@ -877,6 +878,7 @@ struct ReduceArgs {
     ReduceSeg seg[24];
     int nseg, nslabs, B, moments_off, overwrite;
     float* scale_sum;   // += scale (running sum over calls, for the logged united loss)
+    int64_t* index_row; // NULL, or the index table's row cursor: advanced once per call, after both nets read it
     const float* slab[2];
     int stride[2];
     float* scale_out;
@@ -908,7 +910,10 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
         const float scale = (float)(1.0 / ((double)(float)sqrt(var) + 1e-5));
         if (lane == 0) {
             scale_sh = scale;
-            if (blockIdx.x == 0) { a.scale_out[0] = scale; a.moments_out[0] = m1; a.moments_out[1] = m2; a.scale_sum[0] += scale; }
+            if (blockIdx.x == 0) {
+                a.scale_out[0] = scale; a.moments_out[0] = m1; a.moments_out[1] = m2; a.scale_sum[0] += scale;
+                if (a.index_row) a.index_row[0] += 1;
+            }
         }
     }
     const int unit = c * 64 + lane, n4 = (sg.n + 3) / 4;
@@ -977,7 +982,7 @@ int fused_grid(int B) {
 
 int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
                        float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
-                       double* moments_out, float* scale_sum, int overwrite, hipStream_t s) {
+                       double* moments_out, float* scale_sum, int overwrite, int64_t* index_row, hipStream_t s) {
     ReduceArgs r{};
     int poff[13], psize[12], chunks = 0;
     auto add = [&](float* dst, int off, int n, int net) {
@@ -995,7 +1000,7 @@ int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, 
     r.nslabs = fused_grid(critic.B); r.B = critic.B;
     r.slab[0] = critic.slab; r.slab[1] = actor.slab;
     r.stride[0] = critic.slab_stride; r.stride[1] = actor.slab_stride;
-    r.scale_out = scale_out; r.moments_out = moments_out; r.scale_sum = scale_sum; r.overwrite = overwrite;
+    r.scale_out = scale_out; r.moments_out = moments_out; r.scale_sum = scale_sum; r.overwrite = overwrite; r.index_row = index_row;
     hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3(chunks), dim3(512), 0, s, r);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
         PIME_NO_HOIST();
         const int pos = tile * 32 + (lane & 31);
         const bool valid = pos < a.B;
-        const long long row = a.indices[valid ? pos : a.B - 1];
+        const int64_t* const idx = a.indices + (a.index_row ? (size_t)a.index_row[0] * a.B : 0);
+        const long long row = idx[valid ? pos : a.B - 1];
         const float* xrow = a.state + (size_t)row * a.D;
         float* st = a.stash + (size_t)tile * NT * 1024;
         // per-sample loss inputs: issued now so that their (index-dependent) latency hides behind the layers
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(kTrainThreads) void ppo_fwd_bwd_kernel(PpoArgs a) {
     for (int tile = blockIdx.x * waves + wave; tile < ntiles; tile += gridDim.x * waves) {
         PIME_NO_HOIST();
         const int pos = tile * 32 + (lane & 31);
-        const long long row = a.indices[pos < a.B ? pos : a.B - 1];
+        const int64_t* const idx = a.indices + (a.index_row ? (size_t)a.index_row[0] * a.B : 0);
+        const long long row = idx[pos < a.B ? pos : a.B - 1];
         const float* xrow = a.state + (size_t)row * a.D;
         float* st = a.stash + (size_t)tile * NT * 1024;
         const float dout = a.dout[pos];  // written by this very wave in phase A
@@ -410,24 +412,25 @@ struct ScaleArgs {
     int B;
     float* scale_out;
     float* scale_sum;   // += scale (running sum over calls)
+    int64_t* index_row; // NULL, or the index table's row cursor (advanced here, after every reader)
 };
 
 __global__ void critic_scale_kernel(ScaleArgs a) {
     const double s = a.moments[0], ss = a.moments[1], B = (double)a.B;
     const double var = a.B > 1 ? fmax((ss - s * s / B) / (B - 1.0), 0.0) : 0.0;
     const float scale = (float)(1.0 / ((double)(float)sqrt(var) + 1e-5));
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.scale_out[0] = scale; a.scale_sum[0] += scale; }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.scale_out[0] = scale; a.scale_sum[0] += scale; if (a.index_row) a.index_row[0] += 1; }
     float* g = a.grad[blockIdx.y];
     const int n = a.n[blockIdx.y];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) g[i] *= scale;
 }
 
 int launch_critic_scale(int D, int md, float* const* grads, const double* moments, int B, float* scale_out,
-                        float* scale_sum, hipStream_t s) {
+                        float* scale_sum, int64_t* index_row, hipStream_t s) {
     ScaleArgs a{};
     const int sizes[8] = {md * D, md, md * md, md, md * md, md, md, 1};
     for (int i = 0; i < 8; ++i) { a.grad[i] = grads[i]; a.n[i] = sizes[i]; }
-    a.moments = moments; a.B = B; a.scale_out = scale_out; a.scale_sum = scale_sum;
+    a.moments = moments; a.B = B; a.scale_out = scale_out; a.scale_sum = scale_sum; a.index_row = index_row;
     hipLaunchKernelGGL(critic_scale_kernel, dim3(16, 8), dim3(256), 0, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;

@@ -11,7 +11,8 @@ struct PackArgs {
 
 struct PpoArgs {
     const float *state, *action, *logprob, *adv, *r_sum;  // flat trajectory buffers, rows = transitions
-    const int64_t* indices;                               // [B] minibatch rows
+    const int64_t* indices;                               // [B] minibatch rows (row index_row[0] of a [rows][B] table)
+    const int64_t* index_row;                             // NULL, or the device-side row cursor of the index table
     int B, D, Di;
     const float* a_std_log;     // actor: [1] parameter
     double* moments;            // critic: [2] sum and sum of squares of the minibatch targets (float64 atomics)

@@ -360,8 +360,8 @@ class AgentPPO(AgentBase):
 
         The launch sequence of a step is identical every time, so after one eager step (which also creates Adam's
         state) it is captured into HIP graphs and replayed (the update is otherwise bound by ~200 us/step of host work):
-        ONE graph per step -- [index draw, gradients, Adam, re-pack] -- on a single GPU with torch's own index draw
-        (torch.randint is graph-safe: the generator's Philox offset advances per replay exactly as in eager mode), else
+        ONE graph per step -- [gradients, Adam, re-pack] -- on a single GPU with torch's own index draw (all minibatches
+        of the update drawn at once into a table the kernels walk with a device-side cursor), else
         two graphs -- [gradients] and [Adam, re-pack] -- split where the data-parallel all-reduce / an injected index
         tensor / the bench's launch timer goes.  Three launch gaps per step (~15 us of ~360) is the difference."""
         dev = buf_state.device
@@ -388,27 +388,40 @@ class AgentPPO(AgentBase):
 
         one_graph = (self.use_hip_graphs and self.use_single_graph and self.dp is None and self.index_hook is None
                      and self.launch_timer is None)
+        if one_graph:
+            # all minibatches of this update in one draw (agent.py:630 draws them one torch.randint per step); the kernels
+            # walk the table with a device-side row cursor, so the captured graph needs no per-step input
+            if st.table is None or st.table.shape[0] < n_steps:
+                st.table, st.graph_full = torch.empty((n_steps, batch_size), dtype=torch.int64, device=dev), None
+            torch.randint(buf_len, size=(n_steps, batch_size), device=dev, out=st.table[:n_steps])
+            st.row.zero_()
+
+            def step_on_table():
+                fused(buf_state, action, st.logprob, st.adv, st.r_sum, st.table, self.ratio_clip, self.lambda_entropy,
+                      st.scale, overwrite=True, index_row=st.row)
+                apply()
         last = None
         for step in range(n_steps):
-            if one_graph and st.warm:
-                if st.graph_full is None:
+            if one_graph:
+                if step == n_steps - 1:
+                    last = fused.loss_sums.clone()
+                if st.warm and st.graph_full is None:
                     torch.cuda.synchronize(dev)
                     try:
                         gf = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(gf, capture_error_mode="thread_local"):
-                            torch.randint(buf_len, size=(batch_size,), device=dev, out=st.idx)      # agent.py:630
-                            grads(st.idx)
-                            apply()
+                            step_on_table()
                         st.graph_full = gf
                     except RuntimeError as exc:
-                        print(f"| single-graph capture failed ({exc}); using the two-graph sequence")
-                        self.use_single_graph = one_graph = False
+                        print(f"| single-graph capture failed ({exc}); continuing with eager launches")
+                        self.use_single_graph = False
                         torch.cuda.synchronize(dev)
                 if st.graph_full is not None:
-                    if step == n_steps - 1:
-                        last = fused.loss_sums.clone()
                     st.graph_full.replay()
-                    continue
+                else:
+                    step_on_table()
+                    st.warm = True
+                continue
             replaying = self.use_hip_graphs and st.warm and st.graph_a is not None
             indices = self._minibatch_indices(step, buf_len, batch_size, dev, out=st.idx if replaying else None)
             if step == n_steps - 1:
@@ -467,7 +480,8 @@ class AgentPPO(AgentBase):
         if st is None or st.buf_len != buf_len or st.batch != batch_size:
             import types
             f32 = dict(dtype=torch.float32, device=dev)
-            st = types.SimpleNamespace(buf_len=buf_len, batch=batch_size, key=None, graph_a=None, graph_b=None, graph_full=None, warm=False,
+            st = types.SimpleNamespace(buf_len=buf_len, batch=batch_size, key=None, graph_a=None, graph_b=None, graph_full=None, table=None, warm=False,
+                                       row=torch.zeros(1, dtype=torch.int64, device=dev),
                                        r_sum=torch.empty(buf_len, **f32), logprob=torch.empty(buf_len, **f32),
                                        adv=torch.empty(buf_len, **f32), scale=torch.ones(1, **f32),
                                        action=torch.empty(buf_len, **f32), state=torch.empty((buf_len, state_dim), **f32),

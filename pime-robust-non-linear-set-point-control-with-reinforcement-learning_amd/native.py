@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(PACKAGE_DIR, "libpime_hip.so")
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
-ABI_VERSION = 6
+ABI_VERSION = 7
 ENV_PH, ENV_WT = 0, 1
 STATE_F64, STATE_MIXED = 0, 1
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
@@ -42,7 +42,7 @@ class PpoNet(C.Structure):
 
 class PpoBatch(C.Structure):
     _fields_ = [("state", C.c_void_p), ("action", C.c_void_p), ("logprob", C.c_void_p), ("adv", C.c_void_p),
-                ("r_sum", C.c_void_p), ("indices", C.c_void_p), ("B", C.c_int32), ("flags", C.c_int32)]
+                ("r_sum", C.c_void_p), ("indices", C.c_void_p), ("B", C.c_int32), ("flags", C.c_int32), ("index_row", C.c_void_p)]
 
 
 PPO_OVERWRITE_GRADS = 1

@@ -225,19 +225,21 @@ class FusedPPOGrad:
         self.flat_grad.zero_()
 
     def __call__(self, state, action, logprob, adv, r_sum, indices, ratio_clip, lambda_entropy, critic_scale,
-                 overwrite=False):
+                 overwrite=False, index_row=None):
         """Accumulates (overwrite=True: writes) d(obj_united)/d(theta) of the minibatch `indices` into the .grad views;
-        loss_sums[3] accumulates the critic scale of every call.  All tensors float32
+        loss_sums[3] accumulates the critic scale of every call.  index_row (int64 [1] on the device): `indices` is then a
+        table [rows, B]; the call uses row index_row[0] and advances it (so a captured graph can be replayed per step).  All tensors float32
         CUDA and contiguous; state [L, D]; action/logprob/adv/r_sum [L]; indices int64 [B]; critic_scale float32 [1]
         is WRITTEN with 1/(r_sum[indices].std()+1e-5), the factor applied to the critic's gradients (agent.py:652)."""
-        B = indices.numel()
-        assert B <= self.max_batch and indices.dtype == torch.int64
+        B = indices.numel() if index_row is None else indices.shape[-1]
+        assert B <= self.max_batch and indices.dtype == torch.int64 and indices.is_contiguous()
         if self._structs is None:
             self._build_structs()
         actor, critic, _ = self._structs
         batch = native.PpoBatch(state=state.data_ptr(), action=action.data_ptr(), logprob=logprob.data_ptr(),
                                 adv=adv.data_ptr(), r_sum=r_sum.data_ptr(), indices=indices.data_ptr(), B=B,
-                                flags=native.PPO_OVERWRITE_GRADS if overwrite else 0)
+                                flags=native.PPO_OVERWRITE_GRADS if overwrite else 0,
+                                index_row=index_row.data_ptr() if index_row is not None else None)
         with torch.cuda.device(self.device):
             native.check(native.lib().pime_ppo_minibatch_grad(C.byref(actor), C.byref(critic), C.byref(batch),
                                                               C.c_float(ratio_clip), C.c_float(lambda_entropy),

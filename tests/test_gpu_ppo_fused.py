@@ -129,6 +129,13 @@ def test_fused_gradients_are_reproducible_and_accumulate():
     torch.cuda.synchronize()
     assert torch.equal(fused.flat_grad, g1)
     np.testing.assert_allclose(float(fused.loss_sums[3]) - before, float(scale), rtol=1e-6)
+    # index table + device-side row cursor (what the captured one-graph optimizer step uses): row 1 of the table == idx
+    table = torch.randint(3 * B, (3, B), device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+    table[1] = idx
+    row = torch.ones(1, dtype=torch.int64, device=DEV)
+    fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, table, 0.2, 0.02, scale, overwrite=True, index_row=row)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.flat_grad, g1) and int(row) == 2
 
 
 def test_fused_update_net_matches_torch_update():
