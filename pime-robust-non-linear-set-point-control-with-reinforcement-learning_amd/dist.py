@@ -54,6 +54,16 @@ class DataParallel:
         td.all_reduce(t, op=td.ReduceOp.SUM)
         return t
 
+    def all_reduce_mean(self, t):
+        """Mean over the ranks in ONE collective: RCCL's AVG op on the GPU (no separate divide launch); gloo has no
+        AVG, so the CPU tests sum and divide."""
+        if td.get_backend() == "nccl":
+            td.all_reduce(t, op=td.ReduceOp.AVG)
+        else:
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+            t.div_(self.world)
+        return t
+
     def average_gradients(self, params):
         """Flatten every gradient into ONE buffer, all-reduce it once, scatter the mean back."""
         grads = [p.grad for p in params if p.grad is not None]

@@ -378,83 +378,64 @@ class AgentPPO(AgentBase):
         if st.key != key:
             st.key, st.graph_a, st.graph_b, st.graph_full = key, None, None, None
 
-        def grads(idx):   # overwrite: no zeroing launch; the running sum of the critic scale lands in loss_sums[3]
-            fused(buf_state, action, st.logprob, st.adv, st.r_sum, idx, self.ratio_clip, self.lambda_entropy, st.scale,
-                  overwrite=True)
+        # Minibatch indices: with torch's own draw, all n_steps minibatches are drawn at once (agent.py:630 draws them one
+        # torch.randint per step) into a table the kernels walk with a device-side row cursor, so a captured graph needs
+        # no per-step input.  An index hook (parity tests) hands over one tensor per step instead.
+        use_table = self.index_hook is None
+        if use_table:
+            if st.table is None or st.table.shape[0] < n_steps:
+                st.table = torch.empty((n_steps, batch_size), dtype=torch.int64, device=dev)
+                st.graph_a = st.graph_b = st.graph_full = None
+            torch.randint(buf_len, size=(n_steps, batch_size), device=dev, out=st.table[:n_steps])
+            st.row.zero_()
+
+        def grads():   # overwrite: no zeroing launch; the running sum of the critic scale lands in loss_sums[3]
+            fused(buf_state, action, st.logprob, st.adv, st.r_sum, st.table if use_table else st.idx, self.ratio_clip,
+                  self.lambda_entropy, st.scale, overwrite=True, index_row=st.row if use_table else None)
 
         def apply():
             self.optimizer.step()
             fused.repack()
 
-        one_graph = (self.use_hip_graphs and self.use_single_graph and self.dp is None and self.index_hook is None
-                     and self.launch_timer is None)
-        if one_graph:
-            # all minibatches of this update in one draw (agent.py:630 draws them one torch.randint per step); the kernels
-            # walk the table with a device-side row cursor, so the captured graph needs no per-step input
-            if st.table is None or st.table.shape[0] < n_steps:
-                st.table, st.graph_full = torch.empty((n_steps, batch_size), dtype=torch.int64, device=dev), None
-            torch.randint(buf_len, size=(n_steps, batch_size), device=dev, out=st.table[:n_steps])
-            st.row.zero_()
+        def capture(*thunks):
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread of a data-parallel run may touch the HIP API meanwhile
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for thunk in thunks:
+                    thunk()
+            return g
 
-            def step_on_table():
-                fused(buf_state, action, st.logprob, st.adv, st.r_sum, st.table, self.ratio_clip, self.lambda_entropy,
-                      st.scale, overwrite=True, index_row=st.row)
-                apply()
+        one_graph = self.use_single_graph and self.dp is None and use_table and self.launch_timer is None
+        if st.mode != (use_table, one_graph):   # the captured graphs bake in which index source they read
+            st.mode, st.graph_a, st.graph_b, st.graph_full = (use_table, one_graph), None, None, None
         last = None
         for step in range(n_steps):
-            if one_graph:
-                if step == n_steps - 1:
-                    last = fused.loss_sums.clone()
-                if st.warm and st.graph_full is None:
-                    torch.cuda.synchronize(dev)
-                    try:
-                        gf = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(gf, capture_error_mode="thread_local"):
-                            step_on_table()
-                        st.graph_full = gf
-                    except RuntimeError as exc:
-                        print(f"| single-graph capture failed ({exc}); continuing with eager launches")
-                        self.use_single_graph = False
-                        torch.cuda.synchronize(dev)
-                if st.graph_full is not None:
-                    st.graph_full.replay()
-                else:
-                    step_on_table()
-                    st.warm = True
-                continue
-            replaying = self.use_hip_graphs and st.warm and st.graph_a is not None
-            indices = self._minibatch_indices(step, buf_len, batch_size, dev, out=st.idx if replaying else None)
+            if not use_table:
+                st.idx.copy_(self.index_hook(step, buf_len, batch_size).to(dev))
             if step == n_steps - 1:
                 last = fused.loss_sums.clone()
-            use_graph = self.use_hip_graphs and st.warm
-            if use_graph and st.graph_a is None:
-                torch.cuda.synchronize(dev)
+            if self.use_hip_graphs and st.warm and st.graph_a is None and st.graph_full is None:
                 try:
-                    # thread_local: the RCCL watchdog thread of a data-parallel run may touch the HIP API meanwhile
-                    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                        grads(st.idx)
-                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
-                        apply()
-                    st.graph_a, st.graph_b = ga, gb
+                    if one_graph:
+                        st.graph_full = capture(grads, apply)
+                    else:
+                        st.graph_a, st.graph_b = capture(grads), capture(apply)
                 except RuntimeError as exc:  # keep training on the eager launch sequence
                     print(f"| HIP graph capture failed ({exc}); continuing with eager launches")
-                    self.use_hip_graphs = use_graph = False
+                    self.use_hip_graphs = False
                     torch.cuda.synchronize(dev)
-            if use_graph:
-                if indices is not st.idx:
-                    st.idx.copy_(indices)
-                run = st.graph_a.replay
-            else:
-                run = lambda: grads(indices)  # noqa: E731
+            if st.graph_full is not None:
+                st.graph_full.replay()
+                continue
+            run = st.graph_a.replay if st.graph_a is not None else grads
             if self.launch_timer is not None:   # bench.py: HIP events around the gradient launches only
                 self.launch_timer("ppo_minibatch_grad", run)
             else:
                 run()
             if self.dp is not None:
-                self.dp.all_reduce_sum(fused.flat_grad)
-                fused.flat_grad.div_(self.dp.world)
-            if use_graph:
+                self.dp.all_reduce_mean(fused.flat_grad)
+            if st.graph_b is not None:
                 st.graph_b.replay()
             else:
                 apply()
@@ -480,7 +461,7 @@ class AgentPPO(AgentBase):
         if st is None or st.buf_len != buf_len or st.batch != batch_size:
             import types
             f32 = dict(dtype=torch.float32, device=dev)
-            st = types.SimpleNamespace(buf_len=buf_len, batch=batch_size, key=None, graph_a=None, graph_b=None, graph_full=None, table=None, warm=False,
+            st = types.SimpleNamespace(buf_len=buf_len, batch=batch_size, key=None, graph_a=None, graph_b=None, graph_full=None, table=None, mode=None, warm=False,
                                        row=torch.zeros(1, dtype=torch.int64, device=dev),
                                        r_sum=torch.empty(buf_len, **f32), logprob=torch.empty(buf_len, **f32),
                                        adv=torch.empty(buf_len, **f32), scale=torch.ones(1, **f32),
