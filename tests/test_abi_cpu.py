@@ -43,6 +43,29 @@ def test_cfg_struct_layout_matches_c():
     assert nt.lib().pime_env_cfg_default(7, C.byref(cfg)) != 0 and "kind" in nt.last_error()
 
 
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every ABI struct as gcc sees include/pime_hip.h against the ctypes mirrors in native.py."""
+    import subprocess
+    import pime_amd.native as nt
+    structs = {"pime_env_cfg": nt.EnvCfg, "pime_ph_chem": nt.PhChem, "pime_ppo_net": nt.PpoNet, "pime_ppo_batch": nt.PpoBatch}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pime_hip.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), f"sizeof({cname})"
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"offsetof({cname}, {fname})"
+
+
 def test_native_table_matches_oracle_bitwise(ph_table_oracle):
     import pime_amd.native as nt
     np.testing.assert_array_equal(nt.ph_table_build(), ph_table_oracle)
