@@ -138,6 +138,31 @@ def test_fused_gradients_are_reproducible_and_accumulate():
     assert torch.equal(fused.flat_grad, g1) and int(row) == 2
 
 
+def test_split_pipeline_honours_overwrite_and_index_table():
+    """The atomics-based pipeline that serves wide states (LDS map of the fused kernel does not fit): the same ABI
+    options -- PIME_PPO_OVERWRITE_GRADS zeroes its targets first, index_row selects and advances the table row."""
+    from pime_amd import ops
+    B, D = 2048, 30
+    act, cri = _make("resid", 128, D, seed=11)
+    state, action, logprob, adv, r_sum = _data(3 * B, D, act, seed=5)
+    idx = torch.randint(3 * B, (B,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+    want, *_ = _torch_grads(act, cri, state, action, logprob, adv, r_sum, idx, 0.2, 0.02)
+    fused = ops.FusedPPOGrad(act, cri, B)
+    scale = torch.zeros(1, device=DEV)
+    table = torch.zeros((2, B), dtype=torch.int64, device=DEV)
+    table[1] = idx
+    row = torch.ones(1, dtype=torch.int64, device=DEV)
+    fused.flat_grad.fill_(7.0)
+    fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, table, 0.2, 0.02, scale, overwrite=True, index_row=row)
+    torch.cuda.synchronize()
+    assert int(row) == 2
+    got = {n: p.grad for n, p in list(act.named_parameters()) + [("cri." + k, v) for k, v in cri.named_parameters()]
+           if p.requires_grad}
+    for name in want:
+        tol = 3e-4 * float(want[name].abs().max()) + 1e-7
+        assert float((want[name] - got[name]).abs().max()) <= tol, name
+
+
 def test_fused_update_net_matches_torch_update():
     """Whole update_net: the fused path and the torch-autograd path, same start, same minibatch indices."""
     from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
