@@ -10,7 +10,10 @@ One "step" = one pass of the hot path over one batch of synthetic input:
   => 819 200 env-steps per step and per GPU.  Weak scaling: every rank owns 16 384 lanes; one flat-gradient
   all-reduce per optimizer step.
 
-Usage:  python bench.py [--gpus N --steps K --warmup W]     (N > 1: launched by torch.distributed.run)
+Usage:  python bench.py [--gpus N --steps K --warmup W]
+  N > 1 works both ways: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE /
+  MASTER_* from the env), and as plain `python bench.py --gpus N`: the parent then starts N rank processes itself BEFORE it
+  touches the GPU (it never initialises HIP, never re-execs), relays rank 0's JSON line and exits non-zero if a rank fails.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -80,21 +83,26 @@ class KernelTimer:
 
 
 def pmc_traffic_bytes(kernel_prefixes):
-    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/
-    r01_j_pmc_hbm_traffic.json, produced by tools/pmc_traffic.sh on this bench; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read from inside the process, so this is the
-    measured figure of the same command, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_j_pmc_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
+    """(HBM bytes per launch, source file) from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    bench (profiles/r<round>_<tag>_pmc_hbm_traffic.json, produced by tools/pmc_traffic.sh: separate passes, FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950; PIME_PMC_TRAFFIC=<file> names another one).  PMC counters cannot be read
+    from inside the process, so this is the measured figure of the same command on the same kernels -- the file is named in
+    the JSON line so a stale one shows -- or (None, None)."""
+    import glob
+    path = os.environ.get("PIME_PMC_TRAFFIC")
+    if not path:
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+        path = found[-1] if found else None
+    if not path or not os.path.exists(path):
+        return None, None
     data = json.load(open(path))
     total = 0.0
     for pref in kernel_prefixes:
         hit = [v for k, v in data.items() if pref in k]
         if not hit:
-            return None
+            return None, os.path.relpath(path, ROOT)
         total += (hit[0]["fetch_mb_corrected"] + hit[0]["write_mb"]) * 1024 * 1024
-    return total
+    return total, os.path.relpath(path, ROOT)
 
 
 def log(msg):
@@ -131,9 +139,22 @@ def one_step(env, agent, buf):
     return steps
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline():
-    """The same hot path on the host: C oracle envs + torch-CPU nets with the product's own agent code, on a bounded
-    sample: ONE step of the same workload (16 384 lanes x one 50-step episode, batch 65 536, repeat 8 -> 100 optimizer steps)."""
+    """The same hot path on the host cores of this box: the C oracle's env restatement (OpenMP over the
+    lanes) + torch-CPU nets driven by the product's own agent code, on a bounded sample: ONE step of the same workload
+    (16 384 lanes x one 50-step episode, batch 65 536, repeat 8 -> 100 optimizer steps) on all cores -> `value`; plus
+    env-only points (prior controller + tanh(N(0,1) e^-0.5) residual) at N = 1 / 4 096 / 16 384 with one
+    thread and with all cores."""
     import oracle  # noqa: F401  (allowed here: bench.py's cpu_baseline leg)
     from oracle.cpu_stack import OracleBackend, OracleVecEnv
     from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
@@ -141,7 +162,8 @@ def cpu_baseline():
     # the box's CPU share, not the host's core count (oversubscribing torch's intra-op pool stalls for minutes)
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
-    n = LANES  # the full workload: ~15 s of host time
+    oracle.set_threads(cores)
+    n = LANES  # the full workload
     env = OracleVecEnv("ph", n, seed=0)
     torch.manual_seed(0)
     agent = AgentResidualIntegratorModularPPO(backend=OracleBackend(), device="cpu")
@@ -154,9 +176,35 @@ def cpu_baseline():
     t1 = time.perf_counter()
     agent.update_net(buf, n * T_EP, n * T_EP * BATCH // (LANES * T_EP), REPEAT)
     t2 = time.perf_counter()
-    return {"value": steps / (t2 - t0), "unit": "env-steps/s", "cores": cores, "kind": "port",
+    # env-only points: reset + 50 steps (+ auto-reset / resample) per episode under prior + exploration-noise residual
+    points = []
+    rng = np.random.RandomState(0)
+    K = -env.K
+    for lanes in (1, 4096, 16384):
+        for thr in (1, cores):
+            oracle.set_threads(thr)
+            e = oracle.OraclePH(lanes, env.table, seed=0)
+            obs = e.reset()
+            episodes = max(1, min(2000, int(4e6 // (lanes * T_EP))))   # ~4M env-steps at most per point
+            a_pre = (rng.standard_normal((T_EP, lanes)) * np.exp(-0.5)).astype(np.float32)
+            ta = time.perf_counter()
+            for _ in range(episodes):
+                for t in range(T_EP):
+                    act = oracle.residual_action(a_pre[t], obs, K)
+                    obs, _, _, _ = e.step(act, auto_reset=True)
+            tb = time.perf_counter()
+            points.append({"lanes": lanes, "threads": thr, "env_steps_per_s": episodes * T_EP * lanes / (tb - ta)})
+            if lanes == 1:
+                break   # one lane has nothing to spread over threads
+    oracle.set_threads(cores)
+    return {"value": steps / (t2 - t0), "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "nproc": os.cpu_count(),
             "sample": f"{n} lanes x {T_EP} steps (= {steps} env-steps), batch {n * T_EP * BATCH // (LANES * T_EP)}, "
-                      f"repeat {REPEAT}: C oracle env (1 thread) {t1 - t0:.2f}s + torch-CPU PPO update ({cores} threads) {t2 - t1:.2f}s"}
+                      f"repeat {REPEAT}: C oracle env + torch-CPU policy forward (OpenMP / intra-op {cores} threads) {t1 - t0:.2f}s "
+                      f"+ torch-CPU PPO update ({cores} threads) {t2 - t1:.2f}s",
+            "env_only_points": points,
+            "reference_python_n1": {"value": 316, "unit": "env-steps/s", "where": "build container, 8 threads (BASELINE.md §2); "
+                                    "the reference cannot travel to the GPU box"}}
 
 
 def bench_water_tank(args, device, json_fd):
@@ -195,6 +243,63 @@ def bench_water_tank(args, device, json_fd):
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
+    relay rank 0's stdout (the JSON line) and return non-zero if any rank fails.  The parent makes NO GPU call (importing
+    torch does not initialise HIP) and never replaces itself: the ranks are ordinary child processes."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()   # drains rank 0's pipe for the whole run, so the rank can never block on a full one
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                log(f"rank {r} exited with code {code}; stopping the other ranks")
+                for q in alive:   # the survivors would block in their next collective forever
+                    procs[q].terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
+    sys.stdout.buffer.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+def launcher_selftest(json_fd):
+    """--selftest-launcher: the rank plumbing alone (rendezvous, barrier, max / sum over ranks, rank 0 prints) on the gloo
+    backend, no GPU -- what tests/test_bench_launcher.py runs in the GPU-less container."""
+    from pime_amd import dist as pdist
+    rank, world, local = pdist.env_rank_world()
+    dp = pdist.init_from_env(backend="gloo", device="cpu")
+    got_world = torch.distributed.get_world_size() if dp is not None else 1
+    t = dp.max_over_ranks(1.0 + rank) if dp is not None else 1.0
+    total = dp.sum_over_ranks(100 * (rank + 1)) if dp is not None else 100
+    if dp is not None:
+        dp.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"selftest": "launcher", "n_gpus": got_world, "max_t": t, "sum": total}) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,7 +309,11 @@ def main():
     ap.add_argument("--workload", default="ph", choices=["ph", "wt"],
                     help="ph: the headline config (BASELINE config 3); wt: config 2, water tank, 4096 lanes x 200 steps "
                          "(reported for DESIGN.md; the headline metric is the ph line)")
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # no launcher: become one, before anything touches the GPU
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     # stdout must carry exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block at
     # communicator creation) are sent to stderr for the whole run, and the JSON is written to the saved descriptor.
@@ -214,12 +323,17 @@ def main():
 
     from pime_amd import dist as pdist
     rank, world, local = pdist.env_rank_world()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if args.selftest_launcher:
+        return launcher_selftest(json_fd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
     dp = pdist.init_from_env(backend="nccl", device=device) if (world > 1 or os.environ.get("PIME_FORCE_DP") == "1") else None
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if dp is not None:
+        world = torch.distributed.get_world_size()   # the RCCL communicator's size is what the JSON line reports
 
     if args.workload == "wt":
         return bench_water_tank(args, device, json_fd)
@@ -295,13 +409,15 @@ def main():
     n_dom, ms_dom = ks[dominant]
     if dominant == "ppo_minibatch_grad":
         achieved = GRAD_FLOPS_PER_SAMPLE * BATCH / (ms_dom * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic_bytes(["ppo_fused_kernel<4, 0>", "ppo_fused_kernel<4, 2>",
+                                                  "ppo_grad_reduce_kernel"])
         roofline = {"kernel": "ppo_minibatch_grad = ppo_fused_kernel<critic> + ppo_fused_kernel<modular_actor> + "
                               "ppo_grad_reduce_kernel (one minibatch of 65536: forward, loss, backward and weight "
                               "gradients; per-kernel split in profiles/)", "bound": "mfma", "achieved": achieved,
                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                    "traffic": pmc_traffic_bytes(["ppo_fused_kernel<4, 0>", "ppo_fused_kernel<4, 2>",
-                                                  "ppo_grad_reduce_kernel"]),
-                    "traffic_source": "profiles/r01_j_pmc_hbm_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2)",
+                    "traffic": traffic,
+                    "traffic_source": f"{traffic_src} (rocprofv3 --pmc of this bench, separate FETCH_SIZE / WRITE_SIZE passes, "
+                                      "FETCH_SIZE x2)" if traffic_src else None,
                     "launches_per_step": n_dom / args.steps, "avg_launch_ms": ms_dom,
                     "algorithmic_flops_per_launch": GRAD_FLOPS_PER_SAMPLE * BATCH}
     elif "critic" in dominant or "actor" in dominant:
@@ -333,7 +449,7 @@ def main():
         env_gbs = PH_STEP_BYTES * LANES / (ms_env * 1e-3) / 1e9
         roofline_env = {"kernel": "ph_step_kernel (fused residual)", "bound": "hbm", "achieved": env_gbs,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": env_gbs / HBM_PEAK_GBS,
-                        "traffic": pmc_traffic_bytes(["ph_step_kernel"]), "algorithmic_bytes_per_launch": PH_STEP_BYTES * LANES,
+                        "traffic": pmc_traffic_bytes(["ph_step_kernel"])[0], "algorithmic_bytes_per_launch": PH_STEP_BYTES * LANES,
                         "avg_launch_ms": ms_env, "note": "16384-lane launch moves 1.5 MB: launch-latency bound"}
     out = {
         "metric": "env-steps/sec (rollout+update), pH env, 16384 parallel envs",

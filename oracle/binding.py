@@ -90,6 +90,20 @@ def philox_uniform_pair(seed, env, episode, slot, stream):
     return out
 
 
+def set_threads(n=0):
+    """OpenMP threads of the lane / row loops (0 = leave unchanged); returns the current maximum."""
+    return int(lib().oracle_set_threads(int(n)))
+
+
+def explore_noise(seed, env_offset, n, epoch, t):
+    """float32[n]: the exploration noise the fused rollout kernel draws for lanes env_offset..+n at step t of rollout
+    `epoch` (Philox stream 2 + Box-Muller, csrc/rollout.hip)."""
+    eps = np.empty(n, dtype=np.float32)
+    lib().oracle_explore_noise(C.c_uint64(seed), C.c_uint32(env_offset), C.c_int(n), C.c_uint32(epoch), C.c_uint32(t),
+                               _f(eps))
+    return eps
+
+
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
 
 

@@ -18,8 +18,24 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORACLE_API __attribute__((visibility("default")))
+
+/* Env lanes and MLP rows are independent, so the lane / row loops below carry `#pragma omp parallel for` (built with
+ * -fopenmp; the pragmas vanish without it).  No reduction crosses lanes: results are identical for any thread count.
+ * oracle_set_threads(1) gives the single-thread CPU baseline, oracle_set_threads(nproc) the all-cores one. */
+ORACLE_API int oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------------
  * Titration table  (gym_control/envs/ph.py:72-84; constants :32-37; MHCl grid gym_control/__init__.py:12)
@@ -90,6 +106,20 @@ static void philox_pair(uint64_t seed, uint32_t env, uint32_t episode, uint32_t 
 ORACLE_API void oracle_philox_uniform_pair(uint64_t seed, uint32_t env, uint32_t episode, uint32_t slot,
                                            uint32_t stream, double* out2) {
     philox_pair(seed, env, episode, slot, stream, &out2[0], &out2[1]);
+}
+
+/* Exploration noise of the fused rollout (csrc/rollout.hip): eps ~ N(0,1) for lane i at step t of rollout `epoch`.
+ * The reference draws torch.randn_like on the host (net_residual.py:178); the device path has no torch generator, so this
+ * is new: Box-Muller (cosine branch) on the Philox pair of counter (global lane, epoch, t, stream 2), in float64, rounded
+ * to float32 once. */
+enum { STREAM_EXPLORE = 2 };
+ORACLE_API void oracle_explore_noise(uint64_t seed, uint32_t env_offset, int n, uint32_t epoch, uint32_t t, float* eps) {
+#pragma omp parallel for schedule(static) if (n >= 512)
+    for (int i = 0; i < n; ++i) {
+        double ua, ub;
+        philox_pair(seed, env_offset + (uint32_t)i, epoch, t, STREAM_EXPLORE, &ua, &ub);
+        eps[i] = (float)(sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586476925286766559 * ub));
+    }
 }
 
 static double clipd(double v, double lo, double hi) { /* np.clip = minimum(maximum(v, lo), hi) */
@@ -193,6 +223,7 @@ ORACLE_API void oracle_ph_set(oracle_ph* e, int field, const double* in) {
  * reference's draw order; NULL -> Philox.  resample: params are redrawn when episode % resample_every == 0
  * (resample_every == 0: never, i.e. set_reset_all(False)). */
 ORACLE_API void oracle_ph_reset(oracle_ph* e, const uint8_t* mask, const double* draws, float* obs) {
+#pragma omp parallel for schedule(static) if (e->n >= 512)
     for (int i = 0; i < e->n; ++i) {
         if (mask && !mask[i]) continue;
         e->episode[i] += 1;
@@ -230,6 +261,7 @@ ORACLE_API void oracle_ph_step(oracle_ph* e, const double* action, int auto_rese
                                float* obs, double* obs64, double* reward, uint8_t* done) {
     uint8_t* dmask = auto_reset ? (uint8_t*)calloc((size_t)e->n, 1) : NULL;
     int any_done = 0;
+#pragma omp parallel for schedule(static) reduction(| : any_done) if (e->n >= 512)
     for (int i = 0; i < e->n; ++i) {
         const double a = clipd(action[i], -1.0, 1.0);                       /* :321 */
         const double delta_u = e->t[i] != 0 ? a - e->last_a[i] : 0.0;       /* :322 */
@@ -341,6 +373,7 @@ static void wt_write_obs(const oracle_wt* e, int i, float* obs, double* obs64) {
 /* reset_all / reset_r: :902-939 (Integrator), :1166-1203 (Stacking).  draws (nullable) = [n][6] final
  * values (a1, a2, Kp, h1, h2, r) in the reference's global-stream order; NULL -> Philox. */
 ORACLE_API void oracle_wt_reset(oracle_wt* e, const uint8_t* mask, const double* draws, float* obs) {
+#pragma omp parallel for schedule(static) if (e->n >= 512)
     for (int i = 0; i < e->n; ++i) {
         if (mask && !mask[i]) continue;
         e->episode[i] += 1;
@@ -380,6 +413,7 @@ ORACLE_API void oracle_wt_step(oracle_wt* e, const double* action, const double*
     uint8_t* dmask = auto_reset ? (uint8_t*)calloc((size_t)e->n, 1) : NULL;
     int any_done = 0;
     const double lo = -0.0, hi = INFINITY; /* Box(low=-ones*0, high=inf) cast to float32: :252-257 */
+#pragma omp parallel for schedule(static) reduction(| : any_done) if (e->n >= 512)
     for (int i = 0; i < e->n; ++i) {
         e->t[i] += 1;                                                  /* :801 */
         const double u = action[i] * e->pmax / 2. + e->pmax / 2.;      /* action_P :258-260; no clip of a */
@@ -432,6 +466,7 @@ ORACLE_API void oracle_wt_step(oracle_wt* e, const double* action, const double*
  * ---------------------------------------------------------------------------------------------- */
 ORACLE_API void oracle_residual_action(int n, int D, const float* a_pre, const float* obs, const double* priorK,
                                        double* action) {
+#pragma omp parallel for schedule(static) if (n >= 512)
     for (int i = 0; i < n; ++i) {
         double dot = 0.0;
         for (int j = 0; j < D; ++j) dot += (double)obs[(size_t)D * i + j] * priorK[j];
@@ -446,6 +481,7 @@ ORACLE_API void oracle_residual_action(int n, int D, const float* a_pre, const f
  * ---------------------------------------------------------------------------------------------- */
 ORACLE_API void oracle_gae(int T, int N, const float* reward, const float* mask, const float* value, float lambda,
                            int use_gae, float* r_sum, float* adv) {
+#pragma omp parallel for schedule(static) if (N >= 512)
     for (int n = 0; n < N; ++n) {
         float pre_r = 0.f, pre_a = 0.f;
         for (int t = T - 1; t >= 0; --t) {
@@ -470,6 +506,7 @@ ORACLE_API void oracle_gae(int T, int N, const float* reward, const float* mask,
  * ---------------------------------------------------------------------------------------------- */
 static void dense(int M, int K, int Nout, const float* x, int ldx, const float* W, const float* b, int act,
                   float* y, int ldy) {
+#pragma omp parallel for schedule(static) if (M >= 64)
     for (int m = 0; m < M; ++m)
         for (int o = 0; o < Nout; ++o) {
             double acc = b ? b[o] : 0.0;

@@ -2,7 +2,7 @@
 
 The product ships exactly one backend, `HipBackend`, which drives libpime_hip.so and refuses CPU tensors.
 The agents take the backend as a constructor argument only so that the *tests* can inject the CPU oracle
-(tests/oracle_backend.py) to exercise the host-side update logic in a GPU-less container and under gloo;
+(oracle/cpu_stack.py:OracleBackend) to exercise the host-side update logic in a GPU-less container and under gloo;
 nothing in this package constructs any other backend, and there is no automatic selection or fallback.
 """
 import torch

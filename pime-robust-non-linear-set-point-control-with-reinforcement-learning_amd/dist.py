@@ -34,6 +34,16 @@ def init_from_env(backend=None, device=None):
     return DataParallel(rank, world, local, device)
 
 
+def broadcast_scalar(value, src=0):
+    """`value` of rank `src` on every rank (identity when torch.distributed is not initialised)."""
+    if not (td.is_available() and td.is_initialized()):
+        return value
+    dev = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    td.broadcast(t, src=src)
+    return float(t.item())
+
+
 class DataParallel:
     def __init__(self, rank, world, local_rank=0, device=None):
         self.rank, self.world, self.local_rank = rank, world, local_rank

@@ -40,6 +40,8 @@ class AgentBase:
         self._n_updates = 0
         self.dp = None          # pime_amd.dist.DataParallel when training sharded
         self.index_hook = None  # tests: callable(step, buf_len, batch_size) -> LongTensor of minibatch indices
+        self.index_table_hook = None  # tests: callable(n_steps, buf_len, batch_size) -> LongTensor [n_steps, batch_size], the
+        #                               whole update's minibatches at once (keeps the one-graph-per-step path, unlike index_hook)
 
     def _pick_device(self):
         if self.device is None:
@@ -135,6 +137,14 @@ class AgentPPO(AgentBase):
 
     def _make_optimizer(self):
         # ONE Adam over both nets (agent.py:565-566); rebuilt whenever the reference rebuilds it
+        fused = self._packed.get("fused")
+        if fused and fused.params_are(self):
+            # the parameters already live in the fused path's flat tensor: a fresh optimizer there (fresh moments and step
+            # count, as a rebuilt torch Adam has), and the captured graphs -- which replay the OLD optimizer's buffers -- go
+            self.optimizer = fused.make_optimizer(self.learning_rate)
+            fused.static = None
+            self.weights_changed()
+            return
         groups = [{"params": self.act.parameters(), "lr": self.learning_rate},
                   {"params": self.cri.parameters(), "lr": self.learning_rate}]
         # fused=True: one multi-tensor kernel per step on the GPU instead of ~10 foreach launches
@@ -374,7 +384,10 @@ class AgentPPO(AgentBase):
         if not (action.is_contiguous() and buf_state.is_contiguous()):
             st.action.copy_(action); st.state.copy_(buf_state)
             action, buf_state = st.action, st.state
-        key = (buf_state.data_ptr(), action.data_ptr())
+        # everything a captured graph bakes in besides the static tensors: data pointers, the loss scalars (launch arguments)
+        # and the optimizer object whose buffers and learning rate the Adam launch reads
+        key = (buf_state.data_ptr(), action.data_ptr(), float(self.ratio_clip), float(self.lambda_entropy),
+               id(self.optimizer), float(getattr(self.optimizer, "lr", self.learning_rate)))
         if st.key != key:
             st.key, st.graph_a, st.graph_b, st.graph_full = key, None, None, None
 
@@ -386,7 +399,10 @@ class AgentPPO(AgentBase):
             if st.table is None or st.table.shape[0] < n_steps:
                 st.table = torch.empty((n_steps, batch_size), dtype=torch.int64, device=dev)
                 st.graph_a = st.graph_b = st.graph_full = None
-            torch.randint(buf_len, size=(n_steps, batch_size), device=dev, out=st.table[:n_steps])
+            if self.index_table_hook is not None:
+                st.table[:n_steps].copy_(self.index_table_hook(n_steps, buf_len, batch_size).to(dev))
+            else:
+                torch.randint(buf_len, size=(n_steps, batch_size), device=dev, out=st.table[:n_steps])
             st.row.zero_()
 
         def grads():   # overwrite: no zeroing launch; the running sum of the critic scale lands in loss_sums[3]

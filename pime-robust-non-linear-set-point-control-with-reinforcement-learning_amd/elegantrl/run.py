@@ -99,8 +99,18 @@ def make_buffer(agent, env, max_memo, if_per=False):
                         if_gpu=True, device=agent.device)
 
 
+def _agree(dp, flag):
+    """The loop-exit decision must be the SAME on every data-parallel rank (a rank that leaves alone strands the others in
+    their next all-reduce): any rank's reason to stop -- goal reached on its lanes, its view of the `stop` file -- stops all."""
+    if dp is None:
+        return bool(flag)
+    return dp.max_over_ranks(1.0 if flag else 0.0) > 0.5
+
+
 def train_and_evaluate(args):
-    args.init_before_training()
+    dp = getattr(args.agent, "dp", None)
+    is_main = dp is None or dp.rank == 0          # under data parallelism only rank 0 owns cwd: checkpoints, logs, plots
+    args.init_before_training(if_main=is_main)
     cwd, env, agent = args.cwd, args.env, args.agent
     env_eval = args.env_eval if args.env_eval is not None else (env if hasattr(env, "num_envs") else deepcopy(env))
 
@@ -126,19 +136,23 @@ def train_and_evaluate(args):
         print("frozen_transfer!===========================")
     if args.load != "None":
         agent.save_load_model(args.load, if_save=False)
-    if getattr(agent, "dp", None) is not None:
-        agent.dp.broadcast_module(agent.act, agent.cri)
+    if dp is not None:
+        dp.broadcast_module(agent.act, agent.cri)
+        # identical replicas, DIFFERENT exploration / minibatch streams: init_before_training seeded torch alike on every rank
+        torch.manual_seed(args.random_seed + dp.rank)
+        if not is_main:
+            logger.configure(folder=None)
 
     if_on_policy = getattr(agent, "if_on_policy", False)
     buffer = make_buffer(agent, env, args.max_memo, args.if_per)
     evaluator = Evaluator(cwd=cwd, agent_id=args.gpu_id, device=agent.device, env=env_eval, eval_gap=args.eval_gap,
-                          eval_times1=args.eval_times1, eval_times2=args.eval_times2)
+                          eval_times1=args.eval_times1, eval_times2=args.eval_times2, is_main=is_main)
     if_reach_goal = evaluator.evaluate_act(agent)
     logger.dump(step=0)
 
     agent.state = None if hasattr(env, "num_envs") else env.reset()
     total_step = 0
-    if args.test_render is not None:
+    if args.test_render is not None and is_main:
         save_path = os.path.join(cwd, "step_0")
         os.makedirs(save_path, exist_ok=True)
         args.test_render(agent, save_path)
@@ -149,26 +163,28 @@ def train_and_evaluate(args):
             logger.record("training/total_step", total_step)
             logger.dump(step=total_step)
 
-    while not ((args.if_allow_break and if_reach_goal) or total_step >= args.break_step
-               or os.path.exists(f"{cwd}/stop")):
+    while not _agree(dp, (args.if_allow_break and if_reach_goal) or total_step >= args.break_step
+                     or os.path.exists(f"{cwd}/stop")):
         t0 = time.time()
         steps = agent.explore_env(env, buffer, args.target_step, args.reward_scale, args.gamma)
         total_step += steps
         obj_a, obj_c = agent.update_net(buffer, args.target_step, args.batch_size, args.repeat_times)
         logger.record("perf/env_steps_per_s", steps / max(time.time() - t0, 1e-9))
         if_reach_goal = evaluator.evaluate_save(agent, steps, obj_a, obj_c)
-        if args.test_render is not None and total_step % args.test_render_times == 0:
+        if args.test_render is not None and is_main and total_step % args.test_render_times == 0:
             save_path = os.path.join(cwd, f"step_{total_step}")
             os.makedirs(save_path, exist_ok=True)
             args.test_render(agent, save_path)
         logger.record("training/total_step", total_step)
         logger.dump(step=total_step)
-    print(f"| SavedDir: {cwd}\n| UsedTime: {time.time() - evaluator.start_time:.0f}")
+    if is_main:
+        print(f"| SavedDir: {cwd}\n| UsedTime: {time.time() - evaluator.start_time:.0f}")
     return agent, buffer
 
 
 class Evaluator:
-    def __init__(self, cwd, agent_id, eval_times1, eval_times2, eval_gap, env, device):
+    def __init__(self, cwd, agent_id, eval_times1, eval_times2, eval_gap, env, device, is_main=True):
+        self.is_main = is_main   # False on data-parallel ranks > 0: evaluate (same call sequence on the shared env) but write nothing
         self.recorder = [(0., -np.inf, 0., 0., 0.)]  # total_step, r_avg, r_std, obj_a, obj_c
         self.r_max = -np.inf
         self.total_step = 0
@@ -179,7 +195,8 @@ class Evaluator:
         self.used_time = None
         self.start_time = time.time()
         self.eval_func_time = 1
-        print(f"{'ID':>2}  {'Step':>8}  {'MaxR':>8} |{'avgR':>8}  {'stdR':>8}   {'objA':>8}  {'objC':>8} |")
+        if is_main:
+            print(f"{'ID':>2}  {'Step':>8}  {'MaxR':>8} |{'avgR':>8}  {'stdR':>8}   {'objA':>8}  {'objC':>8} |")
 
     def _returns(self, act, times):
         if hasattr(self.env, "num_envs"):  # one launch sequence evaluates num_envs episodes at once
@@ -196,13 +213,15 @@ class Evaluator:
         r_avg, r_std = float(r.mean()), float(r.std())
         if r_avg > self.r_max:
             self.r_max = r_avg
-            agent.save_load_model(self.cwd, if_save=True)
+            if self.is_main:
+                agent.save_load_model(self.cwd, if_save=True)
         logger.record("rollout/ep_rew_mean", r_avg)
         logger.record("rollout/ep_rew_std", r_std)
         logger.record("rollout/log_rew_max", self.r_max)
-        os.makedirs(os.path.join(self.cwd, "init"), exist_ok=True)
-        agent.save_load_model(os.path.join(self.cwd, "init"), if_save=True)
-        print(f"{self.agent_id:<2}  {self.total_step:8.2e}  {self.r_max:8.2f} |{r_avg:8.2f}  {r_std:8.2f}")
+        if self.is_main:
+            os.makedirs(os.path.join(self.cwd, "init"), exist_ok=True)
+            agent.save_load_model(os.path.join(self.cwd, "init"), if_save=True)
+            print(f"{self.agent_id:<2}  {self.total_step:8.2e}  {self.r_max:8.2f} |{r_avg:8.2f}  {r_std:8.2f}")
         self.recorder.append((self.total_step, r_avg, r_std, 0., 0.))
         return bool(self.r_max > self.target_return)
 
@@ -219,8 +238,9 @@ class Evaluator:
             r_avg, r_std = float(r.mean()), float(r.std())
             if r_avg > self.r_max:
                 self.r_max = r_avg
-                agent.save_load_model(self.cwd, if_save=True)
-                print(f"{self.agent_id:<2}  {self.total_step:8.2e}  {self.r_max:8.2f} |")
+                if self.is_main:
+                    agent.save_load_model(self.cwd, if_save=True)
+                    print(f"{self.agent_id:<2}  {self.total_step:8.2e}  {self.r_max:8.2f} |")
             logger.record("rollout/ep_rew_mean", r_avg)
             logger.record("rollout/ep_rew_std", r_std)
             logger.record("rollout/log_rew_max", self.r_max)
@@ -228,7 +248,8 @@ class Evaluator:
             if_reach_goal = bool(self.r_max > self.target_return)
             if if_reach_goal and self.used_time is None:
                 self.used_time = int(time.time() - self.start_time)
-                print(f"{self.agent_id:<2}  {self.total_step:8.2e}  {self.target_return:8.2f} |"
+                if self.is_main:
+                    print(f"{self.agent_id:<2}  {self.total_step:8.2e}  {self.target_return:8.2f} |"
                       f"{r_avg:8.2f}  {r_std:8.2f}   {self.used_time:>8}  ########")
         self.eval_func_time += 1
         return if_reach_goal

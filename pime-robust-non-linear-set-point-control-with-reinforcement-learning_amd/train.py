@@ -123,7 +123,8 @@ def prepare_train(args, env):
     zero = "-zero" if args.env_zero_noise else ""
     tb = os.path.join(root, f"{args.tensorboard_log}_{args.env}{zero}/")
     configure_logger(args.verbose, tb, tag, True)
-    stamp = time.strftime("%Y-%m-%d-%H_%M_%S", time.localtime())
+    # data-parallel ranks must agree on the run directory (they all watch its `stop` file): rank 0's clock names it
+    stamp = time.strftime("%Y-%m-%d-%H_%M_%S", time.localtime(pdist.broadcast_scalar(time.time())))
     kargs.cwd = os.path.join(root, f"{args.env}{zero}/{tag}/seed{args.seed}/{stamp}")
     return kargs, tb
 
@@ -145,12 +146,13 @@ def main(argv=None):
     kargs.Modular_kwargs = {"integrator_dim": env.n_integrator} if ("modular" in algo and hasattr(env, "n_integrator")) else {}
     kargs.if_residual = hasattr(kargs.agent, "init_actor_zero")   # the reference sets True and crashes for TD3
     agent, _ = train_and_evaluate(kargs)
-    save_dir = os.path.join(kargs.cwd, "final_model")
-    os.makedirs(save_dir, exist_ok=True)
-    agent.save_load_model(save_dir, if_save=True)
-    with open(os.path.join(kargs.cwd, "args.txt"), "w") as f:
-        f.write(str(args))
-    print(f"Finish Training and Saved in {kargs.cwd}")
+    if dp is None or dp.rank == 0:   # the replicas are identical: rank 0 alone writes the run directory
+        save_dir = os.path.join(kargs.cwd, "final_model")
+        os.makedirs(save_dir, exist_ok=True)
+        agent.save_load_model(save_dir, if_save=True)
+        with open(os.path.join(kargs.cwd, "args.txt"), "w") as f:
+            f.write(str(args))
+        print(f"Finish Training and Saved in {kargs.cwd}")
     return agent
 
 

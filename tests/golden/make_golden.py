@@ -428,14 +428,37 @@ def golden_ppo_update_and_explore():
     so the rollout can be replayed with injected draws), the per-episode env draws, the state_dicts before
     and after the update and the minibatch indices the reference drew."""
     from elegantrl.agent_residual import AgentResidualIntegratorModularPPO, AgentResidualPPO
-    from elegantrl.env import PreprocessEnv
-    from elegantrl.replay import ReplayBuffer
     out = {}
-    for tag, Agent, env_id, net_dim, target_step, batch, repeat, lam in [
+    _ppo_cases(out, [
         ("ph", AgentResidualIntegratorModularPPO, PH_ID, 32, 200, 64, 4, 0.99),
         ("wt", AgentResidualPPO, WT_STACK_ID.format(1), 32, 400, 128, 2, 0.97),
-    ]:
-        if tag == "ph":
+    ], with_eval=True)
+    save("ppo_update.npz", **out)
+
+
+def golden_ppo_update_wide():
+    """The same explore_env + update_net recording at the widths the HIP kernels serve (the fused gradient kernels take
+    net_dim 64 / 128 / 256; `ppo_update.npz` is net_dim 32): pH ModularPPO at 128 (run_ph_changing.sh:5), water-tank
+    Integrator ModularPPO at 64, and the reference's live water-tank configuration, ResidualPPO on Stacking10 at
+    net_dim 256 (run_watertank_changing.sh:20-27).  No evaluation episode."""
+    from elegantrl.agent_residual import AgentResidualIntegratorModularPPO, AgentResidualPPO
+    out = {}
+    _ppo_cases(out, [
+        ("ph128", AgentResidualIntegratorModularPPO, PH_ID, 128, 1000, 256, 2, 0.99),
+        ("wt64", AgentResidualIntegratorModularPPO, WT_ID, 64, 400, 128, 2, 0.97),
+        ("wts10_256", AgentResidualPPO, WT_STACK_ID.format(10), 256, 400, 128, 2, 0.97),
+    ], with_eval=False)
+    save("ppo_update_wide.npz", **out)
+
+
+def _ppo_cases(out, cases, with_eval):
+    from elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from elegantrl.env import PreprocessEnv
+    from elegantrl.replay import ReplayBuffer
+    for tag, Agent, env_id, net_dim, target_step, batch, repeat, lam in cases:
+        modular = Agent is AgentResidualIntegratorModularPPO
+        is_ph = env_id == PH_ID
+        if is_ph:
             env = PreprocessEnv(make_ph(), if_print=False)
         else:
             env = PreprocessEnv(gym.make(env_id, reward_type="distance", r=4.0), if_print=False)
@@ -445,7 +468,7 @@ def golden_ppo_update_and_explore():
         torch.manual_seed(seed)
         agent = Agent()
         agent.lambda_gae_adv = lam
-        if tag == "ph":
+        if modular:
             agent.init(net_dim, env.state_dim, env.action_dim, env.n_integrator)
         else:
             agent.init(net_dim, env.state_dim, env.action_dim)
@@ -468,7 +491,7 @@ def golden_ppo_update_and_explore():
 
         def rec_reset():
             s = orig_reset()
-            if tag == "ph":
+            if is_ph:
                 draws.append((u.qww_V, u.qc_V, float(u.state), float(u.r)))
             else:
                 draws.append((u.a1, u.a2, u.Kp, float(u.h1), float(u.h2), float(u.r)))
@@ -502,13 +525,14 @@ def golden_ppo_update_and_explore():
                                         agent.ratio_clip, agent.lambda_entropy])
         out.update(_sd_to_np(f"{tag}:act1", agent.act.state_dict()))
         out.update(_sd_to_np(f"{tag}:cri1", agent.cri.state_dict()))
+        if not with_eval:
+            continue
         # deterministic evaluation episode with the updated policy (run.py:600-619)
         from elegantrl.run import get_episode_return
         env.seed(17)
         np.random.seed(17)
         ret, n = get_episode_return(env, agent.act, torch.device("cpu"))
         out[f"{tag}:eval"] = np.array([ret, n])
-    save("ppo_update.npz", **out)
 
 
 def main():
@@ -516,7 +540,8 @@ def main():
     jobs = dict(ph_table=golden_ph_table, ph_zoh=golden_ph_zoh, ph_rollouts=golden_ph_rollouts,
                 ph_stepresponse=golden_ph_stepresponse, wt_rollouts=golden_wt_rollouts,
                 wt_stepresponse=golden_wt_stepresponse, wt_stacking=golden_wt_stacking,
-                gae=golden_gae, nets=golden_nets, ppo_update=golden_ppo_update_and_explore)
+                gae=golden_gae, nets=golden_nets, ppo_update=golden_ppo_update_and_explore,
+                ppo_update_wide=golden_ppo_update_wide)
     for name, fn in jobs.items():
         if only and name not in only:
             continue

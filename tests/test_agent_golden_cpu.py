@@ -103,6 +103,47 @@ def test_update_net_matches_reference(tag):
     np.testing.assert_allclose([obj_a, obj_c], g[f"{tag}:obj"], rtol=2e-4, atol=1e-5)
 
 
+WIDE = {
+    "ph128": dict(agent="AgentResidualIntegratorModularPPO", integrator=1, K=[-0.02, 0.02, 0.035]),
+    "wt64": dict(agent="AgentResidualIntegratorModularPPO", integrator=1, K=[0., 0.4, -0.4, 0.]),
+    "wts10_256": dict(agent="AgentResidualPPO", integrator=None, K=[0.] * 27 + [0., 0.4, -0.4]),
+}
+
+
+@pytest.mark.parametrize("tag", list(WIDE))
+def test_update_net_matches_reference_at_kernel_widths(tag):
+    """The same host logic at the widths the HIP kernels serve (ppo_update_wide.npz: net_dim 128 / 64 / 256); the GPU
+    twin of this test (test_gpu_update_golden.py) runs the fused kernels against the same reference weights."""
+    from pime_amd.elegantrl import agent_residual
+    from pime_amd.elegantrl.replay import ReplayBuffer
+    g = load_golden("ppo_update_wide.npz")
+    hyper = g[f"{tag}:hyper"]
+    net_dim, target_step, batch, repeat, lam = int(hyper[0]), int(hyper[1]), int(hyper[2]), int(hyper[3]), float(hyper[4])
+    c = WIDE[tag]
+    state, other = g[f"{tag}:buf_state"], g[f"{tag}:buf_other"]
+    ag = getattr(agent_residual, c["agent"])(backend=OracleBackend(), device="cpu")
+    ag.lambda_gae_adv = lam
+    if c["integrator"] is not None:
+        ag.init(net_dim, state.shape[1], 1, c["integrator"])
+    else:
+        ag.init(net_dim, state.shape[1], 1)
+    ag.init_residual({"init_K": np.array(c["K"]).reshape(-1, 1)})
+    ag.fix_K()
+    ag.act.load_state_dict(_sd(g, f"{tag}:act0"))
+    ag.cri.load_state_dict(_sd(g, f"{tag}:cri0"))
+    ag.weights_changed()
+    buf = ReplayBuffer(len(state) + 8, state.shape[1], 1, if_on_policy=True, device="cpu")
+    buf.extend_buffer(state, other)
+    idx = g[f"{tag}:indices"]
+    ag.index_hook = lambda step, L, B: torch.from_numpy(idx[step])
+    obj_a, obj_c = ag.update_net(buf, target_step, batch, repeat)
+    for name, net in (("act1", ag.act), ("cri1", ag.cri)):
+        want = _sd(g, f"{tag}:{name}")
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), want[k].numpy(), rtol=0, atol=2e-6, err_msg=f"{name}.{k}")
+    np.testing.assert_allclose([obj_a, obj_c], g[f"{tag}:obj"], rtol=2e-4, atol=1e-5)
+
+
 def test_evaluation_episode(ph_table_oracle):
     """get_episode_return with the updated reference policy on the seeded env (run.py:600-619)."""
     from pime_amd.elegantrl.run import get_episode_return

@@ -1,0 +1,42 @@
+"""bench.py's own rank launcher: `python bench.py --gpus N` with no WORLD_SIZE in the environment (how the driver starts
+the scaling runs) must start N rank processes before any GPU call, relay rank 0's ONE JSON line and fail loudly -- not at
+an assert in the parent -- when the ranks cannot run.  CPU-only: the rank plumbing runs on gloo (--selftest-launcher);
+the real workload is refused in every child with 'needs an MI355X'."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""   # also on a GPU box this test stays off the card
+    return env
+
+
+def test_parent_spawns_ranks_and_relays_rank0_json():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-launcher"], env=_clean_env(), capture_output=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out == {"selftest": "launcher", "n_gpus": 2, "max_t": 2.0, "sum": 300.0}   # world size from the process group
+
+
+def test_ranks_fail_loudly_without_a_gpu_not_at_a_parent_assert():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_clean_env(),
+                       capture_output=True, timeout=300)
+    err = p.stderr.decode()
+    assert p.returncode != 0
+    assert err.count("needs an MI355X") >= 1 and "AssertionError" not in err
+    assert p.stdout.decode().strip() == ""
+
+
+def test_world_size_mismatch_is_reported():
+    env = dict(_clean_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-launcher"], env=env, capture_output=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr.decode()

@@ -87,3 +87,58 @@ def test_two_rank_gloo(tmp_path):
     assert r[0]["steps"] == r[1]["steps"] == 32 * 50
     assert torch.equal(r[0]["flat"], r[1]["flat"]), "replicas diverged"
     assert not torch.equal(r[0]["obs0"], r[1]["obs0"]), "ranks simulated the same env lanes (lane offset ignored)"
+
+
+def _train_worker(rank, world, port, out_dir):
+    """train_and_evaluate under data parallelism with a target_return only rank 0 can reach: rank 0 alone would leave the
+    loop after the first evaluation and rank 1 would block forever in its next all-reduce (the loop-exit flag is now a
+    MAX all-reduce); torch is re-seeded per rank after the weight broadcast; only rank 0 writes checkpoints."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from oracle.cpu_stack import OracleBackend, OracleVecEnv
+    from pime_amd import dist as pdist
+    from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from pime_amd.elegantrl.run import Arguments, train_and_evaluate
+    dp = pdist.init_from_env(backend="gloo", device="cpu")
+    n = 16
+    env = OracleVecEnv("ph", n, seed=5, env_offset=dp.lane_offset(n))
+    env.env_name = "ph-oracle"
+    env.target_return = -1e9 if rank == 0 else 1e9      # reachable on rank 0 only
+    args = Arguments(if_on_policy=True)
+    args.agent = AgentResidualIntegratorModularPPO(backend=OracleBackend(), device="cpu")
+    args.agent.dp = dp
+    args.env = env
+    args.cwd = os.path.join(out_dir, "run")              # the same directory on every rank, as train.py arranges
+    args.if_remove = False
+    args.net_dim, args.batch_size, args.repeat_times, args.target_step, args.max_memo = 32, 128, 1, n * 50, n * 50
+    args.break_step = 10 * n * 50
+    args.eval_gap, args.eval_times1, args.eval_times2 = 1, n, n
+    args.num_threads = 1
+    args.random_seed = 3
+    args.residual_kwargs = {"init_K": env.K.reshape(-1, 1)}
+    args.Modular_kwargs = {"integrator_dim": 1}
+    args.if_residual = True
+    args.fix_K = True
+    agent, buf = train_and_evaluate(args)
+    flat = torch.cat([p.detach().reshape(-1) for p in list(agent.act.parameters()) + list(agent.cri.parameters())])
+    torch.save({"flat": flat, "noise": buf.noise[:4].clone(), "length": buf.length, "seed": torch.initial_seed()},
+               os.path.join(out_dir, f"train_rank{rank}.pt"))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_train_loop_exits_together(tmp_path):
+    import oracle
+    oracle.build()
+    world, port = 2, _free_port()
+    mp.spawn(_train_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"train_rank{k}.pt"), weights_only=True) for k in range(world)]
+    assert torch.equal(r[0]["flat"], r[1]["flat"]), "replicas diverged"
+    assert r[0]["seed"] == 3 and r[1]["seed"] == 4, "torch was not re-seeded with random_seed + rank"
+    # the goal is 'reached' (rank 0) at the evaluation before the loop: no training iteration runs on EITHER rank
+    assert r[0]["length"] == r[1]["length"] == 0
+    run = os.path.join(tmp_path, "run")
+    assert os.path.exists(os.path.join(run, "actor.pth")) and os.path.exists(os.path.join(run, "init", "critic.pth"))

@@ -4,6 +4,7 @@ advantage normalisation the data-parallel path uses for its buffer-global moment
 child process so that the process group does not leak into the rest of the suite.  (World sizes > 1 are covered on the
 CPU with gloo, tests/test_dist_gloo.py; real multi-GPU runs are the driver's.)"""
 import os
+import socket
 import subprocess
 import sys
 
@@ -48,7 +49,10 @@ print("DP_SINGLE_RANK_OK")
 
 def test_dp_update_path_equals_single_gpu_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:   # a free rendezvous port, not a fixed one another run may hold
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = dict(os.environ, PIME_ROOT=root, PIME_FORCE_DP="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _CHILD], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "DP_SINGLE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

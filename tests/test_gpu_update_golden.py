@@ -1,0 +1,92 @@
+"""AgentPPO.update_net through the HIP path (value pass on the f32 matrix cores, GAE scan kernel, fused gradient
+kernels, flat Adam kernel, re-pack; replayed from HIP graphs) against the REFERENCE's own update_net
+(/root/reference/elegantrl/agent.py:611-664 run by tests/golden/make_golden.py on the unmodified reference):
+`tests/golden/ppo_update_wide.npz` holds the reference's buffer, its minibatch indices and its weights before / after at the
+widths the fused kernels serve (pH ModularPPO net_dim 128 = run_ph_changing.sh; water-tank Integrator ModularPPO 64;
+water-tank Stacking10 ResidualPPO 256 = run_watertank_changing.sh).
+
+Both index paths are run: `index_hook` (one tensor per step -> two captured graphs per optimizer step, [gradients] and
+[Adam, re-pack]) and `index_table_hook` (all minibatches pre-loaded into the index table the kernels walk with a device-side
+row cursor -> ONE captured graph per optimizer step, the path bench.py's timed region replays).
+
+Tolerance: 6-7 Adam steps at lr 1e-4.  Adam normalises the gradient, so a parameter whose gradient is at rounding-noise level
+can move by up to lr per step in either direction: weights agree to 3e-5 abs (most to 1e-6), losses to 1e-3 rel."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = {
+    "ph128": dict(agent="AgentResidualIntegratorModularPPO", integrator=1, K=[-0.02, 0.02, 0.035]),
+    "wt64": dict(agent="AgentResidualIntegratorModularPPO", integrator=1, K=[0., 0.4, -0.4, 0.]),
+    "wts10_256": dict(agent="AgentResidualPPO", integrator=None, K=[0.] * 27 + [0., 0.4, -0.4]),
+}
+
+
+def _sd(g, prefix):
+    return {k[len(prefix) + 1:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(prefix + ".")}
+
+
+def _run(tag, mode):
+    from pime_amd.elegantrl import agent_residual
+    from pime_amd.elegantrl.replay import ReplayBuffer
+    g = load_golden("ppo_update_wide.npz")
+    hyper = g[f"{tag}:hyper"]
+    net_dim, target_step, batch, repeat, lam = int(hyper[0]), int(hyper[1]), int(hyper[2]), int(hyper[3]), float(hyper[4])
+    c = CASES[tag]
+    state, other = g[f"{tag}:buf_state"], g[f"{tag}:buf_other"]
+    D = state.shape[1]
+    ag = getattr(agent_residual, c["agent"])(device=DEV)
+    ag.lambda_gae_adv = lam
+    if c["integrator"] is not None:
+        ag.init(net_dim, D, 1, c["integrator"])
+    else:
+        ag.init(net_dim, D, 1)
+    ag.init_residual({"init_K": np.array(c["K"]).reshape(-1, 1)})
+    ag.fix_K()
+    ag.act.load_state_dict({k: v.to(DEV) for k, v in _sd(g, f"{tag}:act0").items()})
+    ag.cri.load_state_dict({k: v.to(DEV) for k, v in _sd(g, f"{tag}:cri0").items()})
+    ag.weights_changed()
+    buf = ReplayBuffer(len(state) + 8, D, 1, if_on_policy=True, device=DEV)
+    buf.extend_buffer(state, other)
+    idx = torch.from_numpy(g[f"{tag}:indices"])
+    assert idx.shape == (int(repeat * len(state) / batch), batch)
+    if mode == "two_graph":
+        ag.index_hook = lambda step, L, B: idx[step]
+    else:
+        ag.index_table_hook = lambda n, L, B: idx[:n]
+    obj_a, obj_c = ag.update_net(buf, target_step, batch, repeat)
+    torch.cuda.synchronize()
+    fused = ag._packed.get("fused")
+    return g, ag, fused, obj_a, obj_c
+
+
+@pytest.mark.parametrize("mode", ["two_graph", "one_graph"])
+@pytest.mark.parametrize("tag", ["ph128", "wt64", "wts10_256"])   # wts10_256: width 256 + 30-float stacked observation
+def test_hip_update_net_matches_reference_weights(tag, mode):
+    g, ag, fused, obj_a, obj_c = _run(tag, mode)
+    assert fused, f"{tag}: update_net did not take the fused HIP gradient path"
+    st = fused.static
+    if mode == "one_graph":
+        assert st.graph_full is not None and st.graph_a is None, "the one-graph-per-step path was not captured"
+    else:
+        assert st.graph_a is not None and st.graph_b is not None and st.graph_full is None
+    worst = 0.0
+    for name, net in (("act1", ag.act), ("cri1", ag.cri)):
+        want = _sd(g, f"{tag}:{name}")
+        got = net.state_dict()
+        assert set(got) == set(want)
+        for k in want:
+            w, v = want[k].numpy(), got[k].cpu().numpy()
+            err = float(np.abs(w - v).max())
+            worst = max(worst, err)
+            np.testing.assert_allclose(v, w, rtol=0, atol=3e-5, err_msg=f"{tag} {name}.{k}")
+    # the weights moved by ~lr per step: make sure the comparison is not vacuous
+    moved = max(float(np.abs(_sd(g, f"{tag}:act1")[k].numpy() - _sd(g, f"{tag}:act0")[k].numpy()).max())
+                for k in _sd(g, f"{tag}:act0"))
+    assert moved > 3e-4 and worst < 0.1 * moved
+    np.testing.assert_allclose([obj_a, obj_c], g[f"{tag}:obj"], rtol=1e-3, atol=1e-4)
