@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 7
+#define PIME_ABI_VERSION 8
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -175,9 +175,12 @@ int pime_gae_scan(const float* reward, const float* mask, const float* value, in
  *                                params[12] = other_net.0 W,b ; other_net.2 W,b ; integrator_net.0 W,b ;
  *                                integrator_net.2 W,b ; net.0 W,b ; net.2 W,b ; Di = integrator_dim (trailing
  *                                columns of x)
- * All weights are [dev] float32 in nn.Linear layout ([out, in] row-major).  md must be 64 or 128 (the image must
- * fit the 160 KB LDS), D <= 32.  out [dev] float32[M] is the scalar head (value, or pre-tanh action mean without
- * noise and prior term). */
+ * All weights are [dev] float32 in nn.Linear layout ([out, in] row-major).  D <= 32.  Widths: 64 and 128 (every kind: the
+ * whole net stays in the 160 KB LDS of a persistent workgroup, csrc/mlp_mfma.hip) and 256 (CRITIC and PLAIN_ACTOR -- the width
+ * run_watertank_changing.sh:20-27 trains on the 30-float Stacking10 observation: 16-sample tiles on v_mfma_f32_16x16x4_f32 with
+ * the 256 x 256 images streamed through LDS in k-slices, csrc/mlp16.hip).  A MODULAR_ACTOR of width 256 has no kernel: the
+ * size queries return 0 with a message and the Python agents warn and use torch modules on the GPU.
+ * out [dev] float32[M] is the scalar head (value, or pre-tanh action mean without noise and prior term). */
 enum pime_mlp_kind { PIME_MLP_CRITIC = 0, PIME_MLP_PLAIN_ACTOR = 1, PIME_MLP_MODULAR_ACTOR = 2 };
 /* floats in the packed image (0 and an error message if the shape is unsupported) */
 int64_t pime_mlp_packed_floats(int32_t kind, int32_t D, int32_t Di, int32_t md);
@@ -235,10 +238,12 @@ int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const flo
  * separate pack launches cost ~20 us of a ~400 us step). */
 int pime_ppo_repack(const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream);
 /* critic_scale: [dev] float32[1], WRITTEN: 1 / (r_sum[indices].std() + 1e-5) with torch's unbiased std (agent.py:652);
- *               the critic's gradients are multiplied by it (fourth, tiny launch)
+ *               the critic's gradients are multiplied by it (in the slab reduction)
  * moments:      [dev] float64[2], WRITTEN: sum and sum of squares of the minibatch targets r_sum[indices]
- * loss_sums:    [dev] float32[4], ACCUMULATED: sum(-min(surr1,surr2)), sum(exp(logp)*logp), sum(smooth_l1), and the
- *               critic_scale of this call (a running sum over calls, for the logged united loss) */
+ * loss_sums:    [dev] float32[6], ACCUMULATED over calls (zero them per update): [0] sum(-min(surr1,surr2)),
+ *               [1] sum(exp(logp)*logp), [2] sum(smooth_l1), [3] sum of the calls' critic_scale, [4] sum over calls of
+ *               (the call's smooth_l1 sum * its critic_scale) -- the critic part of the logged united loss, agent.py:652 --
+ *               [5] scratch (value of [2] after the previous call) */
 int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* batch,
                             float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
                             float* loss_sums, pime_stream stream);
@@ -253,14 +258,18 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
  *   state  [dev] float32[n_steps+1, N, obs_dim]: slot 0 must hold the current observation on entry (pime_env_reset /
  *          pime_env_observe), slots 1..n_steps are written;  action (pre-tanh), noise, reward [dev] float32[n_steps, N];
  *          done [dev] uint8[n_steps, N];  priorK [host] float64[obs_dim]. */
+/* 1 if pime_rollout serves this env handle with this actor (PIME_STATE_MIXED, pH or water-tank Integrator observation,
+ * width 64 / 128), else 0: the caller then steps the env launch by launch (pime_mlp_forward + pime_env_step_residual). */
+int pime_rollout_supported(const pime_env* env, int32_t kind, int32_t md);
 int pime_rollout(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
                  const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, float* state,
                  float* action, float* noise, float* reward, uint8_t* done, pime_stream stream);
 
 /* replaces: self.optimizer.step() of the single Adam over both nets (elegantrl/agent.py:565-566,656-657; no weight
- * decay, no amsgrad) when every parameter lives in ONE flat tensor.  All [dev] float32[n]; step [dev] float32[1] is the
- * step counter, incremented by the call on the device (so the launch can be replayed from a HIP graph).  Calls on
- * different streams must not overlap (one device-side arrival counter). */
+ * decay, no amsgrad) when every parameter lives in ONE flat tensor.  All [dev] float32[n]; step [dev] float32[2], zeroed
+ * by the caller at construction: step[0] is the step counter, incremented by the call on the device (so the launch can be
+ * replayed from a HIP graph), step[1] is this optimizer's arrival counter (scratch).  One optimizer = one stream at a time;
+ * different optimizers are independent. */
 int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, float* step, pime_stream stream);
 

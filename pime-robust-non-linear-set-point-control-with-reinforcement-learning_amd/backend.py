@@ -5,9 +5,21 @@ The agents take the backend as a constructor argument only so that the *tests* c
 (oracle/cpu_stack.py:OracleBackend) to exercise the host-side update logic in a GPU-less container and under gloo;
 nothing in this package constructs any other backend, and there is no automatic selection or fallback.
 """
+import warnings
+
 import torch
 
 from . import native, ops
+
+_warned = set()
+
+
+def _warn_once(key, msg):
+    """A net shape without a hand-written kernel runs as plain torch modules on the GPU (rocBLAS + autograd): several
+    times slower (profiles/r01_a_*), never silently."""
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 class HipBackend:
@@ -26,14 +38,23 @@ class HipBackend:
         the GPU, i.e. rocBLAS; still not a CPU path)."""
         kind = getattr(module, "packed_kind", None)
         if kind is None or getattr(module, "action_dim", 1) != 1:
+            _warn_once(("fwd", type(module).__name__), f"pime_amd: no fused forward kernel for {type(module).__name__} "
+                       f"(action_dim {getattr(module, 'action_dim', '?')}): using the torch module on the GPU")
             return None
         md = module.net[0].out_features if kind != "modular_actor" else module.other_net[0].out_features
         if not ops.PackedMLP.supported(kind, module.state_dim, getattr(module, "integrator_dim", 0), md):
+            _warn_once(("fwd", kind, md, module.state_dim),
+                       f"pime_amd: no fused forward kernel for {kind} width {md} state_dim {module.state_dim} "
+                       f"({native.last_error()}); using the torch module on the GPU.  Supported: INTEGRATION.md 'Supported shapes'")
             return None
         return ops.PackedMLP.from_module(module)
 
     def fused_ppo(self, act, cri, max_batch):
         """ops.FusedPPOGrad for these nets, or False when their shape has no fused kernel."""
         if not ops.FusedPPOGrad.supported(act, cri):
+            _warn_once(("grad", type(act).__name__, type(cri).__name__, getattr(act, "state_dim", None)),
+                       f"pime_amd: no fused PPO gradient kernel for ({type(act).__name__}, {type(cri).__name__}) at these "
+                       f"shapes ({native.last_error()}); update_net runs through torch autograd on the GPU (several times "
+                       "slower).  Supported: INTEGRATION.md 'Supported shapes'")
             return False
         return ops.FusedPPOGrad(act, cri, max_batch)

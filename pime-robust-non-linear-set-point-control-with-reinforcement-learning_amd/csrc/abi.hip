@@ -45,8 +45,14 @@ int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
 int64_t fused_stash_floats(int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
-int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, float* const*, float* const*, float*, float*,
-                       double*, float*, int, int64_t*, hipStream_t);
+int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, int, int, float* const*, float* const*, float*,
+                       float*, double*, float*, int, int64_t*, hipStream_t);
+int fused_grid(int);
+// mlp16.hip: the streamed 16x16x4 family (width 256; widths 64 / 128 under PIME_MLP16=1)
+bool family16(int, int);
+int grid16(int, int, int);
+int launch_pack16(const PackArgs&, float*, float*, hipStream_t);
+int launch_ppo16(int, int, const PpoArgs&, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
 int launch_dw(const DwArgs&, int, hipStream_t);
 int launch_critic_scale(int, int, float* const*, const double*, int, float*, float*, int64_t*, hipStream_t);
@@ -552,7 +558,10 @@ int64_t pime_ppo_bwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t m
 }
 
 int64_t pime_ppo_workspace_floats(int32_t kind, int32_t B, int32_t md) {
-    if (B < 1 || (md != 64 && md != 128)) { set_error("pime_ppo_workspace_floats: B=%d md=%d", B, md); return 0; }
+    if (B < 1 || (md != 64 && md != 128 && md != 256) || (md == 256 && kind == PIME_MLP_MODULAR_ACTOR)) {
+        set_error("pime_ppo_workspace_floats: B=%d md=%d kind=%d", B, md, kind);
+        return 0;
+    }
     return ppo_workspace_floats(kind, B, md);
 }
 
@@ -560,6 +569,14 @@ int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const flo
                       pime_stream stream) {
     PIME_REQUIRE(params != nullptr && image != nullptr, "pime_ppo_pack_bwd: NULL params/image");
     return launch_pack_bwd(kind, D, Di, md, params, image, static_cast<hipStream_t>(stream));
+}
+
+int pime_rollout_supported(const pime_env* e, int32_t kind, int32_t md) {
+    if (e == nullptr) return 0;
+    if (e->cfg.state_mode != PIME_STATE_MIXED) return 0;
+    if (e->cfg.kind != PIME_ENV_PH && e->cfg.num_stack != 0) return 0;
+    if (kind != PIME_MLP_PLAIN_ACTOR && kind != PIME_MLP_MODULAR_ACTOR) return 0;
+    return (md == 64 || md == 128) && !family16(kind, md) ? 1 : 0;
 }
 
 int pime_rollout(pime_env* e, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
@@ -571,6 +588,8 @@ int pime_rollout(pime_env* e, int32_t kind, int32_t md, const float* packed_acto
                  "pime_rollout: the water-tank Stacking observation is not supported by the fused rollout");
     PIME_REQUIRE(packed_actor && a_std_log && priorK && state && action && noise && reward && done && n_steps >= 1,
                  "pime_rollout: bad arguments");
+    PIME_REQUIRE(pime_rollout_supported(e, kind, md), "pime_rollout: no fused rollout for actor kind %d width %d "
+                 "(pime_rollout_supported)", kind, md);
     if (!e->was_reset) { set_error("pime_rollout before pime_env_reset"); return PIME_ERR_STATE; }
     if (int rc = use_device(e)) return rc;
     RolloutArgs a{};
@@ -608,16 +627,29 @@ int pime_ppo_repack(const pime_ppo_net* actor, const pime_ppo_net* critic, pime_
     if (int rc = check_net(critic, false)) return rc;
     PackArgs pa[2];
     const pime_ppo_net* nets[2] = {critic, actor};
+    bool f16[2];
     for (int k = 0; k < 2; ++k) {
         const pime_ppo_net* n = nets[k];
         pa[k] = PackArgs{};
         const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
         for (int i = 0; i < np; ++i) pa[k].p[i] = n->params[i];
         pa[k].kind = n->kind; pa[k].D = n->D; pa[k].Di = n->Di; pa[k].md = n->md;
+        f16[k] = family16(n->kind, n->md);
     }
-    return launch_repack(pa[0], pa[1], const_cast<float*>(critic->img_fwd), const_cast<float*>(critic->img_bwd),
-                         const_cast<float*>(actor->img_fwd), const_cast<float*>(actor->img_bwd),
-                         static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!f16[0] && !f16[1])
+        return launch_repack(pa[0], pa[1], const_cast<float*>(critic->img_fwd), const_cast<float*>(critic->img_bwd),
+                             const_cast<float*>(actor->img_fwd), const_cast<float*>(actor->img_bwd), s);
+    for (int k = 0; k < 2; ++k) {   // a net of the 16-tile family: one launch packs its forward and transposed images
+        const pime_ppo_net* n = nets[k];
+        if (f16[k]) {
+            if (int rc = launch_pack16(pa[k], const_cast<float*>(n->img_fwd), const_cast<float*>(n->img_bwd), s)) return rc;
+        } else {
+            if (int rc = launch_mlp_pack(n->kind, n->D, n->Di, n->md, n->params, const_cast<float*>(n->img_fwd), s)) return rc;
+            if (int rc = launch_pack_bwd(n->kind, n->D, n->Di, n->md, n->params, const_cast<float*>(n->img_bwd), s)) return rc;
+        }
+    }
+    return PIME_OK;
 }
 
 int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b,
@@ -632,8 +664,14 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
     hipStream_t s = static_cast<hipStream_t>(stream);
     DwArgs dw{};
     static const bool force_split = std::getenv("PIME_PPO_SPLIT") != nullptr;  // A/B knob: the net + dW kernel pipeline
-    const bool split = force_split || !fused_fits(actor->kind, actor->D, actor->Di, actor->md) ||
-                       !fused_fits(critic->kind, critic->D, critic->Di, critic->md);
+    // Which kernel serves which net: the streamed 16-tile family (width 256, any state width <= 32; deterministic slabs), the
+    // LDS-resident fused kernel (64 / 128 while its LDS map fits), or -- for both nets together -- the split net + dW pipeline.
+    const bool f16_net[2] = {family16(critic->kind, critic->md), family16(actor->kind, actor->md)};
+    const bool split = force_split || (!f16_net[1] && !fused_fits(actor->kind, actor->D, actor->Di, actor->md)) ||
+                       (!f16_net[0] && !fused_fits(critic->kind, critic->D, critic->Di, critic->md));
+    PIME_REQUIRE(!(split && (f16_net[0] || f16_net[1])),
+                 "pime_ppo_minibatch_grad: a width-256 net cannot be paired with a net that needs the split pipeline "
+                 "(actor kind %d width %d state_dim %d)", actor->kind, actor->md, actor->D);
     static const bool tracing = std::getenv("PIME_FUSED_TRACE") != nullptr;  // tuning aid: phase marks of workgroup 0
     static long long* trace_dev = nullptr;
     if (tracing && !trace_dev) {
@@ -671,6 +709,14 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         if (const char* e = std::getenv("PIME_STAGGER")) a.stagger = std::atoi(e);  // tuning knob
         const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
         for (int i = 0; i < np; ++i) a.grad[i] = n->grads[i];
+        if (f16_net[k]) {
+            int psize[12];
+            a.slab = n->workspace;
+            a.slab_stride = slab_layout(n->kind, n->D, n->Di, n->md, a.poff, psize);
+            fused_args[k] = a;
+            if (int rc = launch_ppo16(n->kind, n->md, a, s)) return rc;
+            continue;
+        }
         if (!split) {
             int psize[12];
             a.slab = n->workspace + fused_stash_floats(b->B, n->md);
@@ -704,6 +750,8 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
     }
     if (!split)
         return launch_grad_reduce(fused_args[0], fused_args[1], critic->kind, critic->md, actor->kind, actor->md,
+                                  f16_net[0] ? grid16(b->B, critic->md, critic->D) : fused_grid(b->B),
+                                  f16_net[1] ? grid16(b->B, actor->md, actor->D) : fused_grid(b->B),
                                   critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, loss_sums + 3,
                                   b->flags & PIME_PPO_OVERWRITE_GRADS, b->index_row, s);
     return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, loss_sums + 3,

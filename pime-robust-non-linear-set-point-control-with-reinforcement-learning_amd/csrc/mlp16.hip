@@ -1,0 +1,709 @@
+// The 16-sample-tile kernel family: 4-layer MLPs (CriticAdv / ActorPPO / ActorResidualPPO) of width 64, 128 or 256 on
+// v_mfma_f32_16x16x4_f32 with the md x md weight images STREAMED through LDS in k-slices instead of resident in it.
+//
+// replaces (reference, /root/reference): the value pass elegantrl/agent.py:619-620 (net.py:274-277), the policy mean
+// net_residual.py:19-22,45-48, and -- per optimizer step of AgentPPO.update_net, agent.py:629-657 -- gather, compute_logprob,
+// clipped surrogate + entropy proxy, SmoothL1, the united loss and `obj_united.backward()`, at the width the reference's live
+// water-tank script trains (net_dim 256 on the 30-float Stacking10 observation, run_watertank_changing.sh:20-27), which the
+// LDS-resident 32x32x2 family (mlp_mfma.hip / ppo_fused.hip) cannot hold.
+//
+// Why 16-sample tiles: a 16x16 accumulator block is 4 registers, so a whole width-md activation of a tile is md/4 registers
+// per lane (32 at md 128, 64 at md 256) instead of md/2.  At md 256 that is what makes "input + output activation of a layer
+// in registers" possible at all.  Workgroups are FOUR waves (one per SIMD, 64 samples per pass): at md <= 128 the LDS map is
+// under 80 KB, so two independent workgroups share a CU and every SIMD holds two waves whose barrier-separated phases are NOT
+// in lock-step with each other (the 32x32x2 gradient kernel runs one 8-wave workgroup per CU and its matrix pipe idles through
+// every non-MFMA phase: profiles/r01_l_pmc_pipe.json); at md 256 a wave owns its SIMD's whole 512-register file, which is what
+// holds three 64-register activations plus a 64-register gradient patch without a stash.
+//
+// Layout facts (v_mfma_f32_16x16x4_f32; lane l: i = l & 15, g = l >> 4):
+//   A[i][k = g] (weights: i = output feature), B[k = g][j = i] (activations: j = sample), D[4g + r][j] in register r.
+//   So the accumulator of a layer has sample l&15 on the lane and output features 16t + 4g + r in register r of tile t, and
+//   register r of tile t of every lane IS the B operand of the next layer's k-step (t, r), which covers the input features
+//   {16t + 4g' + r : g' = 0..3}: the weight image is packed in that k order ("chain order"), activations never leave
+//   registers between layers.  Weight gradients contract over the SAMPLE axis, which sits on the lanes: both operands go
+//   through a sample-major LDS image (row = one sample's features, pitch md + 16 floats: conflict-free both ways).
+//
+// Gradient kernel, per 64-sample group (4 waves x 16 samples), everything on chip, no activation stash:
+//   forward  h1 = act(W0 x) [MFMA from the LDS-resident first-layer image], h2, h3 [streamed], y [VALU dot + 2 shuffles]
+//   loss gradient, head gradient (DPP row sums), dZ3 in place of h3
+//   dW2 = dZ3^T h2 [2 rounds of 32 samples, operands published from registers], dH2 = W2^T dZ3 [streamed], dZ2
+//   dW1 = dZ2^T h1 [h1 recomputed], dH1 = W1^T dZ2, dZ1,  dW0 = dZ1^T x
+//   partial gradients -> this workgroup's slab (plain stores), summed in slab order by ppo_grad_reduce_kernel: reproducible.
+#include "ppo_device.hpp"
+#include "ppo_train.hpp"
+
+namespace pime {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int k16Threads = 256;
+constexpr int k16Waves = 4;     // one wave per SIMD; a second workgroup on the CU supplies each SIMD's second wave
+constexpr int k16Group = 64;    // samples per workgroup pass: 4 tiles of 16
+constexpr int k16Rounds = k16Waves / 2;
+
+// ---- images ------------------------------------------------------------------------------------------------------------
+// MFMA layer image [k-step][quad q][lane][4]: element e of lane (i, g) of quad q at k-step ks is W[16(4q + e) + i][k(ks, g)],
+// k(ks, g) = 16 (ks >> 2) + 4g + (ks & 3) in chain order, 4 ks + g in natural order (first layer: the B operand is x itself).
+struct Layout16 {
+    int T, Dp, KS0;
+    int w0, b0, w1, b1, w2, b2, w3, b3, total;   // forward image (float offsets)
+};
+struct LayoutB16 {
+    int w2t, w1t, total;                         // backward image: W2^T, W1^T as chain-order layers
+};
+
+__host__ __device__ inline Layout16 layout16(int D, int md) {
+    Layout16 L{};
+    L.T = md / 16;
+    L.Dp = (D + 3) & ~3;
+    L.KS0 = L.Dp / 4;
+    int o = 0;
+    auto seg = [&](int& f, int n) { f = o; o += (n + 3) & ~3; };
+    seg(L.w0, L.KS0 * L.T * 64);
+    seg(L.b0, md);
+    seg(L.w1, md * md);
+    seg(L.b1, md);
+    seg(L.w2, md * md);
+    seg(L.b2, md);
+    seg(L.w3, md);
+    seg(L.b3, 4);
+    L.total = o;
+    return L;
+}
+__host__ __device__ inline LayoutB16 layoutb16(int md) {
+    LayoutB16 L{};
+    L.w2t = 0; L.w1t = md * md; L.total = 2 * md * md;
+    return L;
+}
+
+// W: nn.Linear [O][K] row-major.  transposed: the layer computes V = W^T (outputs = W's columns, k = W's rows).
+__device__ inline void pack16_layer(float* __restrict__ dst, const float* __restrict__ W, int O, int K, int n_out, int n_k,
+                                    int KS, bool natural, bool transposed, int tid, int nthr) {
+    const int Q = n_out / 64 > 0 ? n_out / 64 : 1;   // quads of 4 output tiles (n_out is a multiple of 64)
+    const int n = KS * Q * 256;
+    for (int idx = tid; idx < n; idx += nthr) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) % Q, ks = idx / (Q * 256);
+        const int i = lane & 15, g = lane >> 4;
+        const int out = 16 * (4 * q + e) + i;
+        const int k = natural ? 4 * ks + g : 16 * (ks >> 2) + 4 * g + (ks & 3);
+        float v = 0.f;
+        if (out < n_out && k < n_k) v = transposed ? W[(size_t)k * K + out] : W[(size_t)out * K + k];
+        dst[idx] = v;
+    }
+    (void)O;
+}
+
+__global__ void pack16_kernel(PackArgs a, float* __restrict__ fwd, float* __restrict__ bwd) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+    const int md = a.md;
+    if (fwd) {
+        const Layout16 L = layout16(a.D, md);
+        pack16_layer(fwd + L.w0, a.p[0], md, a.D, md, a.D, L.KS0, true, false, tid, nthr);
+        pack16_layer(fwd + L.w1, a.p[2], md, md, md, md, md / 4, false, false, tid, nthr);
+        pack16_layer(fwd + L.w2, a.p[4], md, md, md, md, md / 4, false, false, tid, nthr);
+        for (int i = tid; i < md; i += nthr) {
+            fwd[L.b0 + i] = a.p[1][i];
+            fwd[L.b1 + i] = a.p[3][i];
+            fwd[L.b2 + i] = a.p[5][i];
+            fwd[L.w3 + i] = a.p[6][i];
+        }
+        if (tid < 4) fwd[L.b3 + tid] = tid == 0 ? a.p[7][0] : 0.f;
+    }
+    if (bwd) {
+        const LayoutB16 L = layoutb16(md);
+        pack16_layer(bwd + L.w2t, a.p[4], md, md, md, md, md / 4, false, true, tid, nthr);
+        pack16_layer(bwd + L.w1t, a.p[2], md, md, md, md, md / 4, false, true, tid, nthr);
+    }
+}
+
+#define PIME16_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int ACT>
+__device__ __forceinline__ float act16(float v) {
+    if constexpr (ACT == 0) return v > 0.f ? v : 0.f;
+    else if constexpr (ACT == 1) return fast_tanh(v);
+    else return v;
+}
+
+// ---- a chain layer with its weight image streamed through two LDS slice buffers ------------------------------------------
+// out = act(W in + b); the whole workgroup calls this together (every wave works on its own 16-sample tile, all share the
+// slices).  Slice = SKS k-steps of the image (16 KB at width <= 128, 32 KB at 256).  Per slice: the loads of the NEXT slice
+// are issued into registers, the MFMAs of this slice run from LDS, then the registers are written to the other buffer and
+// ONE barrier both publishes it and retires this slice's reads.  wbuf must be free on entry (callers barrier before).
+template <int T, int ACT, bool HAS_BIAS>
+__device__ __forceinline__ void layer16(const float* __restrict__ gimg, const float* __restrict__ bias, float* __restrict__ wbuf,
+                                        int lane, int tid, const f32x4 (&in)[T], f32x4 (&out)[T]) {
+    constexpr int Q = T / 4;
+    constexpr int KS = T * 4;                       // k-steps of the layer (width / 4)
+    constexpr int SKS = T >= 8 ? 8 : KS;            // k-steps per slice
+    constexpr int NS = KS / SKS;
+    constexpr int SLICE = SKS * Q * 256;            // floats
+    constexpr int PER = SLICE / 4 / k16Threads;     // float4 per thread per slice
+    static_assert(SLICE / 4 % k16Threads == 0, "slice must split evenly over the workgroup");
+    const int g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if constexpr (HAS_BIAS) out[t] = *reinterpret_cast<const f32x4*>(bias + t * 16 + 4 * g);
+        else out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float4* src = reinterpret_cast<const float4*>(gimg) + tid;
+    float4 stage[PER];
+#pragma unroll
+    for (int p = 0; p < PER; ++p) stage[p] = src[p * k16Threads];
+#pragma unroll
+    for (int p = 0; p < PER; ++p) reinterpret_cast<float4*>(wbuf)[tid + p * k16Threads] = stage[p];
+    PIME16_BARRIER();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int p = 0; p < PER; ++p) stage[p] = src[(s + 1) * (SLICE / 4) + p * k16Threads];
+        }
+        const float4* wl = reinterpret_cast<const float4*>(wbuf + (s & 1) * SLICE) + lane;
+#pragma unroll
+        for (int ksl = 0; ksl < SKS; ++ksl) {
+            if ((ksl & 1) == 0) PIME_NO_HOIST();     // bound the weight-fragment prefetch depth
+            const int ks = s * SKS + ksl;
+            const float b = in[ks >> 2][ks & 3];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float4 w = wl[(ksl * Q + q) * 64];
+                out[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b, out[4 * q + 0], 0, 0, 0);
+                out[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b, out[4 * q + 1], 0, 0, 0);
+                out[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b, out[4 * q + 2], 0, 0, 0);
+                out[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b, out[4 * q + 3], 0, 0, 0);
+            }
+        }
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int p = 0; p < PER; ++p)
+                reinterpret_cast<float4*>(wbuf + ((s + 1) & 1) * SLICE)[tid + p * k16Threads] = stage[p];
+        }
+        PIME16_BARRIER();   // next slice published; this slice's reads retired (after the last slice: wbuf is free again)
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[t][r] = act16<ACT>(out[t][r]);
+}
+
+template <int T>
+__host__ __device__ constexpr int layer16_lds_floats() {
+    return 2 * ((T >= 8 ? 8 : T * 4) * (T / 4) * 256);
+}
+
+// First layer from the LDS-resident natural-order image: h = act(W0 x + b0), x[s][4 ks + g] in xr[ks].
+template <int T, int ACT>
+__device__ __forceinline__ void first16(const float* __restrict__ w0, const float* __restrict__ b0, int KS0, int lane,
+                                        const float (&xr)[8], f32x4 (&out)[T]) {
+    constexpr int Q = T / 4;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < T; ++t) out[t] = *reinterpret_cast<const f32x4*>(b0 + t * 16 + 4 * g);
+    const float4* wl = reinterpret_cast<const float4*>(w0) + lane;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (ks < KS0) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float4 w = wl[(ks * Q + q) * 64];
+                out[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, xr[ks], out[4 * q + 0], 0, 0, 0);
+                out[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, xr[ks], out[4 * q + 1], 0, 0, 0);
+                out[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, xr[ks], out[4 * q + 2], 0, 0, 0);
+                out[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, xr[ks], out[4 * q + 3], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[t][r] = act16<ACT>(out[t][r]);
+}
+
+// y = w3 . h + b3: every lane sums its 4T features, the four feature groups of a sample are lanes l, l^16, l^32, l^48.
+template <int T>
+__device__ __forceinline__ float head16(const float* __restrict__ w3, float b3, int lane, const f32x4 (&h)[T]) {
+    const int g = lane >> 4;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(w3 + t * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = fmaf(h[t][r], w[r], acc);
+    }
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    return acc + b3;
+}
+
+// Sum over the 16 lanes of this lane's row (= the 16 samples of the tile at fixed feature group); valid in lane 15 of the row.
+__device__ __forceinline__ float row_sum16(float v) {
+#define PIME16_DPP(x, ctrl) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, true))
+    PIME16_DPP(v, 0x111);  // row_shr:1
+    PIME16_DPP(v, 0x112);  // row_shr:2
+    PIME16_DPP(v, 0x114);  // row_shr:4
+    PIME16_DPP(v, 0x118);  // row_shr:8
+#undef PIME16_DPP
+    return v;
+}
+
+// ---- weight gradient of one layer: dW[a][b] = sum over the group's 128 samples of A[s][a] B[s][b] ---------------------------
+// Two rounds of 32 samples (tiles 2t, 2t+1: waves 2t and 2t+1 publish their tile's A rows and B rows into the sample-major
+// image X); every wave owns an NA x NB patch of 16x16 output blocks per pass.  NBUF = 2: the next round is published while this
+// one is multiplied (one barrier per round); NBUF = 1: two barriers per round, half the LDS.
+template <int TA, int TB>
+struct Dw16Plan {
+    static constexpr int NBLK = TA * TB;
+    static constexpr int TOT = (NBLK + k16Waves - 1) / k16Waves;
+    static constexpr int NB = TB >= 4 ? 4 : TB;
+    static constexpr int PERP = TOT < 16 ? TOT : 16;
+    static constexpr int NA = PERP / NB > 0 ? PERP / NB : 1;
+    static constexpr int PR = TB / NB;                        // patches per row of A tiles
+    static constexpr int NPATCH = (TA / NA) * PR;
+    static constexpr int PASSES = (NPATCH + k16Waves - 1) / k16Waves;
+    static constexpr int PA = TA * 16 + 16, PB = TB * 16 + 16;
+    static constexpr int BUF = 32 * PA + 32 * PB;             // floats of one round image
+    static_assert(TA % NA == 0 && TB % NB == 0, "patches must tile the block grid");
+};
+
+template <int TA, int TB, int NBUF, class PubA, class PubB>
+__device__ __forceinline__ void dw16(float* __restrict__ X, int lane, int wave, const PubA& pub_a, const PubB& pub_b,
+                                     float* __restrict__ gW, int ldw, int ncols, float* __restrict__ gb, bool accum) {
+    using P = Dw16Plan<TA, TB>;
+    constexpr int NA = P::NA, NB = P::NB;
+    const int i = lane & 15, kk = lane >> 4;
+#pragma unroll 1
+    for (int pass = 0; pass < P::PASSES; ++pass) {
+        const int patch = pass * k16Waves + wave;
+        const bool active = patch < P::NPATCH;
+        const int a0 = active ? (patch / P::PR) * NA : 0, b0 = active ? (patch % P::PR) * NB : 0;
+        f32x4 acc[NA][NB];
+        float bsum[NA];
+#pragma unroll
+        for (int x = 0; x < NA; ++x) {
+            bsum[x] = 0.f;
+#pragma unroll
+            for (int y = 0; y < NB; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        auto publish = [&](int t, float* buf) {
+            if ((wave >> 1) == t) {
+                float* rows = buf + ((wave & 1) * 16 + i) * P::PA;
+                pub_a(rows);
+                float* rowsb = buf + 32 * P::PA + ((wave & 1) * 16 + i) * P::PB;
+                pub_b(rowsb);
+            }
+        };
+        PIME16_BARRIER();   // X free (previous job / pass / chain layer done with the region)
+        if constexpr (NBUF == 2) publish(0, X);
+#pragma unroll 1
+        for (int t = 0; t < k16Rounds; ++t) {
+            float* cur = X;
+            if constexpr (NBUF == 2) {
+                PIME16_BARRIER();   // round t published; round t-1's reads of the other buffer retired
+                cur = X + (t & 1) * P::BUF;
+                if (t + 1 < k16Rounds) publish(t + 1, X + ((t + 1) & 1) * P::BUF);
+            } else {
+                if (t > 0) PIME16_BARRIER();   // round t-1's reads retired
+                publish(t, X);
+                PIME16_BARRIER();
+            }
+            PIME_NO_HOIST();
+            if (active) {
+                const float* Ap = cur + kk * P::PA + a0 * 16 + i;
+                const float* Bp = cur + 32 * P::PA + kk * P::PB + b0 * 16 + i;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if ((ks & 1) == 0) PIME_NO_HOIST();   // bound the operand prefetch depth
+                    float av[NA], bv[NB];
+#pragma unroll
+                    for (int x = 0; x < NA; ++x) av[x] = Ap[4 * ks * P::PA + x * 16];
+#pragma unroll
+                    for (int y = 0; y < NB; ++y) bv[y] = Bp[4 * ks * P::PB + y * 16];
+#pragma unroll
+                    for (int x = 0; x < NA; ++x) {
+#pragma unroll
+                        for (int y = 0; y < NB; ++y)
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+                        bsum[x] += av[x];
+                    }
+                }
+            }
+        }
+        if (active) {
+            // block (x, y): register r of lane (j = i, g = kk) is D[16 (a0+x) + 4g + r][16 (b0+y) + j]
+#pragma unroll
+            for (int x = 0; x < NA; ++x) {
+#pragma unroll
+                for (int y = 0; y < NB; ++y) {
+                    const int col = (b0 + y) * 16 + i;
+                    int base = ((a0 + x) * 16 + 4 * kk) * ldw + col;
+                    asm volatile("" : "+v"(base));
+                    if (col < ncols) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* qd = &gW[base + r * ldw];
+                            *qd = accum ? *qd + acc[x][y][r] : acc[x][y][r];
+                        }
+                    }
+                }
+                float bs = bsum[x];
+                bs += __shfl_xor(bs, 16);
+                bs += __shfl_xor(bs, 32);
+                if (gb && b0 == 0 && kk == 0) {
+                    float* qd = &gb[(a0 + x) * 16 + i];
+                    *qd = accum ? *qd + bs : bs;
+                }
+            }
+        }
+    }
+}
+
+template <int TA, int TB, int NBUF>
+__host__ __device__ constexpr int dw16_lds_floats() { return NBUF * Dw16Plan<TA, TB>::BUF; }
+
+// publishers: a tile in accumulator layout (lane (s, g): features 16t + 4g + r) -> its row of the sample-major image
+template <int TT>
+struct PubAcc16 {
+    const f32x4 (&v)[TT];
+    int g;
+    __device__ __forceinline__ void operator()(float* row) const {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) *reinterpret_cast<f32x4*>(row + t * 16 + 4 * g) = v[t];
+    }
+};
+// the raw state: lane (s, g) holds x[s][4 ks + g]; columns >= Dp are zero-filled up to the tile edge
+struct PubX16 {
+    const float (&xr)[8];
+    int g, KS0, cols;
+    __device__ __forceinline__ void operator()(float* row) const {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (ks < KS0) row[4 * ks + g] = xr[ks];
+        for (int c = 4 * KS0 + g; c < cols; c += 4) row[c] = 0.f;
+    }
+};
+
+// ---- LDS map ---------------------------------------------------------------------------------------------------------
+struct Lds16 {
+    int w0, b0, b1, b2, w3, b3, wsum, region, total;
+};
+template <int T>
+__host__ __device__ inline Lds16 lds16(int D, bool grad) {
+    const int md = T * 16;
+    const Layout16 L = layout16(D, md);
+    Lds16 S{};
+    int o = 0;
+    auto seg = [&](int& f, int n) { f = o; o += (n + 3) & ~3; };
+    seg(S.w0, L.KS0 * T * 64);
+    seg(S.b0, md); seg(S.b1, md); seg(S.b2, md); seg(S.w3, md); seg(S.b3, 4);
+    seg(S.wsum, k16Waves * 6 * 2);
+    int region = layer16_lds_floats<T>();
+    if (grad) {
+        constexpr int NBUF = T <= 8 ? 2 : 1;
+        const int dwf = dw16_lds_floats<T, T, NBUF>();
+        region = region > dwf ? region : dwf;
+        const int hacc = k16Waves * md;
+        region = region > hacc ? region : hacc;
+    }
+    seg(S.region, region);
+    S.total = o;
+    return S;
+}
+
+template <int T>
+__device__ __forceinline__ void stage_small16(float* lds, const Lds16& S, const float* __restrict__ img, const Layout16& L, int tid) {
+    const int md = T * 16;
+    const int n0 = L.KS0 * T * 64;
+    for (int e = tid; e < n0 / 4; e += k16Threads) reinterpret_cast<float4*>(lds + S.w0)[e] = reinterpret_cast<const float4*>(img + L.w0)[e];
+    for (int e = tid; e < md; e += k16Threads) {
+        lds[S.b0 + e] = img[L.b0 + e];
+        lds[S.b1 + e] = img[L.b1 + e];
+        lds[S.b2 + e] = img[L.b2 + e];
+        lds[S.w3 + e] = img[L.w3 + e];
+    }
+    if (tid < 4) lds[S.b3 + tid] = img[L.b3 + tid];
+}
+
+__device__ __forceinline__ void gather_x16(const float* __restrict__ xrow, int D, int KS0, int g, float (&xr)[8]) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int c = 4 * ks + g;
+        xr[ks] = (ks < KS0 && c < D) ? xrow[c] : 0.f;
+    }
+}
+
+// ---- forward only: value pass / policy mean --------------------------------------------------------------------------
+template <int T, int ACT>
+__global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void mlp16_forward_kernel(const float* __restrict__ x, int M, int D,
+                                                                                    const float* __restrict__ img,
+                                                                                    float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int md = T * 16;
+    const Layout16 L = layout16(D, md);
+    const Lds16 S = lds16<T>(D, false);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 15, g = lane >> 4;
+    stage_small16<T>(lds, S, img, L, tid);
+    __syncthreads();
+    const int ngroups = (M + k16Group - 1) / k16Group;
+#pragma unroll 1
+    for (int group = blockIdx.x; group < ngroups; group += gridDim.x) {
+        const int m = group * k16Group + wave * 16 + s;
+        float xr[8];
+        gather_x16(x + (size_t)(m < M ? m : M - 1) * D, D, L.KS0, g, xr);
+        f32x4 h1[T], h2[T];
+        first16<T, ACT>(lds + S.w0, lds + S.b0, L.KS0, lane, xr, h1);
+        PIME_NO_HOIST();
+        layer16<T, ACT, true>(img + L.w1, lds + S.b1, lds + S.region, lane, tid, h1, h2);
+        PIME_NO_HOIST();
+        layer16<T, ACT, true>(img + L.w2, lds + S.b2, lds + S.region, lane, tid, h2, h1);
+        const float y = head16<T>(lds + S.w3, lds[S.b3], lane, h1);
+        if (g == 0 && m < M) out[m] = y;
+    }
+}
+
+// ---- PPO minibatch gradients of one net ------------------------------------------------------------------------------
+template <int T, bool ACTOR>
+__global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int ACT = ACTOR ? 1 : 0;
+    constexpr int md = T * 16;
+    constexpr int NBUF = T <= 8 ? 2 : 1;
+    const Layout16 L = layout16(a.D, md);
+    const LayoutB16 Lb = layoutb16(md);
+    const Lds16 S = lds16<T>(a.D, true);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const region = lds + S.region;
+    double* const wsum = reinterpret_cast<double*>(lds + S.wsum);   // [wave][6]
+    stage_small16<T>(lds, S, a.img_fwd, L, tid);
+    if (tid < k16Waves * 6) wsum[tid] = 0.0;
+    __syncthreads();
+    const int ngroups = (a.B + k16Group - 1) / k16Group;
+    const float invB = 1.0f / (float)a.B;
+    float* const sl = a.slab + (size_t)blockIdx.x * a.slab_stride;   // this workgroup's partial gradients
+
+#pragma unroll 1
+    for (int group = blockIdx.x; group < ngroups; group += gridDim.x) {
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));   // keep per-lane offsets inside the loop (hipcc hoists and spills them otherwise)
+        const int s = lane & 15, g = lane >> 4;
+        const bool accum = group != (int)blockIdx.x;
+        const int pos = group * k16Group + wave * 16 + s;
+        const bool valid = pos < a.B;
+        const int64_t* const idx = a.indices + (a.index_row ? (size_t)a.index_row[0] * a.B : 0);
+        const long long row = idx[valid ? pos : a.B - 1];
+        float xr[8];
+        gather_x16(a.state + (size_t)row * a.D, a.D, L.KS0, g, xr);
+        const float in_rsum = ACTOR ? 0.f : a.r_sum[row];
+        const float in_action = ACTOR ? a.action[row] : 0.f;
+        const float in_logprob = ACTOR ? a.logprob[row] : 0.f;
+        const float in_adv = ACTOR ? a.adv[row] : 0.f;
+
+        // ------------------------------------------------------------------------------------------ forward
+        f32x4 h2[T], h3[T];
+        {
+            f32x4 h1[T];
+            first16<T, ACT>(lds + S.w0, lds + S.b0, L.KS0, lane, xr, h1);
+            PIME_NO_HOIST();
+            layer16<T, ACT, true>(a.img_fwd + L.w1, lds + S.b1, region, lane, tid, h1, h2);
+        }
+        PIME_NO_HOIST();
+        layer16<T, ACT, true>(a.img_fwd + L.w2, lds + S.b2, region, lane, tid, h2, h3);
+        const float y = head16<T>(lds + S.w3, lds[S.b3], lane, h3);
+
+        // ------------------------------------------------------------------------------------------ loss gradient
+        float dout = 0.f, s0 = 0.f, s1 = 0.f, gstd = 0.f;
+        double m1 = 0.0, m2 = 0.0;
+        if (valid) {
+            if constexpr (!ACTOR) {
+                const float d = y - in_rsum, ad = fabsf(d);         // SmoothL1, beta = 1 (agent.py:567,649)
+                const float l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+                const float gl = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+                dout = gl * invB;   // unscaled: the slab reduction applies 1/(std+1e-5) (agent.py:652)
+                if (g == 0) { s0 = l; m1 = (double)in_rsum; m2 = (double)in_rsum * (double)in_rsum; }
+            } else {
+                const float asl = a.a_std_log[0], inv_sigma = __expf(-asl);
+                const float z = (y - in_action) * inv_sigma;
+                const float logp = -(asl + kLogSqrt2Pi + 0.5f * z * z);           // compute_logprob
+                const float ratio = __expf(logp - in_logprob);
+                const float lo = 1.f - a.ratio_clip, hi = 1.f + a.ratio_clip;
+                const float clamped = fminf(fmaxf(ratio, lo), hi);
+                const float u = in_adv * ratio, c = in_adv * clamped;             // agent.py:639-641
+                const float w_u = u < c ? 1.f : (u == c ? 0.5f : 0.f);            // torch.min backward (ties split)
+                const float w_c = c < u ? 1.f : (u == c ? 0.5f : 0.f);
+                const bool in_range = ratio >= lo && ratio <= hi;
+                const float g_sur = w_u * u + (in_range ? w_c * u : 0.f);
+                const float p = __expf(logp);
+                const float g_logp = (-g_sur + a.lambda_entropy * p * (logp + 1.f)) * invB;
+                dout = g_logp * (-z * inv_sigma);
+                if (g == 0) { gstd = g_logp * (z * z - 1.f); s0 = -fminf(u, c); s1 = p * logp; }
+            }
+        }
+        {
+            float ghb = g == 0 ? dout : 0.f;   // head bias gradient
+            s0 = wave_sum(s0); s1 = wave_sum(s1); gstd = wave_sum(gstd); ghb = wave_sum(ghb);
+            if constexpr (!ACTOR) {
+                for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+            }
+            if (lane == 0) {
+                double* w = wsum + wave * 6;
+                w[0] += s0; w[1] += s1; w[2] += gstd; w[3] += ghb; w[4] += m1; w[5] += m2;
+            }
+        }
+        // head weight gradient: sum over the tile's samples of dOut h3 (DPP row sums), per wave into the (free) region,
+        // then over the waves in wave order; dZ3 = (w3 dOut) . act'(h3) replaces h3
+        {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(lds + S.w3 + t * 16 + 4 * g);
+                f32x4 hs;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    hs[r] = row_sum16(dout * h3[t][r]);
+                    h3[t][r] = w[r] * dout * act_grad_from_output<ACT>(h3[t][r]);
+                }
+                if (s == 15) *reinterpret_cast<f32x4*>(region + wave * md + t * 16 + 4 * g) = hs;
+            }
+            PIME16_BARRIER();
+            if (tid < md) {
+                float t8 = region[tid];
+                for (int w = 1; w < k16Waves; ++w) t8 += region[w * md + tid];
+                float* qd = &sl[a.poff[6] + tid];
+                *qd = accum ? *qd + t8 : t8;
+            }
+        }
+        // ------------------------------------------------------------------------------------------ backward
+        PIME_NO_HOIST();
+        dw16<T, T, NBUF>(region, lane, wave, PubAcc16<T>{h3, g}, PubAcc16<T>{h2, g}, sl + a.poff[4], md, md, sl + a.poff[5], accum);   // net.4
+        f32x4 d2[T];
+        PIME16_BARRIER();
+        layer16<T, 2, false>(a.img_bwd + Lb.w2t, nullptr, region, lane, tid, h3, d2);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d2[t][r] *= act_grad_from_output<ACT>(h2[t][r]);                                                 // dZ2
+        f32x4(&h1)[T] = h2;   // h2 is dead: its registers take the recomputed first-layer activation
+        PIME_NO_HOIST();
+        first16<T, ACT>(lds + S.w0, lds + S.b0, L.KS0, lane, xr, h1);
+        dw16<T, T, NBUF>(region, lane, wave, PubAcc16<T>{d2, g}, PubAcc16<T>{h1, g}, sl + a.poff[2], md, md, sl + a.poff[3], accum);   // net.2
+        f32x4(&d1)[T] = h3;   // dZ3 is dead
+        PIME16_BARRIER();
+        layer16<T, 2, false>(a.img_bwd + Lb.w1t, nullptr, region, lane, tid, d2, d1);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d1[t][r] *= act_grad_from_output<ACT>(h1[t][r]);                                                 // dZ1
+        PIME_NO_HOIST();
+        if (L.Dp <= 16)
+            dw16<T, 1, NBUF>(region, lane, wave, PubAcc16<T>{d1, g}, PubX16{xr, g, L.KS0, 16}, sl + a.poff[0], a.D, a.D, sl + a.poff[1], accum);
+        else
+            dw16<T, 2, NBUF>(region, lane, wave, PubAcc16<T>{d1, g}, PubX16{xr, g, L.KS0, 32}, sl + a.poff[0], a.D, a.D, sl + a.poff[1], accum);
+        PIME16_BARRIER();   // the next group's first chain layer writes the region
+    }
+
+    // ---- workgroup totals of the scalar sums, in a fixed order (only the logged loss sums use atomics)
+    __syncthreads();
+    if (tid == 0) {
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < k16Waves; ++w)
+            for (int k = 0; k < 6; ++k) t[k] += wsum[w * 6 + k];
+        sl[a.poff[7]] = (float)t[3];                  // head bias
+        if constexpr (!ACTOR) {
+            atomicAdd(&a.loss_sums[2], (float)t[0]);
+            double* mo = reinterpret_cast<double*>(sl + a.poff[8]);
+            mo[0] = t[4]; mo[1] = t[5];
+        } else {
+            atomicAdd(&a.loss_sums[0], (float)t[0]);
+            atomicAdd(&a.loss_sums[1], (float)t[1]);
+            sl[a.poff[8]] = (float)t[2];              // d loss / d a_std_log
+        }
+    }
+}
+
+// ==================================================================================================== host side
+bool family16(int kind, int md) {
+    if (kind == MLP_MODULAR_ACTOR) return false;
+    if (md == 256) return true;
+    static const bool forced = std::getenv("PIME_MLP16") != nullptr;   // A/B knob: serve widths 64 / 128 from this family too
+    return forced && (md == 64 || md == 128);
+}
+
+int64_t packed16_floats(int D, int md) { return layout16(D, md).total; }
+int64_t bwd16_floats(int md) { return layoutb16(md).total; }
+
+int launch_pack16(const PackArgs& a, float* fwd, float* bwd, hipStream_t s) {
+    hipLaunchKernelGGL(pack16_kernel, dim3(128), dim3(256), 0, s, a, fwd, bwd);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+template <int T>
+static int wgs_per_cu(size_t lds_bytes) {
+    const int by_lds = (int)((160 * 1024) / lds_bytes);
+    const int by_regs = T <= 8 ? 2 : 1;
+    return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
+}
+
+int grid16(int B, int md, int D) {
+    const int ngroups = (B + k16Group - 1) / k16Group;
+    size_t lds = 0;
+    int per = 1;
+    if (md == 64) { lds = sizeof(float) * lds16<4>(D, true).total; per = wgs_per_cu<4>(lds); }
+    else if (md == 128) { lds = sizeof(float) * lds16<8>(D, true).total; per = wgs_per_cu<8>(lds); }
+    else { lds = sizeof(float) * lds16<16>(D, true).total; per = wgs_per_cu<16>(lds); }
+    const int cap = 256 * per;
+    return ngroups < cap ? ngroups : cap;
+}
+
+template <int T, int ACT>
+static int launch_fwd16(const float* x, int M, int D, const float* img, float* out, hipStream_t s) {
+    const size_t lds_bytes = sizeof(float) * (size_t)lds16<T>(D, false).total;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp16_forward_kernel<T, ACT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int ngroups = (M + k16Group - 1) / k16Group;
+    const int cap = 256 * wgs_per_cu<T>(lds_bytes);
+    hipLaunchKernelGGL((mlp16_forward_kernel<T, ACT>), dim3(ngroups < cap ? ngroups : cap), dim3(k16Threads), lds_bytes, s, x, M,
+                       D, img, out);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+int launch_forward16(int kind, const float* x, int M, int D, int md, const float* img, float* out, hipStream_t s) {
+    const int T = md / 16;
+#define PIME_F16(TT) \
+    if (T == TT) return kind == MLP_CRITIC ? launch_fwd16<TT, 0>(x, M, D, img, out, s) : launch_fwd16<TT, 1>(x, M, D, img, out, s);
+    PIME_F16(4) PIME_F16(8) PIME_F16(16)
+#undef PIME_F16
+    set_error("no 16-tile forward for width %d", md);
+    return PIME_ERR_ARG;
+}
+
+template <int T, bool ACTOR>
+static int launch_grad16(const PpoArgs& a, hipStream_t s) {
+    const size_t lds_bytes = sizeof(float) * (size_t)lds16<T>(a.D, true).total;
+    PIME_REQUIRE(lds_bytes <= 160 * 1024, "16-tile PPO kernel needs %zu B of LDS", lds_bytes);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo16_kernel<T, ACTOR>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ppo16_kernel<T, ACTOR>), dim3(grid16(a.B, T * 16, a.D)), dim3(k16Threads), lds_bytes, s, a);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+int launch_ppo16(int kind, int md, const PpoArgs& a, hipStream_t s) {
+    const int T = md / 16;
+#define PIME_G16(TT) \
+    if (T == TT) return kind == MLP_CRITIC ? launch_grad16<TT, false>(a, s) : launch_grad16<TT, true>(a, s);
+    PIME_G16(4) PIME_G16(8) PIME_G16(16)
+#undef PIME_G16
+    set_error("no 16-tile PPO kernel for width %d", md);
+    return PIME_ERR_ARG;
+}
+
+}  // namespace pime

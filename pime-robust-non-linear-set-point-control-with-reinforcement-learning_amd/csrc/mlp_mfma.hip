@@ -80,7 +80,14 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const float* _
 }
 
 // ---- host launchers ---------------------------------------------------------------------------------------------
-int64_t mlp_packed_floats(int kind, int D, int Di, int md) { return mlp_layout(kind, D, Di, md).total; }
+bool family16(int kind, int md);
+int64_t packed16_floats(int D, int md);
+int launch_pack16(const PackArgs& a, float* fwd, float* bwd, hipStream_t s);
+int launch_forward16(int kind, const float* x, int M, int D, int md, const float* img, float* out, hipStream_t s);
+
+int64_t mlp_packed_floats(int kind, int D, int Di, int md) {
+    return family16(kind, md) ? packed16_floats(D, md) : (int64_t)mlp_layout(kind, D, Di, md).total;
+}
 
 int mlp_check(int kind, int D, int Di, int md) {
     PIME_REQUIRE(kind >= MLP_CRITIC && kind <= MLP_MODULAR_ACTOR, "mlp kind %d unknown", kind);
@@ -89,8 +96,8 @@ int mlp_check(int kind, int D, int Di, int md) {
         PIME_REQUIRE(Di >= 1 && Di < D, "integrator_dim %d must be in [1, state_dim)", Di);
         PIME_REQUIRE(md == 64 || md == 128, "fused modular-actor forward supports width 64 or 128, got %d", md);
     } else {
-        PIME_REQUIRE(md == 64 || md == 128, "fused MLP forward supports width 64 or 128, got %d "
-                     "(width 256 does not fit the 160 KB LDS-resident design)", md);
+        // 64 / 128: the LDS-resident 32x32x2 family (this file, ppo_fused.hip); 256: the streamed 16x16x4 family (mlp16.hip)
+        PIME_REQUIRE(md == 64 || md == 128 || md == 256, "fused MLP kernels support width 64, 128 or 256, got %d", md);
     }
     return PIME_OK;
 }
@@ -104,6 +111,7 @@ int launch_mlp_pack(int kind, int D, int Di, int md, const float* const* params,
         a.p[i] = params[i];
     }
     a.kind = kind; a.D = D; a.Di = Di; a.md = md;
+    if (family16(kind, md)) return launch_pack16(a, packed, nullptr, s);
     hipLaunchKernelGGL(mlp_pack_kernel, dim3(64), dim3(256), 0, s, a, packed);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
@@ -136,6 +144,7 @@ int launch_mlp_forward(int kind, const float* x, int M, int D, int Di, int md, c
                        hipStream_t s) {
     if (int rc = mlp_check(kind, D, Di, md)) return rc;
     PIME_REQUIRE(M >= 1, "M = %d rows", M);
+    if (family16(kind, md)) return launch_forward16(kind, x, M, D, md, packed, out, s);
     const int T = md / 32;
 #define PIME_FWD(TT, KK) \
     if (T == TT && kind == KK) return launch_fwd<TT, KK>(x, M, D, Di, packed, out, s);

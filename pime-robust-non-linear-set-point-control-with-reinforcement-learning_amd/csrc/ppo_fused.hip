@@ -876,8 +876,8 @@ struct ReduceSeg {
 };
 struct ReduceArgs {
     ReduceSeg seg[24];
-    int nseg, nslabs, B, moments_off, overwrite;
-    float* scale_sum;   // += scale (running sum over calls, for the logged united loss)
+    int nseg, nslabs[2], B, moments_off, overwrite;   // nslabs per net (the two nets may come from different kernel families)
+    float* scale_sum;   // loss_sums + 3: [0] += scale, [1] += critic loss sum of this call * scale, [2] = critic sum so far
     int64_t* index_row; // NULL, or the index table's row cursor: advanced once per call, after both nets read it
     const float* slab[2];
     int stride[2];
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
     const ReduceSeg sg = a.seg[si];
     if (wave == 0) {  // critic scale from the moments (every workgroup: same slabs, same order, same value)
         double m1 = 0.0, m2 = 0.0;
-        for (int s = lane; s < a.nslabs; s += 64) {
+        for (int s = lane; s < a.nslabs[0]; s += 64) {
             const double* mo = reinterpret_cast<const double*>(a.slab[0] + (size_t)s * a.stride[0] + a.moments_off);
             m1 += mo[0]; m2 += mo[1];
         }
@@ -912,6 +912,11 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
             scale_sh = scale;
             if (blockIdx.x == 0) {
                 a.scale_out[0] = scale; a.moments_out[0] = m1; a.moments_out[1] = m2; a.scale_sum[0] += scale;
+                // loss_sums[4] += (this call's SmoothL1 sum) * scale: the logged united loss is the mean of the per-step
+                // values actor + critic * scale (agent.py:652), not mean(critic) * mean(scale).  scale_sum = loss_sums + 3.
+                const float csum = a.scale_sum[-1];
+                a.scale_sum[1] += (csum - a.scale_sum[2]) * scale;
+                a.scale_sum[2] = csum;
                 if (a.index_row) a.index_row[0] += 1;
             }
         }
@@ -921,8 +926,9 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
     if (unit < n4) {
         const float* base = a.slab[sg.net] + sg.off + unit * 4;
         const size_t stride = (size_t)a.stride[sg.net];
+        const int nslabs = a.nslabs[sg.net];
         int s = wave;
-        for (; s + 24 < a.nslabs; s += 32) {   // four loads in flight
+        for (; s + 24 < nslabs; s += 32) {   // four loads in flight
             const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
             const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(s + 8) * stride);
             const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(s + 16) * stride);
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
             acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
             acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
         }
-        for (; s < a.nslabs; s += 8) {
+        for (; s < nslabs; s += 8) {
             const float4 v = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
@@ -981,7 +987,7 @@ int fused_grid(int B) {
 }
 
 int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
-                       float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
+                       int nslabs_c, int nslabs_a, float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
                        double* moments_out, float* scale_sum, int overwrite, int64_t* index_row, hipStream_t s) {
     ReduceArgs r{};
     int poff[13], psize[12], chunks = 0;
@@ -997,7 +1003,7 @@ int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, 
     slab_layout(kind_a, actor.D, actor.Di, md_a, poff, psize);
     for (int i = 0; i < np_a; ++i) add(grads_a[i], poff[i], psize[i], 1);
     add(g_std, poff[np_a], 1, 1);
-    r.nslabs = fused_grid(critic.B); r.B = critic.B;
+    r.nslabs[0] = nslabs_c; r.nslabs[1] = nslabs_a; r.B = critic.B;
     r.slab[0] = critic.slab; r.slab[1] = actor.slab;
     r.stride[0] = critic.slab_stride; r.stride[1] = actor.slab_stride;
     r.scale_out = scale_out; r.moments_out = moments_out; r.scale_sum = scale_sum; r.overwrite = overwrite; r.index_row = index_row;

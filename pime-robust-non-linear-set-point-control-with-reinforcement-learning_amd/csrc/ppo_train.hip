@@ -419,7 +419,13 @@ __global__ void critic_scale_kernel(ScaleArgs a) {
     const double s = a.moments[0], ss = a.moments[1], B = (double)a.B;
     const double var = a.B > 1 ? fmax((ss - s * s / B) / (B - 1.0), 0.0) : 0.0;
     const float scale = (float)(1.0 / ((double)(float)sqrt(var) + 1e-5));
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.scale_out[0] = scale; a.scale_sum[0] += scale; if (a.index_row) a.index_row[0] += 1; }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        a.scale_out[0] = scale; a.scale_sum[0] += scale;
+        const float csum = a.scale_sum[-1];   // loss_sums[2]; see ppo_grad_reduce_kernel
+        a.scale_sum[1] += (csum - a.scale_sum[2]) * scale;
+        a.scale_sum[2] = csum;
+        if (a.index_row) a.index_row[0] += 1;
+    }
     float* g = a.grad[blockIdx.y];
     const int n = a.n[blockIdx.y];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) g[i] *= scale;
@@ -443,8 +449,7 @@ int launch_critic_scale(int D, int md, float* const* grads, const double* moment
 // One launch: every thread reads the OLD step count t0 and updates with t = t0 + 1; the workgroup that finishes last
 // (a device-side arrival counter) stores t.  No workgroup can read step[] after that store: the store waits for all of
 // them to have arrived, and they arrive after their reads.  (A separate 1-thread "tick" launch cost ~3 us per step.)
-__device__ unsigned int adam_arrivals = 0;
-
+// The arrival counter is step[1] (caller-owned, one per optimizer), so optimizers on different streams do not share it.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
                             float* __restrict__ step) {
@@ -462,9 +467,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int prev = atomicAdd(&adam_arrivals, 1u);
+        unsigned int* arrivals = reinterpret_cast<unsigned int*>(step + 1);
+        const unsigned int prev = atomicAdd(arrivals, 1u);
         if (prev == gridDim.x - 1) {
-            adam_arrivals = 0;       // ready for the next launch (launches on one stream are ordered)
+            *arrivals = 0;           // ready for the next launch (launches of one optimizer are stream-ordered)
             step[0] = t_new;
         }
     }
@@ -483,11 +489,26 @@ int launch_adam(float* p, const float* g, float* m, float* v, long long n, float
 // ==================================================================================================== host side
 int mlp_check(int kind, int D, int Di, int md);
 
-int64_t ppo_bwd_image_floats(int kind, int D, int Di, int md) { return bwd_layout(kind, D, Di, md).total; }
+bool family16(int kind, int md);
+int64_t bwd16_floats(int md);
+int grid16(int B, int md, int D);
+int launch_pack16(const PackArgs& a, float* fwd, float* bwd, hipStream_t s);
+
+int64_t ppo_bwd_image_floats(int kind, int D, int Di, int md) {
+    return family16(kind, md) ? bwd16_floats(md) : (int64_t)bwd_layout(kind, D, Di, md).total;
+}
 
 int64_t fused_workspace_floats(int kind, int B, int D, int Di, int md);
 
 int64_t ppo_workspace_floats(int kind, int B, int md) {
+    if (family16(kind, md)) {   // gradient slabs only (no activation stash): bound over the state widths
+        int poff[13], psize[12];
+        const int64_t stride = slab_layout(kind, kMaxObsDim, 1, md, poff, psize);
+        int g = grid16(B, md, 1);
+        const int g2 = grid16(B, md, kMaxObsDim);
+        g = g > g2 ? g : g2;
+        return (int64_t)g * stride;
+    }
     const int64_t ntiles = ((B + 31) / 32 + 7) / 8 * 8;
     const int64_t split = ntiles * stash_tiles(kind, md / 32) * 1024 + ntiles * 32 + ntiles * 32 * kMaxObsDim;
     const int64_t fused = fused_workspace_floats(kind, B, kMaxObsDim, 1, md);  // slab size bound: widest state
@@ -503,6 +524,7 @@ int launch_pack_bwd(int kind, int D, int Di, int md, const float* const* params,
         a.p[i] = params[i];
     }
     a.kind = kind; a.D = D; a.Di = Di; a.md = md;
+    if (family16(kind, md)) return launch_pack16(a, nullptr, out, s);
     hipLaunchKernelGGL(mlp_pack_bwd_kernel, dim3(64), dim3(256), 0, s, a, out);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;

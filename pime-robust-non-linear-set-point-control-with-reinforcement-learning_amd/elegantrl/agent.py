@@ -90,7 +90,7 @@ class AgentBase:
         """Invalidate packed (kernel-layout) copies of the weights."""
         fused = getattr(self, "_packed", {}).get("fused")
         self._packed = {}
-        if fused is not None and fused.params_are(self):
+        if fused and fused.params_are(self):   # (False = "no fused kernel for these nets", remembered below)
             fused.repack()
             self._packed["fused"] = fused
 
@@ -226,7 +226,8 @@ class AgentPPO(AgentBase):
         if not hasattr(self, "_rollout_seed"):
             self._rollout_seed = int(torch.initial_seed()) & (2 ** 63 - 1)   # exploration stream follows torch's seed
             self._rollout_epoch = 0
-        return self._packed_for("act") is not None and self.act.state_dim == env.obs_dim
+        pk = self._packed_for("act")
+        return pk is not None and self.act.state_dim == env.obs_dim and env.rollout_supported(pk)
 
     def _vec_env_step(self, env, a_pre, obs, out_obs, out_reward, out_done):
         """Plain PPO: the env sees tanh(a_pre) (agent.py:599)."""
@@ -465,7 +466,7 @@ class AgentPPO(AgentBase):
         B = float(batch_size)
         ent, cri = tot[1] / (n_steps * B), tot[2] / (n_steps * B)
         act = tot[0] / (n_steps * B) + self.lambda_entropy * ent
-        self._log_losses(act + cri * tot[3] / n_steps, act, cri, ent)
+        self._log_losses(act + tot[4] / (n_steps * B), act, cri, ent)   # mean over steps of (actor + critic * scale), agent.py:652
         obj_a = (tot[0] - lst[0]) / B + self.lambda_entropy * (tot[1] - lst[1]) / B
         obj_c = (tot[2] - lst[2]) / B
         return obj_a, obj_c

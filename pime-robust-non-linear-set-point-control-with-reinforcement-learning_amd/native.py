@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(PACKAGE_DIR, "libpime_hip.so")
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
-ABI_VERSION = 7
+ABI_VERSION = 8
 ENV_PH, ENV_WT = 0, 1
 STATE_F64, STATE_MIXED = 0, 1
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
@@ -96,6 +96,7 @@ _SIGNATURES = {
     "pime_ppo_workspace_floats": (C.c_int64, [_i32, _i32, _i32]),
     "pime_ppo_pack_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pime_ppo_repack": (C.c_int, [_vp, _vp, _vp]),
+    "pime_rollout_supported": (C.c_int, [_vp, _i32, _i32]),
     "pime_rollout": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pime_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     "pime_ppo_minibatch_grad": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),

@@ -145,7 +145,7 @@ class FusedPPOGrad:
         self.flat_param.grad = self.flat_grad
         self._dump = torch.zeros(max(p.numel() for p in list(act.parameters()) + list(cri.parameters())),
                                  dtype=torch.float32, device=self.device)  # sink for frozen parameters' gradients
-        self.loss_sums = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.loss_sums = torch.zeros(6, dtype=torch.float32, device=self.device)   # include/pime_hip.h: pime_ppo_minibatch_grad
         self.moments = torch.zeros(2, dtype=torch.float64, device=self.device)
         for module in (act, cri):
             kind = module.packed_kind
@@ -257,7 +257,7 @@ class FlatAdam:
         self.param, self.grad, self.lr, self.betas, self.eps = param, grad, float(lr), betas, eps
         self.exp_avg = torch.zeros_like(param)
         self.exp_avg_sq = torch.zeros_like(param)
-        self.step_count = torch.zeros(1, dtype=torch.float32, device=param.device)
+        self.step_count = torch.zeros(2, dtype=torch.float32, device=param.device)   # [0] step, [1] arrival counter (scratch)
         self.param_groups = [{"params": [param], "lr": self.lr}]
 
     def step(self):

@@ -259,6 +259,11 @@ class VecControlEnv:
         return (self.cfg.state_mode == native.STATE_MIXED and not self.draws.injects
                 and (self.kind == native.ENV_PH or self.cfg.num_stack == 0))
 
+    def rollout_supported(self, packed_actor):
+        """Does the fused rollout kernel serve this env with this packed actor (kind / width)?  (pime_rollout_supported)"""
+        kind = native.MLP_MODULAR_ACTOR if packed_actor.kind == "modular_actor" else native.MLP_PLAIN_ACTOR
+        return self.supports_fused_rollout and bool(self._lib.pime_rollout_supported(self._h, kind, int(packed_actor.md)))
+
     def rollout(self, packed_actor, a_std_log, priorK, n_steps, noise_seed, noise_epoch, state, action, noise, reward, done):
         """Advance every lane `n_steps` steps under the packed residual policy in ONE launch (csrc/rollout.hip):
         state [n_steps+1, N, D] (slot 0 = current observation), action / noise / reward [n_steps, N], done uint8.

@@ -24,7 +24,7 @@ def test_header_library_binding_agree():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in pime_hip.h but not exported by libpime_hip.so"
     assert sorted(nt.EXPORTS) == declared, "ctypes binding and header disagree"
-    assert nt.lib().pime_abi_version() == nt.ABI_VERSION == 7
+    assert nt.lib().pime_abi_version() == nt.ABI_VERSION == 8
 
 
 def test_cfg_struct_layout_matches_c():
@@ -77,7 +77,11 @@ def test_mlp_pack_size_and_argument_errors():
     # critic md 128, D 3: 128*4 + 2*(16384 + 128) + 128 + 4
     assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 128) == 128 * 4 + 2 * (128 * 128 + 128) + 128 + 4
     assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 3, 1, 128) * 4 < 160 * 1024
-    assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 256) == 0 and "256" in nt.last_error()
+    # width 256: the streamed 16-tile family (csrc/mlp16.hip): first-layer image 1 k-step x 16 tiles x 64, three biases,
+    # two 256 x 256 images, head weights, 4-float head-bias slot
+    assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 256) == 16 * 64 + 3 * 256 + 2 * 256 * 256 + 256 + 4
+    assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 3, 1, 256) == 0 and "256" in nt.last_error()
+    assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 192) == 0 and "192" in nt.last_error()
     assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 3, 3, 128) == 0
 
 

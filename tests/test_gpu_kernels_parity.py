@@ -129,7 +129,7 @@ def test_flat_adam_matches_torch_adam():
         ref.grad = grads[k].clone(); opt.step()
         g.copy_(grads[k]); adam.step()
     torch.cuda.synchronize()
-    assert float(adam.step_count) == 3.0
+    assert float(adam.step_count[0]) == 3.0
     torch.testing.assert_close(mine, ref.detach(), rtol=2e-6, atol=2e-7)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
@@ -139,5 +139,5 @@ def test_flat_adam_matches_torch_adam():
         ref.grad = grads[k].clone(); opt.step()
         g.copy_(grads[k]); graph.replay()
     torch.cuda.synchronize()
-    assert float(adam.step_count) == 6.0
+    assert float(adam.step_count[0]) == 6.0
     torch.testing.assert_close(mine, ref.detach(), rtol=2e-6, atol=2e-7)

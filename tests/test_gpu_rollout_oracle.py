@@ -108,7 +108,15 @@ def test_fused_rollout_replays_through_oracle(env_name, algo, N, md):
         assert bool(d.all()) == (tt == T - 1) and bool(d.any()) == bool(d.all())
         np.testing.assert_array_equal(done[t].astype(bool), d)
         if tt == T - 1:   # the obs row is the first observation of the next episode (in-kernel auto-reset, new ensemble draw)
-            np.testing.assert_allclose(reward[t][alive], rew[alive], rtol=rtol, atol=rtol)
+            # y of the last step is not stored (the slot holds the next episode's first observation), so the one-LUT-cell
+            # rule is applied through the reward: -(y-r)^2 (pH) moves by at most 0.0297 * (2|y-r| + 0.0297) per cell
+            err = np.abs(reward[t] - rew)
+            ok = err <= rtol * (1.0 + np.abs(rew))
+            if is_ph:
+                assert (err[alive] <= 0.0297 * (2.0 * np.sqrt(np.abs(rew[alive])) + 0.0297) + rtol).all()
+                alive &= ok
+            else:
+                assert ok[alive].all()
             cell_exact.append(alive.mean())
             np.testing.assert_array_equal(state[t + 1], obs)
             alive[:] = True

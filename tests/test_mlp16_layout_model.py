@@ -1,0 +1,34 @@
+"""The index arithmetic of the 16x16x4 kernel family (csrc/mlp16.hip) on the host: tools/mlp16_layout_model.py mirrors the
+packed-image formula, the chain order of the k-steps, the transposed image, the sample-major publish / operand reads of the
+weight-gradient rounds and the block -> tensor store map, and checks each against plain matrix products.  No GPU: this is
+what catches a layout slip before a GPU run does (the GPU parity tests are tests/test_gpu_mlp16.py)."""
+import importlib.util
+import os
+
+import pytest
+
+from conftest import ROOT
+
+
+def _model():
+    spec = importlib.util.spec_from_file_location("mlp16_layout_model", os.path.join(ROOT, "tools", "mlp16_layout_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("md,D", [(64, 3), (64, 30), (128, 4), (64, 17)])
+def test_mlp16_layout_maps(md, D):
+    assert _model().self_check(md, D)
+
+
+def test_library_reports_width_256_support():
+    """Size queries need no GPU: width 256 is served for the critic / plain actor (16-tile family), refused for the modular actor."""
+    import pime_amd.native as nt
+    L = nt.lib()
+    assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 30, 0, 256) > 2 * 256 * 256
+    assert L.pime_mlp_packed_floats(nt.MLP_PLAIN_ACTOR, 30, 0, 256) > 2 * 256 * 256
+    assert L.pime_ppo_bwd_image_floats(nt.MLP_CRITIC, 30, 0, 256) == 2 * 256 * 256
+    assert L.pime_ppo_workspace_floats(nt.MLP_CRITIC, 4096, 256) > 0
+    assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 4, 1, 256) == 0 and "256" in nt.last_error()
+    assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 96) == 0

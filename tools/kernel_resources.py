@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""usage: tools/kernel_resources.py [out.txt]
+Compiler-reported resources of every kernel in libpime_hip.so (hipcc -Rpass-analysis=kernel-resource-usage, gfx950):
+VGPRs, AGPRs, scratch (spill) bytes per lane, static LDS, SGPRs, occupancy in waves per SIMD.  Needs no GPU."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pime-robust-non-linear-set-point-control-with-reinforcement-learning_amd", "csrc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "--offload-arch=gfx950",
+         f"-I{ROOT}/include", "-DPIME_BUILD", "-Rpass-analysis=kernel-resource-usage"]
+
+
+def demangle(name):
+    return subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "kernel_resources.txt")
+    lines = []
+    for f in sorted(os.listdir(CSRC)):
+        if not f.endswith(".hip"):
+            continue
+        p = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-c", os.path.join(CSRC, f), "-o", "/dev/null"],
+                           capture_output=True, text=True)
+        cur, rows = None, []
+        for line in p.stderr.splitlines():
+            m = re.search(r"remark: .*?Function Name: (\S+)", line)
+            if m:
+                cur = {"name": m.group(1)}
+                rows.append(cur)
+                continue
+            m = re.search(r"remark: [^:]*:\d+:\d+:\s+([A-Za-z][A-Za-z \[\]/]+): (\S+)", line) or \
+                re.search(r"remark:\s+([A-Za-z][A-Za-z \[\]/]+): (\S+)", line)
+            if m and cur is not None:
+                cur[m.group(1).strip()] = m.group(2)
+        for r in rows:
+            g = r.get
+            lines.append(f"{f}: {demangle(r['name'])[:84]:84s} VGPR {g('VGPRs', '?'):>4} AGPR {g('AGPRs', '?'):>4} "
+                         f"scratch {g('ScratchSize [bytes/lane]', '?'):>5} B/lane  static LDS {g('LDS Size [bytes/block]', '?'):>6} B  "
+                         f"SGPR {g('TotalSGPRs', '?'):>4}  spilled VGPRs {g('VGPRs Spill', '?'):>3}  waves/SIMD {g('Occupancy [waves/SIMD]', '?')}")
+    text = "\n".join(lines) + "\n"
+    open(out, "w").write(text)
+    sys.stdout.write(text)
+
+
+if __name__ == "__main__":
+    main()
