@@ -45,8 +45,8 @@ int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
 int64_t fused_stash_floats(int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
-int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, int, int, float* const*, float* const*, float*,
-                       float*, double*, float*, int, int64_t*, hipStream_t);
+int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, bool, bool, int, int, float* const*, float* const*,
+                       float*, float*, double*, float*, int, int64_t*, hipStream_t);
 int fused_grid(int);
 // mlp16.hip: the streamed 16x16x4 family (width 256; widths 64 / 128 under PIME_MLP16=1)
 bool family16(int, int);
@@ -712,8 +712,10 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         if (f16_net[k]) {
             int psize[12];
             a.slab = n->workspace;
-            a.slab_stride = slab_layout(n->kind, n->D, n->Di, n->md, a.poff, psize);
+            a.slab_stride = slab_layout16(n->D, n->md, a.poff, psize);
             fused_args[k] = a;
+            a.trace = tracing ? trace_dev + 64 * k : nullptr;
+            a.trace_wg = tracing ? std::atoi(std::getenv("PIME_FUSED_TRACE")) : 0;
             if (int rc = launch_ppo16(n->kind, n->md, a, s)) return rc;
             continue;
         }
@@ -750,7 +752,7 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
     }
     if (!split)
         return launch_grad_reduce(fused_args[0], fused_args[1], critic->kind, critic->md, actor->kind, actor->md,
-                                  f16_net[0] ? grid16(b->B, critic->md, critic->D) : fused_grid(b->B),
+                                  f16_net[0], f16_net[1], f16_net[0] ? grid16(b->B, critic->md, critic->D) : fused_grid(b->B),
                                   f16_net[1] ? grid16(b->B, actor->md, actor->D) : fused_grid(b->B),
                                   critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, loss_sums + 3,
                                   b->flags & PIME_PPO_OVERWRITE_GRADS, b->index_row, s);

@@ -28,7 +28,8 @@
 //   loss gradient, head gradient (DPP row sums), dZ3 in place of h3
 //   dW2 = dZ3^T h2 [2 rounds of 32 samples, operands published from registers], dH2 = W2^T dZ3 [streamed], dZ2
 //   dW1 = dZ2^T h1 [h1 recomputed], dH1 = W1^T dZ2, dZ1,  dW0 = dZ1^T x
-//   partial gradients -> this workgroup's slab (plain stores), summed in slab order by ppo_grad_reduce_kernel: reproducible.
+//   partial gradients -> this workgroup's slab (16-byte stores in accumulator order, slab_layout16), summed in slab order and
+//   un-permuted by ppo_grad_reduce_kernel: reproducible bit for bit.
 #include "ppo_device.hpp"
 #include "ppo_train.hpp"
 
@@ -125,61 +126,110 @@ __device__ __forceinline__ float act16(float v) {
     else return v;
 }
 
-// ---- a chain layer with its weight image streamed through two LDS slice buffers ------------------------------------------
+// ---- a chain layer with its weight image streamed through three LDS slice buffers by LDS-DMA ---------------------------
 // out = act(W in + b); the whole workgroup calls this together (every wave works on its own 16-sample tile, all share the
-// slices).  Slice = SKS k-steps of the image (16 KB at width <= 128, 32 KB at 256).  Per slice: the loads of the NEXT slice
-// are issued into registers, the MFMAs of this slice run from LDS, then the registers are written to the other buffer and
-// ONE barrier both publishes it and retires this slice's reads.  wbuf must be free on entry (callers barrier before).
+// slices).  Slice = SKS k-steps of the image (16 KB at width <= 128, 32 KB at 256), moved by global_load_lds_dwordx4 (no
+// staging registers, no ds_write; per wave-instruction 1 KB lands at a wave-uniform LDS base + lane * 16, the global address
+// is per lane).  Iteration s: the DMA of slice s+2 is issued into buffer (s+2)%3 (last read in iteration s-1), the MFMAs of
+// slice s run from buffer s%3 with the weight fragments of the next group of k-steps (16 MFMAs = 512 pipe cycles) in flight,
+// then a counted s_waitcnt leaves only the DMA just issued outstanding (slice s+1 has landed) and ONE barrier publishes it.
+// hipcc sinks register-staged loads down to their ds_write (the L2 round trip then sits exposed in front of every barrier)
+// and lets one ds_read run ahead at most: the DMA has no register to sink, and sched_barrier pins the fragment reads.
+// wbuf must be free on entry (callers barrier before); it is free again on return.
+template <int T>
+struct Layer16Geom {
+    static constexpr int Q = T / 4;
+    static constexpr int KS = T * 4;                       // k-steps of the layer (width / 4)
+    static constexpr int SKS = T >= 8 ? 8 : KS;            // k-steps per slice
+    static constexpr int NS = KS / SKS;
+    static constexpr int SLICE = SKS * Q * 256;            // floats
+    static constexpr int NBUFW = NS >= 3 ? 3 : NS;
+    static constexpr int PER = SLICE / 4 / k16Threads;     // 1 KB DMA pieces per wave per slice
+    static constexpr int KSG = T >= 16 ? 1 : 16 / T;       // k-steps per fragment group: KSG * T = 16 MFMAs
+    static constexpr int NG = SKS / KSG;
+    static constexpr int NF = KSG * Q;                     // float4 fragments per group
+    static_assert(SLICE / 4 % k16Threads == 0, "slice must split evenly over the workgroup");
+};
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N == 0, "add the count");
+}
+
 template <int T, int ACT, bool HAS_BIAS>
 __device__ __forceinline__ void layer16(const float* __restrict__ gimg, const float* __restrict__ bias, float* __restrict__ wbuf,
                                         int lane, int tid, const f32x4 (&in)[T], f32x4 (&out)[T]) {
-    constexpr int Q = T / 4;
-    constexpr int KS = T * 4;                       // k-steps of the layer (width / 4)
-    constexpr int SKS = T >= 8 ? 8 : KS;            // k-steps per slice
-    constexpr int NS = KS / SKS;
-    constexpr int SLICE = SKS * Q * 256;            // floats
-    constexpr int PER = SLICE / 4 / k16Threads;     // float4 per thread per slice
-    static_assert(SLICE / 4 % k16Threads == 0, "slice must split evenly over the workgroup");
+    using G = Layer16Geom<T>;
+    constexpr int Q = G::Q, SKS = G::SKS, NS = G::NS, SLICE = G::SLICE, PER = G::PER, KSG = G::KSG, NG = G::NG, NF = G::NF;
     const int g = lane >> 4;
+    const int wave_base = (tid >> 6) * 256;   // floats: this wave's 1 KB piece inside every 4 KB of a slice
+    // Source address = SCALAR base (the slice, made provably wave-uniform) + one 32-bit lane offset shared by every piece: the
+    // global_load_lds saddr form.  Left to itself hipcc materialises a 64-bit VGPR address per piece, slice and layer, spills
+    // them, and every reload's s_waitcnt vmcnt(0) drains the DMAs in flight (measured: 2.9 us per slice instead of 0.9).
+    const unsigned voff = (unsigned)tid * 16u;
+    auto dma_slice = [&](int slice) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(gimg + slice * SLICE);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        const char* sbase = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+        float* ldst = wbuf + (slice % 3) * SLICE + wave_base;
+#pragma unroll
+        for (int p = 0; p < PER; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(sbase + p * (k16Threads * 16) + voff),
+                                             (lds_void_ptr)(ldst + p * k16Threads * 4), 16, 0, 0);
+    };
+    dma_slice(0);
+    if constexpr (NS > 1) dma_slice(1);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         if constexpr (HAS_BIAS) out[t] = *reinterpret_cast<const f32x4*>(bias + t * 16 + 4 * g);
         else out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float4* src = reinterpret_cast<const float4*>(gimg) + tid;
-    float4 stage[PER];
-#pragma unroll
-    for (int p = 0; p < PER; ++p) stage[p] = src[p * k16Threads];
-#pragma unroll
-    for (int p = 0; p < PER; ++p) reinterpret_cast<float4*>(wbuf)[tid + p * k16Threads] = stage[p];
+    if constexpr (NS > 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // slice 0 landed (slice 1 may still fly)
     PIME16_BARRIER();
+    float4 wf[2][NF];
+    auto load_group = [&](int slice, int gidx, float4 (&dst)[NF]) {
+        const float4* wl = reinterpret_cast<const float4*>(wbuf + (slice % 3) * SLICE) + lane;
+#pragma unroll
+        for (int kk = 0; kk < KSG; ++kk)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) dst[kk * Q + q] = wl[((gidx * KSG + kk) * Q + q) * 64];
+    };
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        if (s + 1 < NS) {
+        if (s + 2 < NS) dma_slice(s + 2);
+        load_group(s, 0, wf[(s * NG) & 1]);
 #pragma unroll
-            for (int p = 0; p < PER; ++p) stage[p] = src[(s + 1) * (SLICE / 4) + p * k16Threads];
-        }
-        const float4* wl = reinterpret_cast<const float4*>(wbuf + (s & 1) * SLICE) + lane;
+        for (int gi = 0; gi < NG; ++gi) {
+            const int cur = (s * NG + gi) & 1;
+            // The group's 16 MFMAs in two halves with the NEXT group's fragment reads issued between them: hipcc waits
+            // lgkmcnt(0) in front of a group's first MFMA, so reads issued right there would sit exposed; issued half a group
+            // (256 pipe cycles) earlier they have landed.
 #pragma unroll
-        for (int ksl = 0; ksl < SKS; ++ksl) {
-            if ((ksl & 1) == 0) PIME_NO_HOIST();     // bound the weight-fragment prefetch depth
-            const int ks = s * SKS + ksl;
-            const float b = in[ks >> 2][ks & 3];
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const float4 w = wl[(ksl * Q + q) * 64];
-                out[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b, out[4 * q + 0], 0, 0, 0);
-                out[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b, out[4 * q + 1], 0, 0, 0);
-                out[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b, out[4 * q + 2], 0, 0, 0);
-                out[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b, out[4 * q + 3], 0, 0, 0);
+                for (int m = half * (NF / 2); m < (half + 1) * (NF / 2); ++m) {
+                    const int kk = m / Q, q = m % Q;
+                    const int ks = s * SKS + gi * KSG + kk;
+                    const float b = in[ks >> 2][ks & 3];
+                    const float4 w = wf[cur][m];
+                    out[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b, out[4 * q + 0], 0, 0, 0);
+                    out[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b, out[4 * q + 1], 0, 0, 0);
+                    out[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b, out[4 * q + 2], 0, 0, 0);
+                    out[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b, out[4 * q + 3], 0, 0, 0);
+                }
+                if (half == 0 && gi + 1 < NG) load_group(s, gi + 1, wf[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (s + 1 < NS) {
-#pragma unroll
-            for (int p = 0; p < PER; ++p)
-                reinterpret_cast<float4*>(wbuf + ((s + 1) & 1) * SLICE)[tid + p * k16Threads] = stage[p];
-        }
-        PIME16_BARRIER();   // next slice published; this slice's reads retired (after the last slice: wbuf is free again)
+        // slice s+1 must have landed before the barrier publishes it; the DMA of slice s+2 (the PER youngest) may still fly
+        if (s + 2 < NS) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+        PIME16_BARRIER();   // slice s+1 published; slice s's reads retired (after the last slice: wbuf is free again)
     }
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -189,7 +239,7 @@ __device__ __forceinline__ void layer16(const float* __restrict__ gimg, const fl
 
 template <int T>
 __host__ __device__ constexpr int layer16_lds_floats() {
-    return 2 * ((T >= 8 ? 8 : T * 4) * (T / 4) * 256);
+    return Layer16Geom<T>::NBUFW * Layer16Geom<T>::SLICE;
 }
 
 // First layer from the LDS-resident natural-order image: h = act(W0 x + b0), x[s][4 ks + g] in xr[ks].
@@ -247,10 +297,11 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 }
 
-// ---- weight gradient of one layer: dW[a][b] = sum over the group's 128 samples of A[s][a] B[s][b] ---------------------------
-// Two rounds of 32 samples (tiles 2t, 2t+1: waves 2t and 2t+1 publish their tile's A rows and B rows into the sample-major
-// image X); every wave owns an NA x NB patch of 16x16 output blocks per pass.  NBUF = 2: the next round is published while this
-// one is multiplied (one barrier per round); NBUF = 1: two barriers per round, half the LDS.
+// ---- weight gradient of one layer: dW[a][b] = sum over the group's 64 samples of A[s][a] B[s][b] ----------------------------
+// Rounds of RT tiles (RT = 4: ONE round, every wave publishes its tile's A rows and B rows into the sample-major image X, one
+// barrier, 16 k-steps; RT = 2 at width 256, where the 64-row image does not fit: two rounds, waves 2t and 2t+1 publish round
+// t); every wave owns an NA x NB patch of 16x16 output blocks per pass.  The operand reads of the next k-step are issued
+// half-way through a k-step's MFMAs.
 template <int TA, int TB>
 struct Dw16Plan {
     static constexpr int NBLK = TA * TB;
@@ -261,91 +312,84 @@ struct Dw16Plan {
     static constexpr int PR = TB / NB;                        // patches per row of A tiles
     static constexpr int NPATCH = (TA / NA) * PR;
     static constexpr int PASSES = (NPATCH + k16Waves - 1) / k16Waves;
-    static constexpr int PA = TA * 16 + 16, PB = TB * 16 + 16;
-    static constexpr int BUF = 32 * PA + 32 * PB;             // floats of one round image
+    // Row pitch = 20 (mod 32) floats: the publishers' ds_write_b128 (8 consecutive rows per LDS pass, 4 banks each) hit 32
+    // distinct banks; the operand ds_read_b32 (rows 4ks + {0, 1} in one 32-lane pass) conflict 2-way on 4 lanes of 32, which
+    // costs nothing beside 16 MFMAs per k-step.  (Pitch = 16 mod 32: reads clean, writes 4-way: 0.7 us per round.)
+    static constexpr int PA = TA * 16 + 20, PB = TB * 16 + 20;
     static_assert(TA % NA == 0 && TB % NB == 0, "patches must tile the block grid");
 };
 
-template <int TA, int TB, int NBUF, class PubA, class PubB>
+template <int TA, int TB, int RT, class PubA, class PubB>
 __device__ __forceinline__ void dw16(float* __restrict__ X, int lane, int wave, const PubA& pub_a, const PubB& pub_b,
-                                     float* __restrict__ gW, int ldw, int ncols, float* __restrict__ gb, bool accum) {
+                                     float* __restrict__ gW, float* __restrict__ gb, bool accum) {
     using P = Dw16Plan<TA, TB>;
-    constexpr int NA = P::NA, NB = P::NB;
+    constexpr int NA = P::NA, NB = P::NB, ROWS = RT * 16, NKS = RT * 4, ROUNDS = k16Waves / RT;
     const int i = lane & 15, kk = lane >> 4;
 #pragma unroll 1
     for (int pass = 0; pass < P::PASSES; ++pass) {
         const int patch = pass * k16Waves + wave;
         const bool active = patch < P::NPATCH;
         const int a0 = active ? (patch / P::PR) * NA : 0, b0 = active ? (patch % P::PR) * NB : 0;
+        // The accumulators START from what an earlier group of this workgroup stored (zero for its first group): the slab
+        // loads are issued here and land behind the publish / barriers, instead of a load -> add -> store chain at the end.
         f32x4 acc[NA][NB];
+        f32x4* q[NA][NB];
         float bsum[NA];
 #pragma unroll
         for (int x = 0; x < NA; ++x) {
             bsum[x] = 0.f;
 #pragma unroll
-            for (int y = 0; y < NB; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int y = 0; y < NB; ++y) {
+                int off = (((a0 + x) * TB + b0 + y) * 64 + lane) * 4;   // slab_layout16: block-major, accumulator order
+                asm volatile("" : "+v"(off));
+                q[x][y] = reinterpret_cast<f32x4*>(gW + off);
+                acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (accum && active) acc[x][y] = *q[x][y];
+            }
         }
-        auto publish = [&](int t, float* buf) {
-            if ((wave >> 1) == t) {
-                float* rows = buf + ((wave & 1) * 16 + i) * P::PA;
-                pub_a(rows);
-                float* rowsb = buf + 32 * P::PA + ((wave & 1) * 16 + i) * P::PB;
-                pub_b(rowsb);
-            }
-        };
-        PIME16_BARRIER();   // X free (previous job / pass / chain layer done with the region)
-        if constexpr (NBUF == 2) publish(0, X);
 #pragma unroll 1
-        for (int t = 0; t < k16Rounds; ++t) {
-            float* cur = X;
-            if constexpr (NBUF == 2) {
-                PIME16_BARRIER();   // round t published; round t-1's reads of the other buffer retired
-                cur = X + (t & 1) * P::BUF;
-                if (t + 1 < k16Rounds) publish(t + 1, X + ((t + 1) & 1) * P::BUF);
-            } else {
-                if (t > 0) PIME16_BARRIER();   // round t-1's reads retired
-                publish(t, X);
-                PIME16_BARRIER();
+        for (int t = 0; t < ROUNDS; ++t) {
+            PIME16_BARRIER();   // X free: the previous round / pass / job / chain layer is done with the region
+            if (wave / RT == t) {
+                pub_a(X + ((wave % RT) * 16 + i) * P::PA);
+                pub_b(X + ROWS * P::PA + ((wave % RT) * 16 + i) * P::PB);
             }
+            PIME16_BARRIER();
             PIME_NO_HOIST();
             if (active) {
-                const float* Ap = cur + kk * P::PA + a0 * 16 + i;
-                const float* Bp = cur + 32 * P::PA + kk * P::PB + b0 * 16 + i;
+                const float* Ap = X + kk * P::PA + a0 * 16 + i;
+                const float* Bp = X + ROWS * P::PA + kk * P::PB + b0 * 16 + i;
+                float av[2][NA], bv[2][NB];   // operands of k-step ks+1 are in flight while k-step ks multiplies
+                auto load_ops = [&](int ks, float (&a_)[NA], float (&b_)[NB]) {
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    if ((ks & 1) == 0) PIME_NO_HOIST();   // bound the operand prefetch depth
-                    float av[NA], bv[NB];
+                    for (int x = 0; x < NA; ++x) a_[x] = Ap[4 * ks * P::PA + x * 16];
 #pragma unroll
-                    for (int x = 0; x < NA; ++x) av[x] = Ap[4 * ks * P::PA + x * 16];
+                    for (int y = 0; y < NB; ++y) b_[y] = Bp[4 * ks * P::PB + y * 16];
+                };
+                load_ops(0, av[0], bv[0]);
 #pragma unroll
-                    for (int y = 0; y < NB; ++y) bv[y] = Bp[4 * ks * P::PB + y * 16];
+                for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
                     for (int x = 0; x < NA; ++x) {
 #pragma unroll
                         for (int y = 0; y < NB; ++y)
-                            acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], bv[y], acc[x][y], 0, 0, 0);
-                        bsum[x] += av[x];
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][x], bv[ks & 1][y], acc[x][y], 0, 0, 0);
+                        bsum[x] += av[ks & 1][x];
+                        if (x == (NA - 1) / 2) {   // half-way: the next k-step's operand reads, landed by the time they are waited for
+                            if (ks + 1 < NKS) load_ops(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
         if (active) {
-            // block (x, y): register r of lane (j = i, g = kk) is D[16 (a0+x) + 4g + r][16 (b0+y) + j]
+            // one 16-byte store per lane and block: a wave writes 1 KB contiguous
 #pragma unroll
             for (int x = 0; x < NA; ++x) {
 #pragma unroll
-                for (int y = 0; y < NB; ++y) {
-                    const int col = (b0 + y) * 16 + i;
-                    int base = ((a0 + x) * 16 + 4 * kk) * ldw + col;
-                    asm volatile("" : "+v"(base));
-                    if (col < ncols) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float* qd = &gW[base + r * ldw];
-                            *qd = accum ? *qd + acc[x][y][r] : acc[x][y][r];
-                        }
-                    }
-                }
+                for (int y = 0; y < NB; ++y) *q[x][y] = acc[x][y];
                 float bs = bsum[x];
                 bs += __shfl_xor(bs, 16);
                 bs += __shfl_xor(bs, 32);
@@ -358,8 +402,8 @@ __device__ __forceinline__ void dw16(float* __restrict__ X, int lane, int wave, 
     }
 }
 
-template <int TA, int TB, int NBUF>
-__host__ __device__ constexpr int dw16_lds_floats() { return NBUF * Dw16Plan<TA, TB>::BUF; }
+template <int TA, int TB, int RT>
+__host__ __device__ constexpr int dw16_lds_floats() { return RT * 16 * (Dw16Plan<TA, TB>::PA + Dw16Plan<TA, TB>::PB); }
 
 // publishers: a tile in accumulator layout (lane (s, g): features 16t + 4g + r) -> its row of the sample-major image
 template <int TT>
@@ -399,8 +443,8 @@ __host__ __device__ inline Lds16 lds16(int D, bool grad) {
     seg(S.wsum, k16Waves * 6 * 2);
     int region = layer16_lds_floats<T>();
     if (grad) {
-        constexpr int NBUF = T <= 8 ? 2 : 1;
-        const int dwf = dw16_lds_floats<T, T, NBUF>();
+        constexpr int RT = T <= 8 ? 4 : 2;
+        const int dwf = dw16_lds_floats<T, T, RT>();
         region = region > dwf ? region : dwf;
         const int hacc = k16Waves * md;
         region = region > hacc ? region : hacc;
@@ -462,12 +506,18 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void mlp16_forward_kern
 }
 
 // ---- PPO minibatch gradients of one net ------------------------------------------------------------------------------
+// PIME_FUSED_TRACE=<workgroup>: wall-clock marks (100 MHz) of that workgroup's first two groups -- a tuning aid
+#define PIME16_MARK(i)                                                                                          \
+    do {                                                                                                        \
+        if (a.trace && blockIdx.x == a.trace_wg && threadIdx.x == 0 && mark0 + (i) < 32) a.trace[mark0 + (i)] = wall_clock64(); \
+    } while (0)
+
 template <int T, bool ACTOR>
 __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int ACT = ACTOR ? 1 : 0;
     constexpr int md = T * 16;
-    constexpr int NBUF = T <= 8 ? 2 : 1;
+    constexpr int RT = T <= 8 ? 4 : 2;   // tiles per weight-gradient round (dw16)
     const Layout16 L = layout16(a.D, md);
     const LayoutB16 Lb = layoutb16(md);
     const Lds16 S = lds16<T>(a.D, true);
@@ -487,6 +537,8 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
         asm volatile("" : "+v"(lane));   // keep per-lane offsets inside the loop (hipcc hoists and spills them otherwise)
         const int s = lane & 15, g = lane >> 4;
         const bool accum = group != (int)blockIdx.x;
+        const int mark0 = accum ? 12 : 0;
+        PIME16_MARK(0);
         const int pos = group * k16Group + wave * 16 + s;
         const bool valid = pos < a.B;
         const int64_t* const idx = a.indices + (a.index_row ? (size_t)a.index_row[0] * a.B : 0);
@@ -504,10 +556,13 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
             f32x4 h1[T];
             first16<T, ACT>(lds + S.w0, lds + S.b0, L.KS0, lane, xr, h1);
             PIME_NO_HOIST();
+            PIME16_MARK(1);
             layer16<T, ACT, true>(a.img_fwd + L.w1, lds + S.b1, region, lane, tid, h1, h2);
         }
+        PIME16_MARK(2);
         PIME_NO_HOIST();
         layer16<T, ACT, true>(a.img_fwd + L.w2, lds + S.b2, region, lane, tid, h2, h3);
+        PIME16_MARK(3);
         const float y = head16<T>(lds + S.w3, lds[S.b3], lane, h3);
 
         // ------------------------------------------------------------------------------------------ loss gradient
@@ -572,11 +627,14 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
             }
         }
         // ------------------------------------------------------------------------------------------ backward
+        PIME16_MARK(4);
         PIME_NO_HOIST();
-        dw16<T, T, NBUF>(region, lane, wave, PubAcc16<T>{h3, g}, PubAcc16<T>{h2, g}, sl + a.poff[4], md, md, sl + a.poff[5], accum);   // net.4
+        dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{h3, g}, PubAcc16<T>{h2, g}, sl + a.poff[4], sl + a.poff[5], accum);   // net.4
         f32x4 d2[T];
         PIME16_BARRIER();
+        PIME16_MARK(5);
         layer16<T, 2, false>(a.img_bwd + Lb.w2t, nullptr, region, lane, tid, h3, d2);
+        PIME16_MARK(6);
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -584,20 +642,23 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
         f32x4(&h1)[T] = h2;   // h2 is dead: its registers take the recomputed first-layer activation
         PIME_NO_HOIST();
         first16<T, ACT>(lds + S.w0, lds + S.b0, L.KS0, lane, xr, h1);
-        dw16<T, T, NBUF>(region, lane, wave, PubAcc16<T>{d2, g}, PubAcc16<T>{h1, g}, sl + a.poff[2], md, md, sl + a.poff[3], accum);   // net.2
+        dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{d2, g}, PubAcc16<T>{h1, g}, sl + a.poff[2], sl + a.poff[3], accum);   // net.2
         f32x4(&d1)[T] = h3;   // dZ3 is dead
         PIME16_BARRIER();
+        PIME16_MARK(7);
         layer16<T, 2, false>(a.img_bwd + Lb.w1t, nullptr, region, lane, tid, d2, d1);
+        PIME16_MARK(8);
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) d1[t][r] *= act_grad_from_output<ACT>(h1[t][r]);                                                 // dZ1
         PIME_NO_HOIST();
         if (L.Dp <= 16)
-            dw16<T, 1, NBUF>(region, lane, wave, PubAcc16<T>{d1, g}, PubX16{xr, g, L.KS0, 16}, sl + a.poff[0], a.D, a.D, sl + a.poff[1], accum);
+            dw16<T, 1, RT>(region, lane, wave, PubAcc16<T>{d1, g}, PubX16{xr, g, L.KS0, 16}, sl + a.poff[0], sl + a.poff[1], accum);
         else
-            dw16<T, 2, NBUF>(region, lane, wave, PubAcc16<T>{d1, g}, PubX16{xr, g, L.KS0, 32}, sl + a.poff[0], a.D, a.D, sl + a.poff[1], accum);
+            dw16<T, 2, RT>(region, lane, wave, PubAcc16<T>{d1, g}, PubX16{xr, g, L.KS0, 32}, sl + a.poff[0], sl + a.poff[1], accum);
         PIME16_BARRIER();   // the next group's first chain layer writes the region
+        PIME16_MARK(9);
     }
 
     // ---- workgroup totals of the scalar sums, in a fixed order (only the logged loss sums use atomics)

@@ -873,6 +873,8 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
 struct ReduceSeg {
     float* dst;
     int off, n, net;   // slab offset (floats), element count, 0 = critic / 1 = actor
+    int perm_tb;       // 0: slab in tensor order; TB > 0: block-major accumulator order with TB column tiles (slab_layout16)
+    int ldw, ncols;    // perm_tb > 0: row length and valid columns of the destination tensor
 };
 struct ReduceArgs {
     ReduceSeg seg[24];
@@ -950,8 +952,18 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
         for (int w = 1; w < 8; ++w) { const float4 v = part[w][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
         const float sc = sg.net == 0 ? scale_sh : 1.0f;
         const float o[4] = {t.x * sc, t.y * sc, t.z * sc, t.w * sc};
-        for (int k = 0; k < 4; ++k)
-            if (unit * 4 + k < sg.n) sg.dst[unit * 4 + k] = a.overwrite ? o[k] : sg.dst[unit * 4 + k] + o[k];
+        if (sg.perm_tb > 0) {   // unit = one lane's four accumulator registers of block (blk / TB, blk % TB)
+            const int blk = unit >> 6, ln = unit & 63;
+            const int row = (blk / sg.perm_tb) * 16 + 4 * (ln >> 4), col = (blk % sg.perm_tb) * 16 + (ln & 15);
+            if (col < sg.ncols)
+                for (int k = 0; k < 4; ++k) {
+                    float* q = &sg.dst[(row + k) * sg.ldw + col];
+                    *q = a.overwrite ? o[k] : *q + o[k];
+                }
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (unit * 4 + k < sg.n) sg.dst[unit * 4 + k] = a.overwrite ? o[k] : sg.dst[unit * 4 + k] + o[k];
+        }
     }
 }
 
@@ -987,22 +999,35 @@ int fused_grid(int B) {
 }
 
 int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
-                       int nslabs_c, int nslabs_a, float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
+                       bool f16_c, bool f16_a, int nslabs_c, int nslabs_a, float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
                        double* moments_out, float* scale_sum, int overwrite, int64_t* index_row, hipStream_t s) {
     ReduceArgs r{};
     int poff[13], psize[12], chunks = 0;
-    auto add = [&](float* dst, int off, int n, int net) {
-        r.seg[r.nseg++] = ReduceSeg{dst, off, n, net};
+    auto add = [&](float* dst, int off, int n, int net, int perm_tb = 0, int ldw = 0, int ncols = 0) {
+        r.seg[r.nseg++] = ReduceSeg{dst, off, n, net, perm_tb, ldw, ncols};
         chunks += ((n + 3) / 4 + 63) / 64;
     };
-    const int np_c = 8;
-    slab_layout(kind_c, critic.D, critic.Di, md_c, poff, psize);
-    for (int i = 0; i < np_c; ++i) add(grads_c[i], poff[i], psize[i], 0);
-    r.moments_off = poff[np_c];
-    const int np_a = kind_a == MLP_MODULAR_ACTOR ? 12 : 8;
-    slab_layout(kind_a, actor.D, actor.Di, md_a, poff, psize);
-    for (int i = 0; i < np_a; ++i) add(grads_a[i], poff[i], psize[i], 1);
-    add(g_std, poff[np_a], 1, 1);
+    auto add_net = [&](const PpoArgs& a, int kind, int md, bool f16, float* const* grads, int net, int* scalar_off) {
+        const int np = kind == MLP_MODULAR_ACTOR ? 12 : 8;
+        if (f16) {   // block-major weight gradients (slab_layout16)
+            slab_layout16(a.D, md, poff, psize);
+            const int tb0 = ((a.D + 3) & ~3) <= 16 ? 1 : 2, T = md / 16;
+            for (int i = 0; i < np; ++i) {
+                if (i == 0) add(grads[i], poff[i], psize[i], net, tb0, a.D, a.D);
+                else if (i == 2 || i == 4) add(grads[i], poff[i], psize[i], net, T, md, md);
+                else add(grads[i], poff[i], psize[i], net);
+            }
+        } else {
+            slab_layout(kind, a.D, a.Di, md, poff, psize);
+            for (int i = 0; i < np; ++i) add(grads[i], poff[i], psize[i], net);
+        }
+        *scalar_off = poff[np];
+    };
+    int scalar_c = 0, scalar_a = 0;
+    add_net(critic, kind_c, md_c, f16_c, grads_c, 0, &scalar_c);
+    r.moments_off = scalar_c;
+    add_net(actor, kind_a, md_a, f16_a, grads_a, 1, &scalar_a);
+    add(g_std, scalar_a, 1, 1);
     r.nslabs[0] = nslabs_c; r.nslabs[1] = nslabs_a; r.B = critic.B;
     r.slab[0] = critic.slab; r.slab[1] = actor.slab;
     r.stride[0] = critic.slab_stride; r.stride[1] = actor.slab_stride;

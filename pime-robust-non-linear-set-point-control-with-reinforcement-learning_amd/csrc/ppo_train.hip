@@ -503,7 +503,7 @@ int64_t fused_workspace_floats(int kind, int B, int D, int Di, int md);
 int64_t ppo_workspace_floats(int kind, int B, int md) {
     if (family16(kind, md)) {   // gradient slabs only (no activation stash): bound over the state widths
         int poff[13], psize[12];
-        const int64_t stride = slab_layout(kind, kMaxObsDim, 1, md, poff, psize);
+        const int64_t stride = slab_layout16(kMaxObsDim, md, poff, psize);
         int g = grid16(B, md, 1);
         const int g2 = grid16(B, md, kMaxObsDim);
         g = g > g2 ? g : g2;

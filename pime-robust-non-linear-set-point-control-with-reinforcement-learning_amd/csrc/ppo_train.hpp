@@ -63,6 +63,20 @@ inline int slab_layout(int kind, int D, int Di, int md, int* poff, int* psize) {
     return o + 4;
 }
 
+// Slab layout of a net of the 16-tile family (csrc/mlp16.hip): the three weight matrices are stored BLOCK-major in
+// accumulator order -- block (a, b) of 16 x 16, then lane, then register: element ((a TB + b) 64 + lane) 4 + r is
+// dW[16a + 4 (lane >> 4) + r][16b + (lane & 15)] -- so that a lane stores its four accumulator registers as ONE 16-byte
+// word (a wave: 1 KB contiguous; in tensor order the same block is 64 stores of 64-byte segments).  The slab reduction
+// un-permutes while it writes the 270 KB result.  First-layer columns are padded to TB0 = 1 or 2 tiles.
+inline int slab_layout16(int D, int md, int* poff, int* psize) {
+    const int tb0 = ((D + 3) & ~3) <= 16 ? 1 : 2;
+    const int s[8] = {md * tb0 * 16, md, md * md, md, md * md, md, md, 1};
+    int o = 0;
+    for (int i = 0; i < 8; ++i) { psize[i] = s[i]; poff[i] = o; o += (s[i] + 3) & ~3; }
+    poff[8] = o;
+    return o + 4;
+}
+
 constexpr int kMaxDwJobs = 16;
 
 struct DwArgs {

@@ -65,9 +65,9 @@ def chain_layer(img, T_in_ksteps, T_out, inp_acc=None, xr=None):
     return out
 
 
-def dw_job(A_tiles, B_tiles, TA, TB, nwaves=4):
-    """dw16: A_tiles / B_tiles = per-wave accumulator-layout tiles [wave][T][64][4] (or B as x rows, see caller);
-    returns dW [16 TA][16 TB] assembled through the kernel's publish / read / store index maps."""
+def dw_job(A_tiles, B_tiles, TA, TB, RT=4, nwaves=4):
+    """dw16: A_tiles / B_tiles = per-wave accumulator-layout tiles [wave][T][64][4]; rounds of RT tiles (RT = 4: one round of
+    all 64 samples; RT = 2: two rounds).  Returns dW [16 TA][16 TB] assembled through the kernel's publish / read / store maps."""
     NBLK = TA * TB
     TOT = (NBLK + nwaves - 1) // nwaves
     NB = 4 if TB >= 4 else TB
@@ -76,7 +76,8 @@ def dw_job(A_tiles, B_tiles, TA, TB, nwaves=4):
     PR = TB // NB
     NPATCH = (TA // NA) * PR
     PASSES = (NPATCH + nwaves - 1) // nwaves
-    PA, PB = TA * 16 + 16, TB * 16 + 16
+    PA, PB = TA * 16 + 20, TB * 16 + 20
+    ROWS, NKS = RT * 16, RT * 4
     dW = np.zeros((16 * TA, 16 * TB))
     bias = np.zeros(16 * TA)
     for p in range(PASSES):
@@ -87,23 +88,25 @@ def dw_job(A_tiles, B_tiles, TA, TB, nwaves=4):
             a0, b0 = (patch // PR) * NA, (patch % PR) * NB
             acc = np.zeros((NA, NB, 64, 4))
             bsum = np.zeros((NA, 64))
-            for t in range(nwaves // 2):
-                X = np.zeros(32 * PA + 32 * PB)
-                for w in (2 * t, 2 * t + 1):     # publish: PubAcc16 into rows (w & 1) * 16 + s
-                    rows = ((w & 1) * 16 + I) * PA
+            for t in range(nwaves // RT):
+                X = np.zeros(ROWS * PA + ROWS * PB)
+                for w in range(nwaves):          # publish: PubAcc16 into rows (w % RT) * 16 + s of round w // RT
+                    if w // RT != t:
+                        continue
+                    rows = ((w % RT) * 16 + I) * PA
                     for tt in range(TA):
                         for r in range(4):
                             X[rows + tt * 16 + 4 * G + r] = A_tiles[w][tt][:, r]
-                    rowsb = 32 * PA + ((w & 1) * 16 + I) * PB
+                    rowsb = ROWS * PA + ((w % RT) * 16 + I) * PB
                     for tt in range(TB):
                         for r in range(4):
                             X[rowsb + tt * 16 + 4 * G + r] = B_tiles[w][tt][:, r]
-                for ks in range(8):
+                for ks in range(NKS):
                     for x in range(NA):
                         av = X[G * PA + a0 * 16 + I + 4 * ks * PA + x * 16]
                         bsum[x] += av
                         for y in range(NB):
-                            bv = X[32 * PA + G * PB + b0 * 16 + I + 4 * ks * PB + y * 16]
+                            bv = X[ROWS * PA + G * PB + b0 * 16 + I + 4 * ks * PB + y * 16]
                             acc[x, y] = mfma_16x16x4(av, bv, acc[x, y])
             for x in range(NA):
                 for y in range(NB):
@@ -139,9 +142,10 @@ def self_check(md=64, D=7, seed=0):
     # weight gradient over a 64-sample group: 4 waves x 16 samples
     dZ = rng.standard_normal((4, 16, md))
     H = rng.standard_normal((4, 16, md))
-    dW, db = dw_job([to_acc_layout(dZ[w], T) for w in range(4)], [to_acc_layout(H[w], T) for w in range(4)], T, T)
-    assert np.allclose(dW, np.einsum("wsi,wsj->ij", dZ, H)), "dW hidden"
-    assert np.allclose(db, dZ.sum((0, 1))), "bias gradient"
+    for RT in (4, 2):
+        dW, db = dw_job([to_acc_layout(dZ[w], T) for w in range(4)], [to_acc_layout(H[w], T) for w in range(4)], T, T, RT)
+        assert np.allclose(dW, np.einsum("wsi,wsj->ij", dZ, H)), "dW hidden"
+        assert np.allclose(db, dZ.sum((0, 1))), "bias gradient"
     # first-layer weight gradient: B = the state rows (PubX16), one or two 16-column tiles
     TB = 1 if Dp <= 16 else 2
     X4 = rng.standard_normal((4, 16, D))
