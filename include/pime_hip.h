@@ -230,6 +230,10 @@ typedef struct pime_ppo_batch {
 /* the call OVERWRITES the gradient tensors (and g_a_std_log) instead of adding to them: saves the caller's zeroing launch */
 #define PIME_PPO_OVERWRITE_GRADS 1
 
+/* floats of img_fwd / img_bwd of a pime_ppo_net (filled by pime_ppo_repack; img_bwd alone by pime_ppo_pack_bwd).  The forward
+ * image of the gradient path is NOT always pime_mlp_pack's: nets of width 64 / 128 whose observation is too wide for the
+ * LDS-resident gradient kernel (the stacked water tank, 30 floats) take the streamed 16-tile family here. */
+int64_t pime_ppo_fwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t md);
 int64_t pime_ppo_bwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t md);
 int64_t pime_ppo_workspace_floats(int32_t kind, int32_t B, int32_t md);
 int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const float* const* params, float* image,

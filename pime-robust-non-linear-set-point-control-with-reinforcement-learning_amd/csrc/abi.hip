@@ -45,11 +45,13 @@ int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
 int64_t fused_stash_floats(int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
-int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, bool, bool, int, int, float* const*, float* const*,
-                       float*, float*, double*, float*, int, int64_t*, hipStream_t);
+int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, bool, bool, bool, bool, int, int, float* const*,
+                       float* const*, float*, float*, double*, float*, int, int64_t*, hipStream_t);
 int fused_grid(int);
 // mlp16.hip: the streamed 16x16x4 family (width 256; widths 64 / 128 under PIME_MLP16=1)
 bool family16(int, int);
+bool family16_grad(int, int, int, int);
+int64_t ppo_fwd_image_floats(int, int, int, int);
 int grid16(int, int, int);
 int launch_pack16(const PackArgs&, float*, float*, hipStream_t);
 int launch_ppo16(int, int, const PpoArgs&, hipStream_t);
@@ -108,6 +110,7 @@ void carve_wt(Carver& c, WtPtrs<S>& p, int n, int obs_dim, int num_stack) {
     p.h1 = c.take<S>(n); p.h2 = c.take<S>(n); p.r = c.take<S>(n); p.I = c.take<S>(n);
     p.a1 = c.take<S>(n); p.a2 = c.take<S>(n); p.kp = c.take<S>(n);
     p.frames = num_stack > 0 ? c.take<S>((size_t)n * obs_dim) : nullptr;
+    p.head = num_stack > 0 ? c.take<int32_t>(n) : nullptr;
     p.t = c.take<int32_t>(n); p.episode = c.take<int32_t>(n);
 }
 
@@ -557,6 +560,11 @@ int64_t pime_ppo_bwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t m
     return ppo_bwd_image_floats(kind, D, Di, md);
 }
 
+int64_t pime_ppo_fwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t md) {
+    if (mlp_check(kind, D, Di, md) != PIME_OK) return 0;
+    return ppo_fwd_image_floats(kind, D, Di, md);
+}
+
 int64_t pime_ppo_workspace_floats(int32_t kind, int32_t B, int32_t md) {
     if (B < 1 || (md != 64 && md != 128 && md != 256) || (md == 256 && kind == PIME_MLP_MODULAR_ACTOR)) {
         set_error("pime_ppo_workspace_floats: B=%d md=%d kind=%d", B, md, kind);
@@ -574,7 +582,10 @@ int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const flo
 int pime_rollout_supported(const pime_env* e, int32_t kind, int32_t md) {
     if (e == nullptr) return 0;
     if (e->cfg.state_mode != PIME_STATE_MIXED) return 0;
-    if (e->cfg.kind != PIME_ENV_PH && e->cfg.num_stack != 0) return 0;
+    if (e->cfg.kind != PIME_ENV_PH && e->cfg.num_stack != 0) {   // Stacking1/4/10 under a plain actor (no integrator column)
+        const int S = e->cfg.num_stack;
+        if (kind != PIME_MLP_PLAIN_ACTOR || !(S == 1 || S == 4 || S == 10)) return 0;
+    }
     if (kind != PIME_MLP_PLAIN_ACTOR && kind != PIME_MLP_MODULAR_ACTOR) return 0;
     return (md == 64 || md == 128) && !family16(kind, md) ? 1 : 0;
 }
@@ -584,8 +595,6 @@ int pime_rollout(pime_env* e, int32_t kind, int32_t md, const float* packed_acto
                  float* action, float* noise, float* reward, uint8_t* done, pime_stream stream) {
     PIME_REQUIRE(e != nullptr, "NULL env handle");
     PIME_REQUIRE(e->cfg.state_mode == PIME_STATE_MIXED, "pime_rollout: needs an env handle in PIME_STATE_MIXED mode");
-    PIME_REQUIRE(e->cfg.kind == PIME_ENV_PH || e->cfg.num_stack == 0,
-                 "pime_rollout: the water-tank Stacking observation is not supported by the fused rollout");
     PIME_REQUIRE(packed_actor && a_std_log && priorK && state && action && noise && reward && done && n_steps >= 1,
                  "pime_rollout: bad arguments");
     PIME_REQUIRE(pime_rollout_supported(e, kind, md), "pime_rollout: no fused rollout for actor kind %d width %d "
@@ -593,7 +602,7 @@ int pime_rollout(pime_env* e, int32_t kind, int32_t md, const float* packed_acto
     if (!e->was_reset) { set_error("pime_rollout before pime_env_reset"); return PIME_ERR_STATE; }
     if (int rc = use_device(e)) return rc;
     RolloutArgs a{};
-    a.env = e->cfg.kind == PIME_ENV_PH ? 0 : 1;
+    a.env = e->cfg.kind == PIME_ENV_PH ? 0 : (e->cfg.num_stack == 0 ? 1 : 2);
     a.n = e->cfg.n_envs;
     a.env_offset = e->cfg.env_offset;
     if (a.env == 0) { a.p = e->ph; a.p.auto_reset = 1; a.st = e->ph32; }
@@ -634,7 +643,7 @@ int pime_ppo_repack(const pime_ppo_net* actor, const pime_ppo_net* critic, pime_
         const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
         for (int i = 0; i < np; ++i) pa[k].p[i] = n->params[i];
         pa[k].kind = n->kind; pa[k].D = n->D; pa[k].Di = n->Di; pa[k].md = n->md;
-        f16[k] = family16(n->kind, n->md);
+        f16[k] = family16_grad(n->kind, n->md, n->D, n->Di);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!f16[0] && !f16[1])
@@ -664,35 +673,39 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
     hipStream_t s = static_cast<hipStream_t>(stream);
     DwArgs dw{};
     static const bool force_split = std::getenv("PIME_PPO_SPLIT") != nullptr;  // A/B knob: the net + dW kernel pipeline
-    // Which kernel serves which net: the streamed 16-tile family (width 256, any state width <= 32; deterministic slabs), the
-    // LDS-resident fused kernel (64 / 128 while its LDS map fits), or -- for both nets together -- the split net + dW pipeline.
-    const bool f16_net[2] = {family16(critic->kind, critic->md), family16(actor->kind, actor->md)};
-    const bool split = force_split || (!f16_net[1] && !fused_fits(actor->kind, actor->D, actor->Di, actor->md)) ||
-                       (!f16_net[0] && !fused_fits(critic->kind, critic->D, critic->Di, critic->md));
-    PIME_REQUIRE(!(split && (f16_net[0] || f16_net[1])),
-                 "pime_ppo_minibatch_grad: a width-256 net cannot be paired with a net that needs the split pipeline "
-                 "(actor kind %d width %d state_dim %d)", actor->kind, actor->md, actor->D);
-    static const bool tracing = std::getenv("PIME_FUSED_TRACE") != nullptr;  // tuning aid: phase marks of workgroup 0
+    // Which kernel serves which net (index 0 = critic, 1 = actor):
+    //   F16   the streamed 16-tile family (mlp16.hip): width 256, and 64 / 128 on observations too wide for FUSED; slabs
+    //   FUSED the LDS-resident kernel (ppo_fused.hip): 64 / 128 while its LDS map fits; slabs
+    //   SPLIT the net + dW pipeline (ppo_train.hip, float atomics): a modular actor on a wide observation, or PIME_PPO_SPLIT
+    // Slab nets are finished by ppo_grad_reduce_kernel (which also derives the critic scale); a split critic by critic_scale_kernel.
+    enum { F16, FUSED, SPLIT };
+    const pime_ppo_net* nets[2] = {critic, actor};
+    int mode[2];
+    for (int k = 0; k < 2; ++k) {
+        const pime_ppo_net* n = nets[k];
+        if (family16_grad(n->kind, n->md, n->D, n->Di)) mode[k] = F16;
+        else mode[k] = (force_split || !fused_fits(n->kind, n->D, n->Di, n->md)) ? SPLIT : FUSED;
+    }
+    const bool any_split = mode[0] == SPLIT || mode[1] == SPLIT, any_slab = mode[0] != SPLIT || mode[1] != SPLIT;
+    static const bool tracing = std::getenv("PIME_FUSED_TRACE") != nullptr;  // tuning aid: phase marks of one workgroup
     static long long* trace_dev = nullptr;
     if (tracing && !trace_dev) {
         PIME_HIP_TRY(hipMalloc(&trace_dev, 2 * 64 * sizeof(long long)));
     }
     if (tracing) PIME_HIP_TRY(hipMemsetAsync(trace_dev, 0, 2 * 64 * sizeof(long long), s));
-    if (split) {
-        PIME_HIP_TRY(hipMemsetAsync(moments, 0, 2 * sizeof(double), s));  // atomics accumulate into it
-        if (b->flags & PIME_PPO_OVERWRITE_GRADS) {   // the atomics of this pipeline need zeroed targets
-            const pime_ppo_net* both[2] = {critic, actor};
-            for (const pime_ppo_net* n : both) {
-                int poff[13], psize[12];
-                slab_layout(n->kind, n->D, n->Di, n->md, poff, psize);
-                const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
-                for (int i = 0; i < np; ++i) PIME_HIP_TRY(hipMemsetAsync(n->grads[i], 0, sizeof(float) * psize[i], s));
-            }
-            PIME_HIP_TRY(hipMemsetAsync(actor->g_a_std_log, 0, sizeof(float), s));
+    if (mode[0] == SPLIT) PIME_HIP_TRY(hipMemsetAsync(moments, 0, 2 * sizeof(double), s));  // atomics accumulate into it
+    if (b->flags & PIME_PPO_OVERWRITE_GRADS) {   // the atomics of the split pipeline need zeroed targets
+        for (int k = 0; k < 2; ++k) {
+            if (mode[k] != SPLIT) continue;
+            const pime_ppo_net* n = nets[k];
+            int poff[13], psize[12];
+            slab_layout(n->kind, n->D, n->Di, n->md, poff, psize);
+            const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
+            for (int i = 0; i < np; ++i) PIME_HIP_TRY(hipMemsetAsync(n->grads[i], 0, sizeof(float) * psize[i], s));
+            if (k == 1) PIME_HIP_TRY(hipMemsetAsync(actor->g_a_std_log, 0, sizeof(float), s));
         }
     }
-    const pime_ppo_net* nets[2] = {critic, actor};
-    PpoArgs fused_args[2];
+    PpoArgs slab_args[2];
     for (int k = 0; k < 2; ++k) {
         const pime_ppo_net* n = nets[k];
         PpoArgs a{};
@@ -709,35 +722,31 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         if (const char* e = std::getenv("PIME_STAGGER")) a.stagger = std::atoi(e);  // tuning knob
         const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
         for (int i = 0; i < np; ++i) a.grad[i] = n->grads[i];
-        if (f16_net[k]) {
-            int psize[12];
+        a.trace = (tracing && mode[k] != SPLIT) ? trace_dev + 64 * k : nullptr;
+        a.trace_wg = tracing ? std::atoi(std::getenv("PIME_FUSED_TRACE")) : 0;
+        int psize[12];
+        if (mode[k] == F16) {
             a.slab = n->workspace;
             a.slab_stride = slab_layout16(n->D, n->md, a.poff, psize);
-            fused_args[k] = a;
-            a.trace = tracing ? trace_dev + 64 * k : nullptr;
-            a.trace_wg = tracing ? std::atoi(std::getenv("PIME_FUSED_TRACE")) : 0;
+            slab_args[k] = a;
             if (int rc = launch_ppo16(n->kind, n->md, a, s)) return rc;
-            continue;
-        }
-        if (!split) {
-            int psize[12];
+        } else if (mode[k] == FUSED) {
             a.slab = n->workspace + fused_stash_floats(b->B, n->md);
             a.slab_stride = slab_layout(n->kind, n->D, n->Di, n->md, a.poff, psize);
-            fused_args[k] = a;
-            a.trace = tracing ? trace_dev + 64 * k : nullptr;
-            a.trace_wg = tracing ? std::atoi(std::getenv("PIME_FUSED_TRACE")) : 0;
+            slab_args[k] = a;
             if (int rc = launch_ppo_fused(n->kind, n->md, a, s)) return rc;
-            continue;
+        } else {
+            slab_args[k] = a;
+            if (int rc = launch_ppo_net(n->kind, n->md, a, s)) return rc;
+            dw.njobs += build_dw_jobs(n->kind, n->md, a, n->params, n->grads, dw.job + dw.njobs);
         }
-        if (int rc = launch_ppo_net(n->kind, n->md, a, s)) return rc;
-        dw.njobs += build_dw_jobs(n->kind, n->md, a, n->params, n->grads, dw.job + dw.njobs);
     }
-    if (split) {
+    if (any_split) {
         dw.tiles_per_wg = 16;
         if (const char* e = std::getenv("PIME_DW_DEBUG")) dw.debug_skip = std::atoi(e);  // timing ablations only
         if (int rc = launch_dw(dw, b->B, s)) return rc;
     }
-    if (tracing && !split) {
+    if (tracing && any_slab) {
         long long t[128];
         PIME_HIP_TRY(hipStreamSynchronize(s));
         PIME_HIP_TRY(hipMemcpy(t, trace_dev, sizeof(t), hipMemcpyDeviceToHost));
@@ -750,14 +759,19 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
             std::fprintf(stderr, "\n");
         }
     }
-    if (!split)
-        return launch_grad_reduce(fused_args[0], fused_args[1], critic->kind, critic->md, actor->kind, actor->md,
-                                  f16_net[0], f16_net[1], f16_net[0] ? grid16(b->B, critic->md, critic->D) : fused_grid(b->B),
-                                  f16_net[1] ? grid16(b->B, actor->md, actor->D) : fused_grid(b->B),
-                                  critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, loss_sums + 3,
-                                  b->flags & PIME_PPO_OVERWRITE_GRADS, b->index_row, s);
-    return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, loss_sums + 3,
-                               b->index_row, s);
+    if (any_slab) {
+        const int nslabs[2] = {mode[0] == F16 ? grid16(b->B, critic->md, critic->D) : fused_grid(b->B),
+                               mode[1] == F16 ? grid16(b->B, actor->md, actor->D) : fused_grid(b->B)};
+        if (int rc = launch_grad_reduce(slab_args[0], slab_args[1], critic->kind, critic->md, actor->kind, actor->md,
+                                        mode[0] == F16, mode[1] == F16, mode[0] != SPLIT, mode[1] != SPLIT, nslabs[0], nslabs[1],
+                                        critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, loss_sums + 3,
+                                        b->flags & PIME_PPO_OVERWRITE_GRADS, mode[0] != SPLIT ? b->index_row : nullptr, s))
+            return rc;
+    }
+    if (mode[0] == SPLIT)   // scales the split critic's gradients, advances the index-table row
+        return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, loss_sums + 3,
+                                   b->index_row, s);
+    return PIME_OK;
 }
 
 }  // extern "C"

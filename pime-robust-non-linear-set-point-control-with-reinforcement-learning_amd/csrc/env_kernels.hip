@@ -67,37 +67,70 @@ __global__ void ph_observe_kernel(PhParams p, PhPtrs<S> st, float* __restrict__ 
 }
 
 // ============================================================================================ water tank
+// Stacking variant (nonlinear_watertank.py:1056-1208): frame ring in SoA order with a per-lane head (env_state.hpp).
 template <typename S>
-__device__ __forceinline__ void wt_write_obs(const WtParams& p, const WtPtrs<S>& st, int i, S h1, S h2, S r, S I,
-                                             float* __restrict__ obs) {
-    if (p.num_stack > 0) {  // Stacking: np.array(frames).reshape(1,-1)[0], oldest first (:1162-1164)
-        const S* f = st.frames + (size_t)i * p.obs_dim;
-        for (int j = 0; j < p.obs_dim; ++j) obs[(size_t)i * p.obs_dim + j] = (float)f[j];
-    } else {                // Integrator: [h1, h2, r, I] (:789-793)
+__device__ __forceinline__ void wt_frames_fill(const WtParams& p, const WtPtrs<S>& st, int i, const WtLane<S>& L) {
+    const size_t n = (size_t)p.n;   // every frame = the first frame (:1181-1183)
+    for (int s = 0; s < p.num_stack; ++s) {
+        st.frames[(3 * s + 0) * n + i] = L.h1; st.frames[(3 * s + 1) * n + i] = L.h2; st.frames[(3 * s + 2) * n + i] = L.r;
+    }
+    st.head[i] = 0;
+}
+template <typename S>
+__device__ __forceinline__ void wt_frames_push(const WtParams& p, const WtPtrs<S>& st, int i, const WtLane<S>& L) {
+    const size_t n = (size_t)p.n;   // deque(maxlen=S).append([h1,h2,r]) (:1143-1144): overwrite the oldest slot
+    const int h = st.head[i];
+    st.frames[(3 * h + 0) * n + i] = L.h1; st.frames[(3 * h + 1) * n + i] = L.h2; st.frames[(3 * h + 2) * n + i] = L.r;
+    st.head[i] = h + 1 == p.num_stack ? 0 : h + 1;
+}
+
+// Observation write-out; EVERY thread of the block calls it (`live` = this lane writes a row).
+//   Integrator: [h1, h2, r, I] (:789-793), one float4 per lane.
+//   Stacking:   np.array(frames).reshape(1,-1)[0], oldest first (:1162-1164) = 3S floats per lane.  Written lane by lane
+//               that is a 12 S-byte stride between neighbouring lanes; instead the block's rows are assembled in LDS
+//               ([blockDim][3S] + a live flag per row) and leave as one contiguous, coalesced run.
+template <typename S>
+__device__ __forceinline__ void wt_write_obs(const WtParams& p, const WtPtrs<S>& st, int i, bool live, S h1, S h2, S r, S I,
+                                             float* __restrict__ obs, float* __restrict__ lds) {
+    if (p.num_stack > 0) {
+        const int D = p.obs_dim;
+        int* flag = reinterpret_cast<int*>(lds + blockDim.x * D);
+        flag[threadIdx.x] = live ? 1 : 0;
+        if (live) {
+            const size_t n = (size_t)p.n;
+            int slot = st.head[i];
+            float* row = lds + threadIdx.x * D;
+            for (int j = 0; j < p.num_stack; ++j) {
+                row[3 * j + 0] = (float)st.frames[(3 * slot + 0) * n + i];
+                row[3 * j + 1] = (float)st.frames[(3 * slot + 1) * n + i];
+                row[3 * j + 2] = (float)st.frames[(3 * slot + 2) * n + i];
+                slot = slot + 1 == p.num_stack ? 0 : slot + 1;
+            }
+        }
+        __syncthreads();
+        const size_t base = (size_t)blockIdx.x * blockDim.x * D;
+        for (int e = threadIdx.x; e < (int)blockDim.x * D; e += blockDim.x)
+            if (flag[e / D]) obs[base + e] = lds[e];
+    } else if (live) {
         float4 o = make_float4((float)h1, (float)h2, (float)r, (float)I);
         *reinterpret_cast<float4*>(obs + 4 * (size_t)i) = o;
     }
 }
 
-// frames of the Stacking variant after a reset: every frame = first frame (:1181-1183)
-template <typename S>
-__device__ __forceinline__ void wt_fill_frames(const WtParams& p, const WtPtrs<S>& st, int i, const WtLane<S>& L) {
-    S* f = st.frames + (size_t)i * p.obs_dim;
-    for (int s = 0; s < p.num_stack; ++s) { f[3 * s] = L.h1; f[3 * s + 1] = L.h2; f[3 * s + 2] = L.r; }
-}
-
 template <typename S>
 __global__ void wt_reset_kernel(WtParams p, WtPtrs<S> st, const uint8_t* __restrict__ mask,
                                 const double* __restrict__ draws, float* __restrict__ obs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    if (mask && !mask[i]) return;
-    WtLane<S> L;
-    wt_lane_load<S>(p, st, i, L);
-    wt_lane_reset<S>(p, p.env_offset + (uint32_t)i, draws ? draws + 6 * (size_t)i : nullptr, L);
-    wt_lane_store<S>(p, st, i, L);
-    if (p.num_stack > 0) wt_fill_frames<S>(p, st, i, L);
-    wt_write_obs<S>(p, st, i, L.h1, L.h2, L.r, L.I, obs);
+    const bool live = i < p.n && (!mask || mask[i]);
+    WtLane<S> L{};
+    if (live) {
+        wt_lane_load<S>(p, st, i, L);
+        wt_lane_reset<S>(p, p.env_offset + (uint32_t)i, draws ? draws + 6 * (size_t)i : nullptr, L);
+        wt_lane_store<S>(p, st, i, L);
+        if (p.num_stack > 0) wt_frames_fill<S>(p, st, i, L);
+    }
+    wt_write_obs<S>(p, st, i, live, L.h1, L.h2, L.r, L.I, obs, lds);
 }
 
 template <typename S, typename ActT, bool RESIDUAL>
@@ -105,48 +138,54 @@ __global__ void wt_step_kernel(WtParams p, WtPtrs<S> st, const ActT* __restrict_
                                const float* __restrict__ obs_in, PriorK K, const double* __restrict__ noise,
                                const double* __restrict__ reset_draws, float* __restrict__ obs,
                                float* __restrict__ reward, uint8_t* __restrict__ done) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    double a;
-    if constexpr (RESIDUAL) {  // agent_residual.py:61
-        double dot = 0.0;
-        for (int j = 0; j < p.obs_dim; ++j) dot += (double)obs_in[(size_t)i * p.obs_dim + j] * K.k[j];
-        a = (double)tanhf((float)act[i]) + dot;
-    } else {
-        a = (double)act[i];
-    }
-    const uint32_t gid = p.env_offset + (uint32_t)i;
-    WtLane<S> L;
-    wt_lane_load<S>(p, st, i, L);
-    double z1n, z2n;
-    wt_lane_noise<S>(p, gid, L, noise ? noise + 2 * (size_t)i : nullptr, z1n, z2n);
-    float rew;
-    const bool d = wt_lane_step<S>(p, a, z1n, z2n, L, rew);
-    reward[i] = rew;
-    done[i] = (uint8_t)d;
-    if (d && p.auto_reset) {
-        wt_lane_reset<S>(p, gid, reset_draws ? reset_draws + 6 * (size_t)i : nullptr, L);
-        wt_lane_store<S>(p, st, i, L);
-        if (p.num_stack > 0) wt_fill_frames<S>(p, st, i, L);
-    } else {
-        wt_lane_store<S>(p, st, i, L);
-        if (p.num_stack > 0) {  // deque(maxlen=S).append([h1,h2,r]) (:1143-1144)
-            S* f = st.frames + (size_t)i * p.obs_dim;
-            for (int j = 0; j < p.obs_dim - 3; ++j) f[j] = f[j + 3];
-            f[p.obs_dim - 3] = L.h1; f[p.obs_dim - 2] = L.h2; f[p.obs_dim - 1] = L.r;
+    const bool live = i < p.n;
+    WtLane<S> L{};
+    if (live) {
+        double a;
+        if constexpr (RESIDUAL) {  // agent_residual.py:61
+            double dot = 0.0;
+            for (int j = 0; j < p.obs_dim; ++j) dot += (double)obs_in[(size_t)i * p.obs_dim + j] * K.k[j];
+            a = (double)tanhf((float)act[i]) + dot;
+        } else {
+            a = (double)act[i];
+        }
+        const uint32_t gid = p.env_offset + (uint32_t)i;
+        wt_lane_load<S>(p, st, i, L);
+        double z1n, z2n;
+        wt_lane_noise<S>(p, gid, L, noise ? noise + 2 * (size_t)i : nullptr, z1n, z2n);
+        float rew;
+        const bool d = wt_lane_step<S>(p, a, z1n, z2n, L, rew);
+        reward[i] = rew;
+        done[i] = (uint8_t)d;
+        if (d && p.auto_reset) {
+            wt_lane_reset<S>(p, gid, reset_draws ? reset_draws + 6 * (size_t)i : nullptr, L);
+            wt_lane_store<S>(p, st, i, L);
+            if (p.num_stack > 0) wt_frames_fill<S>(p, st, i, L);
+        } else {
+            wt_lane_store<S>(p, st, i, L);
+            if (p.num_stack > 0) wt_frames_push<S>(p, st, i, L);
         }
     }
-    wt_write_obs<S>(p, st, i, L.h1, L.h2, L.r, L.I, obs);
+    wt_write_obs<S>(p, st, i, live, L.h1, L.h2, L.r, L.I, obs, lds);
 }
 
 template <typename S>
 __global__ void wt_observe_kernel(WtParams p, WtPtrs<S> st, float* __restrict__ obs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    wt_write_obs<S>(p, st, i, st.h1[i], st.h2[i], st.r[i], p.num_stack > 0 ? S(0) : st.I[i], obs);
+    const bool live = i < p.n;
+    const int k = live ? i : 0;
+    wt_write_obs<S>(p, st, i, live, st.h1[k], st.h2[k], st.r[k], p.num_stack > 0 ? S(0) : st.I[k], obs, lds);
 }
 
 // ============================================================================================ launchers
+// LDS of the Stacking observation staging: [block][3S] floats + one live flag per row
+static inline size_t wt_obs_lds_bytes(const WtParams& p, int block) {
+    return p.num_stack > 0 ? sizeof(float) * (size_t)block * (p.obs_dim + 1) : 0;
+}
+
 static inline dim3 lane_grid(int n, int& block) {
     // one wave per workgroup while the launch is small, so a 16 384-env launch still spreads over all 256 CUs
     block = n <= 65536 ? 64 : 256;
@@ -196,7 +235,7 @@ int launch_wt_reset(const WtParams& p, const WtPtrs<S>& st, const uint8_t* mask,
                     hipStream_t s) {
     int block;
     const dim3 grid = lane_grid(p.n, block);
-    hipLaunchKernelGGL(wt_reset_kernel<S>, grid, dim3(block), 0, s, p, st, mask, draws, obs);
+    hipLaunchKernelGGL(wt_reset_kernel<S>, grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st, mask, draws, obs);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
@@ -208,14 +247,14 @@ int launch_wt_step(const WtParams& p, const WtPtrs<S>& st, const void* act, int 
     int block;
     const dim3 grid = lane_grid(p.n, block);
     if (residual)
-        hipLaunchKernelGGL((wt_step_kernel<S, float, true>), grid, dim3(block), 0, s, p, st, (const float*)act, obs_in,
-                           K, noise, reset_draws, obs, reward, done);
+        hipLaunchKernelGGL((wt_step_kernel<S, float, true>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st,
+                           (const float*)act, obs_in, K, noise, reset_draws, obs, reward, done);
     else if (act_dtype == PIME_F32)
-        hipLaunchKernelGGL((wt_step_kernel<S, float, false>), grid, dim3(block), 0, s, p, st, (const float*)act,
-                           obs_in, K, noise, reset_draws, obs, reward, done);
+        hipLaunchKernelGGL((wt_step_kernel<S, float, false>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st,
+                           (const float*)act, obs_in, K, noise, reset_draws, obs, reward, done);
     else
-        hipLaunchKernelGGL((wt_step_kernel<S, double, false>), grid, dim3(block), 0, s, p, st, (const double*)act,
-                           obs_in, K, noise, reset_draws, obs, reward, done);
+        hipLaunchKernelGGL((wt_step_kernel<S, double, false>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st,
+                           (const double*)act, obs_in, K, noise, reset_draws, obs, reward, done);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
@@ -224,7 +263,7 @@ template <typename S>
 int launch_wt_observe(const WtParams& p, const WtPtrs<S>& st, float* obs, hipStream_t s) {
     int block;
     const dim3 grid = lane_grid(p.n, block);
-    hipLaunchKernelGGL(wt_observe_kernel<S>, grid, dim3(block), 0, s, p, st, obs);
+    hipLaunchKernelGGL(wt_observe_kernel<S>, grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st, obs);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }

@@ -37,7 +37,11 @@ struct WtParams {
 template <typename S>
 struct WtPtrs {
     S *h1, *h2, *r, *I, *a1, *a2, *kp;
-    S* frames;  // [n][num_stack][3], oldest first (Stacking variant only)
+    // Stacking variant only: the last num_stack frames [h1, h2, r] as a RING in SoA order, frames[(slot * 3 + c) * n + lane],
+    // and the per-lane slot of the OLDEST frame (the deque's left end, nonlinear_watertank.py:1143-1144): a step overwrites that
+    // slot and advances head, instead of shifting 3 (S - 1) words per lane; every access is a contiguous wave-wide segment.
+    S* frames;
+    int32_t* head;
     int32_t *t, *episode;
 };
 

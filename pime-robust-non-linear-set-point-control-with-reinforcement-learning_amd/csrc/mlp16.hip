@@ -681,11 +681,25 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
 }
 
 // ==================================================================================================== host side
+bool fused_fits(int kind, int D, int Di, int md);
+
+// Which nets this family serves.  Forward images (pime_mlp_pack / pime_mlp_forward; the fused rollout reads the 32x32x2
+// layout): width 256 only.  Gradient path (pime_ppo_*): width 256, and widths 64 / 128 when the observation is too wide for the
+// LDS-resident kernel's map (the stacked water tank, 30 floats) -- instead of the split net + dW pipeline and its float atomics,
+// so that those gradients are reproducible too.  PIME_MLP16=1 (A/B knob) routes every plain net of width 64 / 128 here.
+static bool forced16() {
+    static const bool forced = std::getenv("PIME_MLP16") != nullptr;
+    return forced;
+}
 bool family16(int kind, int md) {
     if (kind == MLP_MODULAR_ACTOR) return false;
     if (md == 256) return true;
-    static const bool forced = std::getenv("PIME_MLP16") != nullptr;   // A/B knob: serve widths 64 / 128 from this family too
-    return forced && (md == 64 || md == 128);
+    return forced16() && (md == 64 || md == 128);
+}
+bool family16_grad(int kind, int md, int D, int Di) {
+    if (family16(kind, md)) return true;
+    if (kind == MLP_MODULAR_ACTOR || (md != 64 && md != 128)) return false;
+    return !fused_fits(kind, D, Di, md);
 }
 
 int64_t packed16_floats(int D, int md) { return layout16(D, md).total; }

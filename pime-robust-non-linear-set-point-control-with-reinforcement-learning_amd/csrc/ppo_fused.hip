@@ -879,6 +879,7 @@ struct ReduceSeg {
 struct ReduceArgs {
     ReduceSeg seg[24];
     int nseg, nslabs[2], B, moments_off, overwrite;   // nslabs per net (the two nets may come from different kernel families)
+    int has_critic;     // 0: the critic went through the split pipeline (critic_scale_kernel finishes it): no scale, no cursor
     float* scale_sum;   // loss_sums + 3: [0] += scale, [1] += critic loss sum of this call * scale, [2] = critic sum so far
     int64_t* index_row; // NULL, or the index table's row cursor: advanced once per call, after both nets read it
     const float* slab[2];
@@ -900,7 +901,9 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
     }
     if (si >= a.nseg) return;
     const ReduceSeg sg = a.seg[si];
-    if (wave == 0) {  // critic scale from the moments (every workgroup: same slabs, same order, same value)
+    if (wave == 0 && !a.has_critic) {
+        if (lane == 0) scale_sh = 1.0f;
+    } else if (wave == 0) {  // critic scale from the moments (every workgroup: same slabs, same order, same value)
         double m1 = 0.0, m2 = 0.0;
         for (int s = lane; s < a.nslabs[0]; s += 64) {
             const double* mo = reinterpret_cast<const double*>(a.slab[0] + (size_t)s * a.stride[0] + a.moments_off);
@@ -999,7 +1002,7 @@ int fused_grid(int B) {
 }
 
 int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
-                       bool f16_c, bool f16_a, int nslabs_c, int nslabs_a, float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
+                       bool f16_c, bool f16_a, bool use_c, bool use_a, int nslabs_c, int nslabs_a, float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
                        double* moments_out, float* scale_sum, int overwrite, int64_t* index_row, hipStream_t s) {
     ReduceArgs r{};
     int poff[13], psize[12], chunks = 0;
@@ -1023,11 +1026,16 @@ int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, 
         }
         *scalar_off = poff[np];
     };
+    // use_c / use_a: which nets left slabs (a net served by the split pipeline wrote its gradients with atomics already)
     int scalar_c = 0, scalar_a = 0;
-    add_net(critic, kind_c, md_c, f16_c, grads_c, 0, &scalar_c);
+    r.has_critic = use_c ? 1 : 0;
+    if (use_c) add_net(critic, kind_c, md_c, f16_c, grads_c, 0, &scalar_c);
     r.moments_off = scalar_c;
-    add_net(actor, kind_a, md_a, f16_a, grads_a, 1, &scalar_a);
-    add(g_std, scalar_a, 1, 1);
+    if (use_a) {
+        add_net(actor, kind_a, md_a, f16_a, grads_a, 1, &scalar_a);
+        add(g_std, scalar_a, 1, 1);
+    }
+    if (chunks == 0) return PIME_OK;
     r.nslabs[0] = nslabs_c; r.nslabs[1] = nslabs_a; r.B = critic.B;
     r.slab[0] = critic.slab; r.slab[1] = actor.slab;
     r.stride[0] = critic.slab_stride; r.stride[1] = actor.slab_stride;

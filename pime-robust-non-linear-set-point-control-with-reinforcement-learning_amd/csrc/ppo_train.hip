@@ -490,29 +490,37 @@ int launch_adam(float* p, const float* g, float* m, float* v, long long n, float
 int mlp_check(int kind, int D, int Di, int md);
 
 bool family16(int kind, int md);
+bool family16_grad(int kind, int md, int D, int Di);
+int64_t packed16_floats(int D, int md);
 int64_t bwd16_floats(int md);
 int grid16(int B, int md, int D);
 int launch_pack16(const PackArgs& a, float* fwd, float* bwd, hipStream_t s);
 
 int64_t ppo_bwd_image_floats(int kind, int D, int Di, int md) {
-    return family16(kind, md) ? bwd16_floats(md) : (int64_t)bwd_layout(kind, D, Di, md).total;
+    return family16_grad(kind, md, D, Di) ? bwd16_floats(md) : (int64_t)bwd_layout(kind, D, Di, md).total;
+}
+int64_t ppo_fwd_image_floats(int kind, int D, int Di, int md) {
+    return family16_grad(kind, md, D, Di) ? packed16_floats(D, md) : (int64_t)mlp_layout(kind, D, Di, md).total;
 }
 
 int64_t fused_workspace_floats(int kind, int B, int D, int Di, int md);
 
 int64_t ppo_workspace_floats(int kind, int B, int md) {
-    if (family16(kind, md)) {   // gradient slabs only (no activation stash): bound over the state widths
+    int64_t f16 = 0;
+    if (kind != MLP_MODULAR_ACTOR) {   // the 16-tile family: gradient slabs only (no activation stash), bound over the state widths
         int poff[13], psize[12];
         const int64_t stride = slab_layout16(kMaxObsDim, md, poff, psize);
         int g = grid16(B, md, 1);
         const int g2 = grid16(B, md, kMaxObsDim);
         g = g > g2 ? g : g2;
-        return (int64_t)g * stride;
+        f16 = (int64_t)g * stride;
     }
+    if (md == 256) return f16;
     const int64_t ntiles = ((B + 31) / 32 + 7) / 8 * 8;
     const int64_t split = ntiles * stash_tiles(kind, md / 32) * 1024 + ntiles * 32 + ntiles * 32 * kMaxObsDim;
     const int64_t fused = fused_workspace_floats(kind, B, kMaxObsDim, 1, md);  // slab size bound: widest state
-    return split > fused ? split : fused;
+    const int64_t old = split > fused ? split : fused;
+    return old > f16 ? old : f16;   // the caller does not say the state width: room for whichever family serves it
 }
 
 int launch_pack_bwd(int kind, int D, int Di, int md, const float* const* params, float* out, hipStream_t s) {
@@ -524,7 +532,7 @@ int launch_pack_bwd(int kind, int D, int Di, int md, const float* const* params,
         a.p[i] = params[i];
     }
     a.kind = kind; a.D = D; a.Di = Di; a.md = md;
-    if (family16(kind, md)) return launch_pack16(a, nullptr, out, s);
+    if (family16_grad(kind, md, D, Di)) return launch_pack16(a, nullptr, out, s);
     hipLaunchKernelGGL(mlp_pack_bwd_kernel, dim3(64), dim3(256), 0, s, a, out);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;

@@ -1,4 +1,4 @@
-// Fused on-device rollout for the pH and water-tank (Integrator observation) envs: ONE launch advances every lane through `n_steps` steps --
+// Fused on-device rollout for the pH and water-tank (Integrator and Stacking1/4/10 observation) envs: ONE launch advances every lane through `n_steps` steps --
 // policy forward on the f32 matrix cores, exploration noise, residual action composition, env step (+ in-kernel
 // auto-reset) and the trajectory-buffer writes -- with the env state and the observation in registers for the whole
 // episode.  Replaces the per-step launch sequence of AgentResidual*.explore_env
@@ -42,10 +42,15 @@ __device__ __forceinline__ void layer_first_regs(const float* __restrict__ w0, c
 
 constexpr int kRolloutThreads = 128;
 
-template <int T, int KIND, int ENV>
+// ENV 0: pH, obs [y, r, I];  1: water tank, Integrator obs [h1, h2, r, I];  2: water tank, Stacking obs = the last STACK frames
+// [h1, h2, r], oldest first (nonlinear_watertank.py:1056-1208).  For ENV 2 the observation registers ARE the frame deque: a step
+// shifts them by one frame and appends the new one, a reset fills every frame with the first (:1181-1183); the SoA ring in HBM
+// is only written back when the launch ends.
+template <int T, int KIND, int ENV, int STACK>
 __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int D = ENV == 0 ? 3 : 4, Di = 1, Do = D - Di;
+    constexpr int D = ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), Di = ENV == 2 ? 0 : 1, Do = D - Di;
+    static_assert(ENV != 2 || KIND == MLP_PLAIN_ACTOR, "the Stacking observation has no integrator column: plain actors only");
     constexpr int H = T / 2 > 0 ? T / 2 : 1;
     const MlpLayout L = mlp_layout(KIND, D, Di, T * 32);
     stage_image(lds, a.img, L.total / 4);
@@ -120,7 +125,13 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
             wt_lane_noise<float>(a.wp, gid, W, nullptr, z1n, z2n);
             d = wt_lane_step<float>(a.wp, a_env, z1n, z2n, W, rew);
             if (d) wt_lane_reset<float>(a.wp, gid, nullptr, W);
-            nxt[0] = W.h1; nxt[1] = W.h2; nxt[2] = W.r; nxt[D - 1] = W.I;
+            if constexpr (ENV == 1) {
+                nxt[0] = W.h1; nxt[1] = W.h2; nxt[2] = W.r; nxt[D - 1] = W.I;
+            } else {   // deque(maxlen=S).append (:1143-1144), or after a reset every frame = the first one (:1181-1183)
+#pragma unroll
+                for (int j = 0; j < D - 3; ++j) nxt[j] = d ? (j % 3 == 0 ? W.h1 : (j % 3 == 1 ? W.h2 : W.r)) : obs[j + 3];
+                nxt[D - 3] = W.h1; nxt[D - 2] = W.h2; nxt[D - 1] = W.r;
+            }
         }
         const size_t k = (size_t)t * N + i;
         if (writer) {
@@ -138,34 +149,44 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
     if (writer) {
         if constexpr (ENV == 0) ph_lane_store<float>(a.p, a.st, i, E);
         else wt_lane_store<float>(a.wp, a.wst, i, W);
+        if constexpr (ENV == 2) {   // the frame ring of the step-per-launch kernels: slot j = frame j, oldest at slot 0
+#pragma unroll
+            for (int j = 0; j < D; ++j) a.wst.frames[(size_t)j * N + i] = obs[j];
+            a.wst.head[i] = 0;
+        }
     }
 }
 
 int mlp_check(int kind, int D, int Di, int md);
 
-template <int T, int KIND, int ENV>
+template <int T, int KIND, int ENV, int STACK>
 static int launch_rollout_t(const RolloutArgs& a, hipStream_t s) {
-    const MlpLayout L = mlp_layout(KIND, ENV == 0 ? 3 : 4, 1, T * 32);
+    const MlpLayout L = mlp_layout(KIND, ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), ENV == 2 ? 0 : 1, T * 32);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<T, KIND, ENV>),
+        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<T, KIND, ENV, STACK>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int tiles = (a.n + 31) / 32, per_wg = kRolloutThreads / 64;
-    hipLaunchKernelGGL((rollout_kernel<T, KIND, ENV>), dim3((tiles + per_wg - 1) / per_wg), dim3(kRolloutThreads),
+    hipLaunchKernelGGL((rollout_kernel<T, KIND, ENV, STACK>), dim3((tiles + per_wg - 1) / per_wg), dim3(kRolloutThreads),
                        lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 
 int launch_rollout(int kind, int md, const RolloutArgs& a, hipStream_t s) {
-    if (int rc = mlp_check(kind, a.env == 0 ? 3 : 4, kind == MLP_MODULAR_ACTOR ? 1 : 0, md)) return rc;
+    const int D = a.env == 0 ? 3 : (a.env == 1 ? 4 : 3 * a.wp.num_stack);
+    if (int rc = mlp_check(kind, D, kind == MLP_MODULAR_ACTOR ? 1 : 0, md)) return rc;
     PIME_REQUIRE(kind != MLP_CRITIC, "rollout needs an actor image");
     const int T = md / 32;
+#define PIME_RS(TT, SS) \
+    if (T == TT && kind == MLP_PLAIN_ACTOR && a.env == 2 && a.wp.num_stack == SS) return launch_rollout_t<TT, MLP_PLAIN_ACTOR, 2, SS>(a, s);
+    PIME_RS(4, 1) PIME_RS(4, 4) PIME_RS(4, 10) PIME_RS(2, 1) PIME_RS(2, 4) PIME_RS(2, 10)
+#undef PIME_RS
 #define PIME_RO(TT, KK, EE) \
-    if (T == TT && kind == KK && a.env == EE) return launch_rollout_t<TT, KK, EE>(a, s);
+    if (T == TT && kind == KK && a.env == EE) return launch_rollout_t<TT, KK, EE, 0>(a, s);
     PIME_RO(4, MLP_MODULAR_ACTOR, 0) PIME_RO(2, MLP_MODULAR_ACTOR, 0) PIME_RO(4, MLP_PLAIN_ACTOR, 0) PIME_RO(2, MLP_PLAIN_ACTOR, 0)
     PIME_RO(4, MLP_MODULAR_ACTOR, 1) PIME_RO(2, MLP_MODULAR_ACTOR, 1) PIME_RO(4, MLP_PLAIN_ACTOR, 1) PIME_RO(2, MLP_PLAIN_ACTOR, 1)
 #undef PIME_RO

@@ -4,7 +4,7 @@
 
 namespace pime {
 struct RolloutArgs {
-    int env;                 // 0: pH (obs [y, r, I]), 1: water tank, Integrator observation [h1, h2, r, I]
+    int env;                 // 0: pH (obs [y, r, I]); 1: water tank, Integrator observation [h1, h2, r, I]; 2: water tank, Stacking
     int n;                   // lanes
     uint32_t env_offset;
     PhParams p;

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "pime_mlp_pack": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pime_mlp_forward": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
 
+    "pime_ppo_fwd_image_floats": (C.c_int64, [_i32, _i32, _i32, _i32]),
     "pime_ppo_bwd_image_floats": (C.c_int64, [_i32, _i32, _i32, _i32]),
     "pime_ppo_workspace_floats": (C.c_int64, [_i32, _i32, _i32]),
     "pime_ppo_pack_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),

@@ -155,7 +155,7 @@ class FusedPPOGrad:
             D, Di = module.state_dim, getattr(module, "integrator_dim", 0)
             md = plist[0].shape[0]
             k = _KINDS[kind]
-            n_fwd = L.pime_mlp_packed_floats(k, D, Di, md)
+            n_fwd = L.pime_ppo_fwd_image_floats(k, D, Di, md)
             n_bwd = L.pime_ppo_bwd_image_floats(k, D, Di, md)
             n_ws = L.pime_ppo_workspace_floats(k, self.max_batch, md)
             if n_fwd <= 0 or n_bwd <= 0 or n_ws <= 0:

@@ -254,10 +254,9 @@ class VecControlEnv:
 
     @property
     def supports_fused_rollout(self):
-        """The one-launch-per-episode rollout kernel exists for mixed-precision state, in-kernel (Philox) draws and --
-        for the water tank -- the Integrator observation."""
-        return (self.cfg.state_mode == native.STATE_MIXED and not self.draws.injects
-                and (self.kind == native.ENV_PH or self.cfg.num_stack == 0))
+        """The one-launch-per-episode rollout kernel needs mixed-precision state and in-kernel (Philox) draws; which
+        observation / actor shapes it serves is the library's answer (`rollout_supported`)."""
+        return self.cfg.state_mode == native.STATE_MIXED and not self.draws.injects
 
     def rollout_supported(self, packed_actor):
         """Does the fused rollout kernel serve this env with this packed actor (kind / width)?  (pime_rollout_supported)"""

@@ -93,6 +93,14 @@ def test_plain_ppo_actor_width_256():
     check_grads("ppo", 256, 3, 1024)
 
 
+@pytest.mark.parametrize("md,D,B", [(128, 30, 2048), (64, 30, 1000), (128, 12, 4096)])
+def test_wide_observation_gradients_are_deterministic(md, D, B):
+    """Stacking10 / Stacking4 observations at width 64 / 128: too wide for the LDS-resident gradient kernel, served by the
+    16-tile family's slabs (bit-for-bit reproducible; the split pipeline's float atomics were not) -- check_grads asserts both
+    the autograd match and the bitwise repeat."""
+    check_grads("resid", md, D, B)
+
+
 def test_width_256_agent_takes_the_hip_path():
     """AgentResidualPPO at net_dim 256 on the Stacking10 env: packed forwards + fused gradients (no silent torch fallback),
     step-wise rollout (the fused rollout kernel serves widths 64 / 128: pime_rollout_supported says so)."""

@@ -66,7 +66,8 @@ def _torch_grads(act, cri, state, action, logprob, adv, r_sum, idx, clip, lam):
                                          ("resid", 128, 3, 4096), ("resid", 64, 12, 777), ("ppo", 128, 3, 2048),
                                          ("modular", 128, 3, 65536),
                                          ("modular", 128, 3, 70000),   # > 256 sample groups: workgroups accumulate a 2nd group
-                                         ("resid", 128, 30, 2048),     # stacked-tank width: LDS map does not fit -> split pipeline
+                                         ("resid", 128, 30, 2048),     # stacked-tank width: LDS map does not fit -> streamed 16-tile family
+                                         ("modular", 128, 30, 2048),   # wide modular actor: the split net + dW pipeline
                                          ("modular", 128, 6, 3000),
                                          ("modular", 128, 10, 2048),   # first-layer gradients in matrix form (fan-in > 8)
                                          ("resid", 128, 10, 1500)])
@@ -139,11 +140,12 @@ def test_fused_gradients_are_reproducible_and_accumulate():
 
 
 def test_split_pipeline_honours_overwrite_and_index_table():
-    """The atomics-based pipeline that serves wide states (LDS map of the fused kernel does not fit): the same ABI
-    options -- PIME_PPO_OVERWRITE_GRADS zeroes its targets first, index_row selects and advances the table row."""
+    """The atomics-based pipeline that serves a modular actor on a wide state (LDS map of the fused kernel does not fit;
+    plain nets go to the streamed 16-tile family instead): the same ABI options -- PIME_PPO_OVERWRITE_GRADS zeroes its
+    targets first, index_row selects and advances the table row."""
     from pime_amd import ops
     B, D = 2048, 30
-    act, cri = _make("resid", 128, D, seed=11)
+    act, cri = _make("modular", 128, D, seed=11)
     state, action, logprob, adv, r_sum = _data(3 * B, D, act, seed=5)
     idx = torch.randint(3 * B, (B,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
     want, *_ = _torch_grads(act, cri, state, action, logprob, adv, r_sum, idx, 0.2, 0.02)

@@ -53,16 +53,20 @@ def _oracle_mean(algo, obs, sd):
     ("PH_V35", "PPO", 4096, 64),                              # plain PPO: the env sees tanh(a_pre), no prior term
     ("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 4096, 128),   # BASELINE config 2 workload
     ("WT_INTEGRATOR", "ResidualPPO", 2048, 64),
+    ("WT_STACKING10", "ResidualPPO", 2048, 128),                    # run_watertank_changing.sh:20-27 observation (30 floats)
+    ("WT_STACKING4", "ResidualPPO", 1024, 64),
+    ("WT_STACKING1", "PPO", 1024, 128),
 ])
 def test_fused_rollout_replays_through_oracle(env_name, algo, N, md):
     import oracle
     from pime_amd import gym_control
     from pime_amd.elegantrl.run import make_buffer
     is_ph = env_name == "PH_V35"
+    stack = int(env_name[len("WT_STACKING"):]) if env_name.startswith("WT_STACKING") else 0
+    env_id = gym_control.WT_STACKING.format(stack) if stack else getattr(gym_control, env_name)
     seed, offset = 21, 4096     # a non-zero lane offset: the Philox counter word is the GLOBAL lane id
     kw = {} if is_ph else dict(reward_type="distance", max_step=60)
-    env = gym_control.make_vec(getattr(gym_control, env_name), N, device=DEV, state_mode="mixed", seed=seed,
-                               env_offset=offset, **kw)
+    env = gym_control.make_vec(env_id, N, device=DEV, state_mode="mixed", seed=seed, env_offset=offset, **kw)
     T = env.max_step
     ag = _agent(algo, env, md)
     assert ag._fused_rollout_ok(env), "the fused rollout path must serve this configuration"
@@ -74,7 +78,7 @@ def test_fused_rollout_replays_through_oracle(env_name, algo, N, md):
     if is_ph:
         ref = oracle.OraclePH(N, oracle.ph_table(), seed=seed, env_offset=offset)
     else:
-        ref = oracle.OracleWT(N, max_steps=T, reward_type="distance", seed=seed, env_offset=offset)
+        ref = oracle.OracleWT(N, max_steps=T, reward_type="distance", num_stack=stack, seed=seed, env_offset=offset)
     priorK = ag._rollout_priorK()
     sd = {k: v.detach().cpu().numpy() for k, v in ag.act.state_dict().items()}
     sigma = np.float32(np.exp(sd["a_std_log"][0, 0]))
@@ -128,7 +132,9 @@ def test_fused_rollout_replays_through_oracle(env_name, algo, N, md):
         np.testing.assert_allclose(reward[t][alive], rew[alive], rtol=rtol, atol=rtol)
         np.testing.assert_allclose(state[t + 1][alive], obs[alive], rtol=rtol, atol=rtol)
         if not is_ph:   # the oracle continues from ITS state: re-sync it to the kernel's f32 state so errors do not compound
-            for name, col in (("h1", 0), ("h2", 1), ("I", 3)):
+            D = state.shape[2]   # Stacking: the newest frame is the last one
+            cols = (("h1", D - 3), ("h2", D - 2)) if stack else (("h1", 0), ("h2", 1), ("I", 3))
+            for name, col in cols:
                 ref.set(name, state[t + 1][:, col].astype(np.float64))
     assert min(cell_exact) >= 0.97, f"only {min(cell_exact):.3f} of the lanes stayed cell-exact over an episode"
     # ensemble params were resampled by the in-kernel reset of episode 2 exactly as the oracle's
