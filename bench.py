@@ -300,13 +300,48 @@ def launcher_selftest(json_fd):
         os.write(json_fd, (json.dumps({"selftest": "launcher", "n_gpus": got_world, "max_t": t, "sum": total}) + "\n").encode())
 
 
+def bench_water_tank_td3(args, device, json_fd):
+    """BASELINE config 2 as BASELINE.json words it: water-tank Integrator env, 4096 vectorised instances, residual TD3
+    (AgentResidualTD3: composed from the reference's TD3 pieces).  One step = 200 lock-steps of all lanes
+    (one episode each: 819 200 transitions into the device ring) + 200 TD3 optimizer steps (one per lock-step, the reference's
+    schedule counted per lock-step), batch 4096, net_dim 128; update replayed from HIP graphs, nets in PyTorch-ROCm."""
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.agent_residual import AgentResidualTD3
+    from pime_amd.elegantrl.run import make_buffer
+    lanes, T, batch = 4096, 200, 4096
+    env = gym_control.make_vec(gym_control.WT_INTEGRATOR, lanes, device=device, state_mode="mixed", seed=0, reward_type="distance")
+    torch.manual_seed(0)
+    agent = AgentResidualTD3(device=device)
+    agent.init(NET_DIM, env.state_dim, 1)
+    agent.init_residual({"init_K": env.K.reshape(-1, 1)})
+    buf = make_buffer(agent, env, 2 ** 21)
+
+    def step():
+        n = agent.explore_env(env, buf, lanes * T, 1.0, GAMMA)
+        agent.update_net(buf, lanes * T, batch, 1)
+        return n
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total = sum(step() for _ in range(args.steps))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": "env-steps/sec (rollout+update), water-tank env, 4096 parallel envs, residual TD3", "value": total / dt,
+           "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "water tank Integrator-v2 (reward 'distance'), 4096 lanes x 200 lock-steps, AgentResidualTD3 "
+                                  "net_dim 128, 200 optimizer steps of batch 4096 per step (HIP-graph replay)"}}
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ph", choices=["ph", "wt"],
+    ap.add_argument("--workload", default="ph", choices=["ph", "wt", "wt_td3"],
                     help="ph: the headline config (BASELINE config 3); wt: config 2, water tank, 4096 lanes x 200 steps "
                          "(reported for DESIGN.md; the headline metric is the ph line)")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
@@ -337,6 +372,8 @@ def main():
 
     if args.workload == "wt":
         return bench_water_tank(args, device, json_fd)
+    if args.workload == "wt_td3":
+        return bench_water_tank_td3(args, device, json_fd)
     env, agent, buf = build_stack(device, rank, world, dp)
     timer = KernelTimer()
     # time the hand-written kernels where the agent calls them

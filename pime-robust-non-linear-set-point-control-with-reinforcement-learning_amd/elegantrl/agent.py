@@ -21,7 +21,7 @@ from . import logger
 from .. import dist as pdist
 from ..backend import HipBackend
 from .net import Actor, ActorPPO, CriticAdv, CriticTwin
-from .replay import TrajectoryBuffer
+from .replay import TrajectoryBuffer, VecReplayBuffer
 
 
 class AgentBase:
@@ -519,14 +519,23 @@ class AgentPPO(AgentBase):
 
 # ================================================================================================= TD3
 class AgentTD3(AgentBase):
-    """Twin-delayed DDPG on the flat ring buffer (agent.py:276-394).  Pure PyTorch-ROCm; kept for the
-    reference's `--algo TD3` entry (which only runs there with the residual flags patched off)."""
+    """Twin-delayed DDPG (agent.py:276-394): twin critics, target policy smoothing, delayed soft target updates.
+
+    One-instance env + flat ring buffer: the reference's loop, op for op (pinned against the reference's weights by
+    tests/test_td3_golden_cpu.py).  Vectorised env (`env.num_envs`) + `VecReplayBuffer`: all lanes step in lock-step through
+    the HIP env kernel, transitions stay in HBM, and `update_net` runs target_step / num_envs * repeat_times optimizer steps
+    (the reference's "one gradient step per env step" counted per LOCK-STEP, not per lane), each replayed from HIP graphs
+    after the first eager ones.  Nets, losses and Adam are PyTorch-ROCm, as BASELINE.json's north_star prescribes for the
+    off-policy update."""
 
     def __init__(self, backend=None, device=None):
         super().__init__(backend, device)
         self.explore_noise = 0.1
         self.policy_noise = 0.2
         self.update_freq = 2
+        self.use_hip_graphs = True
+        self._graphs = None
+        self._obs = None
 
     def init(self, net_dim, state_dim, action_dim, if_per=False):
         assert not if_per, "prioritised replay is not on the residual-control path"
@@ -534,12 +543,21 @@ class AgentTD3(AgentBase):
         from copy import deepcopy
         self.cri = CriticTwin(net_dim, state_dim, action_dim).to(self.device)
         self.cri_target = deepcopy(self.cri)
-        self.cri_optimizer = torch.optim.Adam(self.cri.parameters(), lr=self.learning_rate)
         self.act = Actor(net_dim, state_dim, action_dim).to(self.device)
         self.act_target = deepcopy(self.act)
-        self.act_optimizer = torch.optim.Adam(self.act.parameters(), lr=self.learning_rate)
+        self._make_optimizers()
         self.criterion = torch.nn.SmoothL1Loss()
         self.get_obj_critic = self.get_obj_critic_raw
+
+    def _make_optimizers(self):
+        kw = dict(fused=True, capturable=True) if self.device.type == "cuda" else {}
+        self.cri_optimizer = torch.optim.Adam(self.cri.parameters(), lr=self.learning_rate, **kw)
+        self.act_optimizer = torch.optim.Adam(self.act.parameters(), lr=self.learning_rate, **kw)
+        self._graphs = None
+
+    def _prior_term(self, states):
+        """Prior-controller part of the env action (none for plain TD3)."""
+        return None
 
     def select_action(self, state, if_deterministic=False):
         states = torch.as_tensor(np.asarray(state)[None], dtype=torch.float32, device=self.device)
@@ -548,6 +566,43 @@ class AgentTD3(AgentBase):
             if not if_deterministic:
                 action = (action + torch.randn_like(action) * self.explore_noise).clamp(-1, 1)
         return action.cpu().numpy()
+
+    def _env_action(self, state, action):
+        """What a one-instance env receives for the stored `action` (the residual agents add the prior term)."""
+        return action
+
+    def explore_env(self, env, buffer, target_step, reward_scale, gamma):
+        if hasattr(env, "num_envs"):
+            return self.explore_vec_env(env, buffer, target_step, reward_scale, gamma)
+        for _ in range(target_step):   # agent.py:54-70, continuing from self.state
+            action = self.select_action(self.state)
+            next_s, reward, done, _ = env.step(self._env_action(self.state, action))
+            buffer.append_buffer(self.state, (reward * reward_scale, 0.0 if done else gamma, *action))
+            self.state = env.reset() if done else next_s
+        return target_step
+
+    def explore_vec_env(self, env, buffer, target_step, reward_scale, gamma):
+        """target_step transitions = target_step / N lock-steps of all N lanes, continuing the running episodes; finished
+        lanes are reset inside the env kernel and their next row holds the new episode's first observation."""
+        assert isinstance(buffer, VecReplayBuffer) and buffer.num_envs == env.num_envs
+        N = env.num_envs
+        steps = max(1, target_step // N)
+        if self._obs is None:
+            self._obs = env.reset().clone()
+            self._next_obs = torch.empty_like(self._obs)
+        for _ in range(steps):
+            obs = self._obs
+            with torch.no_grad():
+                a = self.act(obs)
+                a = (a + torch.randn_like(a) * self.explore_noise).clamp(-1, 1)   # agent.py:305
+                prior = self._prior_term(obs)
+                a_env = a if prior is None else a + prior
+            _, rew, done = env.step(a_env, auto_reset=True, out_obs=self._next_obs)
+            with torch.no_grad():
+                mask = (1.0 - done.to(torch.float32)) * gamma
+                buffer.append_step(obs, rew * reward_scale if reward_scale != 1.0 else rew, mask, a)
+            self._obs, self._next_obs = self._next_obs, self._obs
+        return steps * N
 
     def get_obj_critic_raw(self, buffer, batch_size):
         with torch.no_grad():
@@ -558,30 +613,69 @@ class AgentTD3(AgentBase):
         q1, q2 = self.cri.get_q1_q2(state, action)
         return self.criterion(q1, q_label) + self.criterion(q2, q_label), state
 
+    def _one_update(self, buffer, batch_size, soft):
+        obj_critic, state = self.get_obj_critic(buffer, batch_size)
+        self.cri_optimizer.zero_grad(set_to_none=False)
+        obj_critic.backward()
+        self.cri_optimizer.step()
+        if soft:
+            self.soft_update(self.cri_target, self.cri, self.soft_update_tau)
+        obj_actor = -self.cri_target(state, self.act(state)).mean()
+        self.act_optimizer.zero_grad(set_to_none=False)
+        obj_actor.backward()
+        self.act_optimizer.step()
+        if soft:
+            self.soft_update(self.act_target, self.act, self.soft_update_tau)
+        return obj_actor.detach(), obj_critic.detach()
+
     def update_net(self, buffer, target_step, batch_size, repeat_times):
         buffer.update_now_len_before_sample()
         dev = self.device
+        vec = isinstance(buffer, VecReplayBuffer)
+        n_steps = int(target_step * repeat_times) if not vec else max(1, int(target_step // buffer.num_envs * repeat_times))
         sums = torch.zeros(2, device=dev)
         obj_actor = obj_critic = torch.zeros((), device=dev)
-        n_steps = int(target_step * repeat_times)
+        graphs = self._graphs if (vec and self.use_hip_graphs and dev.type == "cuda") else None
+        key = (id(buffer), batch_size, buffer.stored_slots if vec else 0, buffer.next_slot if vec else 0)
         for i in range(n_steps):
-            obj_critic, state = self.get_obj_critic(buffer, batch_size)
-            self.cri_optimizer.zero_grad()
-            obj_critic.backward()
-            self.cri_optimizer.step()
-            if i % self.update_freq == 0:
-                self.soft_update(self.cri_target, self.cri, self.soft_update_tau)
-            obj_actor = -self.cri_target(state, self.act(state)).mean()
-            self.act_optimizer.zero_grad()
-            obj_actor.backward()
-            self.act_optimizer.step()
-            if i % self.update_freq == 0:
-                self.soft_update(self.act_target, self.act, self.soft_update_tau)
-            sums += torch.stack([obj_actor.detach(), obj_critic.detach()])
-        self._n_updates += int(target_step)
+            soft = i % self.update_freq == 0
+            if vec and self.use_hip_graphs and dev.type == "cuda" and i >= 2:
+                # the step's launch sequence is fixed once Adam's state exists: capture it twice (with / without the delayed
+                # soft update) and replay.  The sampler's index bounds are baked in, so the graphs live for this call only
+                # unless the ring is full and the cursor unchanged.
+                if graphs is None or graphs.get("key") != key:
+                    graphs = self._capture_updates(buffer, batch_size, key)
+                    self._graphs = graphs
+                if graphs:
+                    g = graphs[soft]
+                    g["graph"].replay()
+                    sums += g["out"]
+                    obj_actor, obj_critic = g["out"][0], g["out"][1]
+                    continue
+            obj_actor, obj_critic = self._one_update(buffer, batch_size, soft)
+            sums += torch.stack([obj_actor, obj_critic])
+        self._n_updates += int(target_step if not vec else n_steps)
         if n_steps:
             mean = (sums / n_steps).tolist()
             logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
             logger.record("train/actor_loss", mean[0])
             logger.record("train/critic_loss", mean[1])
-        return float(obj_actor.detach()), float(obj_critic.detach()) / 2
+        return float(obj_actor), float(obj_critic) / 2
+
+    def _capture_updates(self, buffer, batch_size, key):
+        out = {"key": key}
+        try:
+            torch.cuda.synchronize(self.device)
+            for soft in (True, False):
+                res = torch.zeros(2, device=self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    oa, oc = self._one_update(buffer, batch_size, soft)
+                    res.copy_(torch.stack([oa, oc]))
+                out[soft] = {"graph": g, "out": res}
+            return out
+        except RuntimeError as exc:   # keep training on eager launches
+            print(f"| HIP graph capture of the TD3 update failed ({exc}); continuing with eager launches")
+            self.use_hip_graphs = False
+            torch.cuda.synchronize(self.device)
+            return {}

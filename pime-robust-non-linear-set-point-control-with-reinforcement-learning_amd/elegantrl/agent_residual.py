@@ -5,7 +5,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .agent import AgentPPO
+from .agent import AgentPPO, AgentTD3
 from .net import CriticAdv
 from .net_residual import ActorResidualIntegratorModularPPO, ActorResidualPPO
 
@@ -59,3 +59,44 @@ class AgentResidualIntegratorModularPPO(AgentResidualPPO):
     def frozen_integrator(self):
         self.act.frozen_integrator()
         self.cri.frozen_transfer()
+
+
+class AgentResidualTD3(AgentTD3):
+    """Residual TD3: BASELINE.json names it, the reference does not have it (`train.py --algo TD3` crashes in
+    `init_actor_zero`).  Composed here from the reference's PIECES -- Actor (net.py:96-110), CriticTwin (:305-332), AgentTD3
+    (agent.py:276-341), the zero-initialised output layer (agent.py:569-574) and the prior gain priorK = -K
+    (agent_residual.py:15-24) -- the way AgentResidualPPO composes its own (agent_residual.py:61):
+
+        env action = clamp(tanh(pi_theta(s)) + explore noise, -1, 1) + s @ priorK        (evaluation: tanh(pi_theta(s)) + s @ priorK)
+
+    The replay buffer and the critics see the RESIDUAL action (before the prior term), as the PPO buffer does.
+    No reference oracle exists for the composition; the parts are pinned (tests/test_td3_golden_cpu.py, nets.npz)."""
+
+    def init_residual(self, residual_kwarg):
+        K = np.asarray(residual_kwarg["init_K"], dtype=np.float64)
+        self.priorK = -K
+        self.act.priorK = nn.Parameter(-torch.as_tensor(K, dtype=torch.float32, device=self.device), requires_grad=False)
+        self.act_target.priorK = nn.Parameter(self.act.priorK.detach().clone(), requires_grad=False)
+        self.init_actor_zero()
+
+    def fix_K(self):
+        self.act.priorK.requires_grad = False
+
+    def init_actor_zero(self):
+        """Zero the policy's output layer (and its target's): the initial policy is the prior controller alone."""
+        with torch.no_grad():
+            for net in (self.act, self.act_target):
+                net.net[-1].weight.fill_(0.)
+                net.net[-1].bias.fill_(0.)
+        self._make_optimizers()
+
+    def _prior_term(self, states):
+        return states @ self.act.priorK
+
+    def _env_action(self, state, action):
+        return action + state @ self.priorK
+
+    def eval_policy(self, states):
+        """Deterministic ENV action for evaluation (run.py:600-619 calls the policy on the observation): residual + prior.
+        `self.act(states)` alone is the residual action the critics are trained on."""
+        return self.act(states) + states @ self.act.priorK

@@ -6,6 +6,9 @@ mask, action[, noise]) and `sample_batch` relies on row i+1 being the successor 
 stays on the agent's device also for on-policy use (the reference forces host NumPy there and re-uploads the whole
 buffer every update, replay.py:265-266,353-367).
 
+`VecReplayBuffer` is the off-policy ring for N lock-stepped env lanes: time-major [L, N, .] in HBM; the successor of
+(slot t, lane n) is (slot t+1, lane n), i.e. flat row i + N where the reference uses i + 1 (replay.py:344-351).
+
 `TrajectoryBuffer` is the vectorised-rollout store: time-major [T, N, .] tensors resident in HBM that the env
 step kernel and the policy write into directly; lane n of slot t is the transition env n made at its step t.
 """
@@ -110,3 +113,75 @@ class TrajectoryBuffer:
         T = self.length
         flat = lambda x: x[:T].reshape(T * self.num_envs, *x.shape[2:])  # noqa: E731
         return flat(self.reward), flat(self.mask), flat(self.action), flat(self.noise), flat(self.state)
+
+
+class VecReplayBuffer:
+    """Off-policy ring buffer for N lock-stepped env lanes, resident on the device.
+
+    Slot t holds what every lane did at its t-th stored step: state [L, N, D], other [L, N, 2 + A] = (reward * scale, mask,
+    action).  The flat views `buf_state` [L * N, D] / `buf_other` keep the reference's row semantics with one change: the
+    successor of row i is row i + N (same lane, next slot), not i + 1 (replay.py:350: `self.buf_state[indices + 1]` relies on one
+    env filling the ring in time order).  A lane that ended an episode at slot t has mask 0 there and the first observation
+    of its next episode at slot t + 1, exactly as the reference stores `env.reset()` in the next row.
+
+    `sample_batch` draws (slot, lane) uniformly over the stored slots THAT HAVE a successor: the newest slot is excluded --
+    when the ring is full its "successor" would be the oldest slot (the reference samples that row too, replay.py:345 draws
+    from now_len - 1 rows regardless of where the write cursor is; a documented deviation, 1 / L of the rows)."""
+
+    def __init__(self, max_len, num_envs, state_dim, action_dim, device):
+        self.device = torch.device(device)
+        self.num_envs, self.state_dim, self.action_dim = int(num_envs), int(state_dim), int(action_dim)
+        self.slots = max(2, -(-int(max_len) // self.num_envs))
+        self.max_len = self.slots * self.num_envs
+        f = dict(dtype=torch.float32, device=self.device)
+        self.state = torch.zeros((self.slots, self.num_envs, self.state_dim), **f)
+        self.other = torch.zeros((self.slots, self.num_envs, 2 + self.action_dim), **f)
+        self.buf_state = self.state.view(self.max_len, self.state_dim)
+        self.buf_other = self.other.view(self.max_len, 2 + self.action_dim)
+        self.next_slot = 0
+        self.if_full = False
+        self.now_len = 0
+        self.if_on_policy = False
+
+    @property
+    def stored_slots(self):
+        return self.slots if self.if_full else self.next_slot
+
+    def append_step(self, state, reward, mask, action):
+        """One lock-step of every lane: state [N, D], reward / mask [N], action [N, A] (device tensors)."""
+        t = self.next_slot
+        self.state[t].copy_(state)
+        o = self.other[t]
+        o[:, 0].copy_(reward)
+        o[:, 1].copy_(mask)
+        o[:, 2:].copy_(action.reshape(self.num_envs, self.action_dim))
+        self.next_slot += 1
+        if self.next_slot >= self.slots:
+            self.next_slot, self.if_full = 0, True
+
+    def update_now_len_before_sample(self):
+        self.now_len = self.stored_slots * self.num_envs
+
+    def sample_indices(self, batch_size, out=None):
+        """Flat row indices [batch] of transitions with a valid successor, and their successors' indices."""
+        n_slots = self.stored_slots
+        assert n_slots >= 2, "need two stored steps before sampling"
+        N = self.num_envs
+        u = torch.randint((n_slots - 1) * N, size=(batch_size,), device=self.device) if out is None else \
+            torch.randint((n_slots - 1) * N, size=(batch_size,), device=self.device, out=out)
+        if self.if_full:   # slots in age order start at the write cursor (the oldest); the newest (cursor - 1) is excluded
+            slot = (u // N + self.next_slot) % self.slots
+            idx = slot * N + u % N
+            nxt = ((slot + 1) % self.slots) * N + u % N
+        else:
+            idx, nxt = u, u + N
+        return idx, nxt
+
+    def sample_batch(self, batch_size):
+        """(reward, mask, action, state, next_state), shapes as ReplayBuffer.sample_batch."""
+        idx, nxt = self.sample_indices(batch_size)
+        r_m_a = self.buf_other[idx]
+        return r_m_a[:, 0:1], r_m_a[:, 1:2], r_m_a[:, 2:], self.buf_state[idx], self.buf_state[nxt]
+
+    def empty_buffer_before_explore(self):
+        self.next_slot, self.if_full, self.now_len = 0, False, 0

@@ -14,7 +14,7 @@ import torch
 
 from . import logger
 from .env import PreprocessEnv
-from .replay import ReplayBuffer, TrajectoryBuffer
+from .replay import ReplayBuffer, TrajectoryBuffer, VecReplayBuffer
 
 
 class Arguments:
@@ -94,6 +94,8 @@ def make_buffer(agent, env, max_memo, if_per=False):
         per_episode = env.num_envs * env.max_step
         episodes = max(1, -(-max_memo // per_episode))
         return TrajectoryBuffer(episodes * env.max_step, env.num_envs, env.state_dim, env.action_dim, agent.device)
+    if hasattr(env, "num_envs"):   # off-policy agent on a vectorised env: the per-lane device ring
+        return VecReplayBuffer(max_memo, env.num_envs, env.state_dim, env.action_dim, agent.device)
     return ReplayBuffer(max_len=max_memo + env.max_step, state_dim=env.state_dim,
                         action_dim=1 if env.if_discrete else env.action_dim, if_on_policy=on_policy, if_per=if_per,
                         if_gpu=True, device=agent.device)
@@ -198,6 +200,12 @@ class Evaluator:
         if is_main:
             print(f"{'ID':>2}  {'Step':>8}  {'MaxR':>8} |{'avgR':>8}  {'stdR':>8}   {'objA':>8}  {'objC':>8} |")
 
+    @staticmethod
+    def _policy(agent):
+        """What maps an observation to the deterministic env action: the actor module itself (its forward adds the prior term
+        for the residual PPO actors), or the agent's `eval_policy` where the actor's forward is the residual action alone."""
+        return getattr(agent, "eval_policy", None) or agent.act
+
     def _returns(self, act, times):
         if hasattr(self.env, "num_envs"):  # one launch sequence evaluates num_envs episodes at once
             r = []
@@ -209,7 +217,7 @@ class Evaluator:
     def evaluate_act(self, agent):
         if self.eval_times1 == 0:
             return False
-        r = self._returns(agent.act, self.eval_times1)
+        r = self._returns(self._policy(agent), self.eval_times1)
         r_avg, r_std = float(r.mean()), float(r.std())
         if r_avg > self.r_max:
             self.r_max = r_avg
@@ -231,9 +239,9 @@ class Evaluator:
         self.total_step += steps
         if_reach_goal = False
         if self.eval_func_time % self.eval_gap == 0:
-            r = self._returns(agent.act, self.eval_times1)
+            r = self._returns(self._policy(agent), self.eval_times1)
             if r.mean() > self.r_max:  # confirm a new best with more episodes before saving
-                r = np.concatenate([r, self._returns(agent.act, max(self.eval_times2 - self.eval_times1, 0))]) \
+                r = np.concatenate([r, self._returns(self._policy(agent), max(self.eval_times2 - self.eval_times1, 0))]) \
                     if self.eval_times2 > self.eval_times1 else r
             r_avg, r_std = float(r.mean()), float(r.std())
             if r_avg > self.r_max:

@@ -535,13 +535,43 @@ def _ppo_cases(out, cases, with_eval):
         out[f"{tag}:eval"] = np.array([ret, n])
 
 
+def golden_td3_update():
+    """AgentTD3.update_net of the reference (elegantrl/agent.py:276-341: twin critics, target policy smoothing, delayed soft
+    updates) on a flat ring buffer of random transitions, CPU, torch seeded right before the call: weights of actor / critic /
+    both targets before and after 6 update steps, and the returned losses.  The reference has no residual TD3 (SURVEY.md
+    fact 5); this pins the TD3 pieces the build composes one from."""
+    from elegantrl.agent import AgentTD3
+    from elegantrl.replay import ReplayBuffer
+    out = {}
+    torch.manual_seed(21)
+    agent = AgentTD3()
+    agent.init(64, 4, 1)
+    rng = np.random.RandomState(4)
+    n = 500
+    buf = ReplayBuffer(max_len=n + 8, state_dim=4, action_dim=1, if_on_policy=False, if_per=False, if_gpu=True)
+    state = (rng.rand(n, 4) * np.array([10., 10., 10., 50.]) - np.array([0., 0., 0., 25.])).astype(np.float32)
+    other = np.stack([-rng.rand(n) * 5, np.where(rng.rand(n) < 0.02, 0.0, 0.99), np.tanh(rng.randn(n))], axis=1).astype(np.float32)
+    buf.extend_buffer(torch.as_tensor(state), torch.as_tensor(other))
+    for tag, net in (("act0", agent.act), ("cri0", agent.cri)):
+        out.update(_sd_to_np(f"td3:{tag}", net.state_dict()))
+    torch.manual_seed(77)
+    obj_a, obj_c = agent.update_net(buf, 3, 64, 2)
+    for tag, net in (("act1", agent.act), ("cri1", agent.cri), ("act_target1", agent.act_target), ("cri_target1", agent.cri_target)):
+        out.update(_sd_to_np(f"td3:{tag}", net.state_dict()))
+    out["td3:state"], out["td3:other"] = state, other
+    out["td3:obj"] = np.array([obj_a, obj_c])
+    out["td3:hyper"] = np.array([64, 3, 64, 2, agent.learning_rate, agent.soft_update_tau, agent.explore_noise, agent.policy_noise,
+                                 agent.update_freq])
+    save("td3_update.npz", **out)
+
+
 def main():
     only = set(sys.argv[1:])
     jobs = dict(ph_table=golden_ph_table, ph_zoh=golden_ph_zoh, ph_rollouts=golden_ph_rollouts,
                 ph_stepresponse=golden_ph_stepresponse, wt_rollouts=golden_wt_rollouts,
                 wt_stepresponse=golden_wt_stepresponse, wt_stacking=golden_wt_stacking,
                 gae=golden_gae, nets=golden_nets, ppo_update=golden_ppo_update_and_explore,
-                ppo_update_wide=golden_ppo_update_wide)
+                ppo_update_wide=golden_ppo_update_wide, td3_update=golden_td3_update)
     for name, fn in jobs.items():
         if only and name not in only:
             continue

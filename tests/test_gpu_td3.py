@@ -1,0 +1,97 @@
+"""The vectorised off-policy path on the GPU: the TD3 nets against the reference's own outputs
+(tests/golden/nets.npz: CriticTwin `twin4:q1/q2`, Actor `actor4:forward`), the per-lane device ring, and the residual-TD3
+agent on the HIP water-tank env with its update replayed from HIP graphs.  The update arithmetic itself is pinned against
+the reference's weights on the CPU (tests/test_td3_golden_cpu.py); nets / losses / Adam are PyTorch-ROCm here by design
+(BASELINE.json north_star: "the residual actor-critic update ... and the replay sampler stay on-device in PyTorch-ROCm")."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _sd_nets(g, tag):
+    return {k[len(tag) + 1:]: torch.from_numpy(g[k].copy()).to(DEV) for k in g.files if k.startswith(tag + ".")}
+
+
+def test_td3_nets_reproduce_reference_outputs_on_gpu():
+    from pime_amd.elegantrl.net import Actor, CriticTwin
+    g = load_golden("nets.npz")
+    x4, a1 = torch.from_numpy(g["x4"]).to(DEV), torch.from_numpy(g["a1"]).to(DEV)
+    twin = CriticTwin(32, 4, 1).to(DEV)
+    twin.load_state_dict(_sd_nets(g, "twin4"), strict=True)
+    det = Actor(32, 4, 1).to(DEV)
+    det.load_state_dict(_sd_nets(g, "actor4"), strict=True)
+    with torch.no_grad():
+        q1, q2 = twin.get_q1_q2(x4, a1)
+        np.testing.assert_allclose(q1.cpu().numpy(), g["twin4:q1"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(q2.cpu().numpy(), g["twin4:q2"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(det(x4).cpu().numpy(), g["actor4:forward"], rtol=1e-5, atol=1e-5)
+
+
+def test_td3_update_matches_reference_on_gpu():
+    """The reference's update_net golden through the GPU modules: the sampled rows and the smoothing noise come from torch's
+    CPU generator in the golden and from the device generator here, so rows / noise are injected instead of seeded."""
+    from pime_amd.elegantrl.agent import AgentTD3
+    from pime_amd.elegantrl.replay import ReplayBuffer
+    g = load_golden("td3_update.npz")
+    net_dim, target_step, batch, repeat = (int(v) for v in g["td3:hyper"][:4])
+    ag = AgentTD3(device=DEV)
+    ag.init(net_dim, 4, 1)
+    for net, tag in ((ag.act, "act0"), (ag.cri, "cri0"), (ag.act_target, "act0"), (ag.cri_target, "cri0")):
+        net.load_state_dict({k[len("td3:" + tag) + 1:]: torch.from_numpy(g[k].copy()).to(DEV) for k in g.files
+                             if k.startswith(f"td3:{tag}.")})
+    buf = ReplayBuffer(len(g["td3:state"]) + 8, 4, 1, if_on_policy=False, device=DEV)
+    buf.extend_buffer(g["td3:state"], g["td3:other"])
+    # replay the CPU generator's draws: sample_batch's randint, then get_action's randn_like, per update step
+    cpu_gen = torch.Generator().manual_seed(77)
+    orig_randint, orig_randn_like = torch.randint, torch.randn_like
+    torch.randint = lambda high, size, device=None, **k: orig_randint(high, size, generator=cpu_gen).to(DEV)
+    torch.randn_like = lambda t, **k: torch.randn(t.shape, generator=cpu_gen).to(DEV)
+    try:
+        obj_a, obj_c = ag.update_net(buf, target_step, batch, repeat)
+    finally:
+        torch.randint, torch.randn_like = orig_randint, orig_randn_like
+    for tag, net in (("act1", ag.act), ("cri1", ag.cri), ("act_target1", ag.act_target), ("cri_target1", ag.cri_target)):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), g[f"td3:{tag}.{k}"], rtol=0, atol=1e-5, err_msg=f"{tag}.{k}")
+    np.testing.assert_allclose([obj_a, obj_c], g["td3:obj"], rtol=1e-3, atol=1e-5)
+
+
+def test_residual_td3_on_the_hip_env_with_graph_replay():
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.agent_residual import AgentResidualTD3
+    from pime_amd.elegantrl.replay import VecReplayBuffer
+    from pime_amd.elegantrl.run import get_episode_return_vec, make_buffer
+    N = 1024
+    env = gym_control.make_vec(gym_control.WT_INTEGRATOR, N, device=DEV, seed=5, reward_type="distance", max_step=50)
+    torch.manual_seed(0)
+    ag = AgentResidualTD3(device=DEV)
+    ag.init(128, env.state_dim, 1)
+    ag.init_residual({"init_K": env.K.reshape(-1, 1)})
+    buf = make_buffer(ag, env, 2 ** 17)
+    assert isinstance(buf, VecReplayBuffer)
+    r0 = get_episode_return_vec(env, ag.eval_policy).mean()       # the prior P controller alone
+    ag._obs = None
+    steps = ag.explore_env(env, buf, 60 * N, 1.0, 0.99)
+    assert steps == 60 * N and buf.stored_slots == 60
+    done_rows = (buf.other[:60, :, 1] == 0).sum().item()
+    assert done_rows == N            # 60 lock-steps of 50-step episodes: every lane finished exactly one
+    w0 = torch.cat([p.detach().reshape(-1) for p in ag.act.parameters()]).clone()
+    oa, oc = ag.update_net(buf, 60 * N, 512, 1)                   # 60 optimizer steps: 2 eager, capture, 58 replays
+    torch.cuda.synchronize()
+    assert ag._graphs and True in ag._graphs and False in ag._graphs, "the TD3 update was not captured into HIP graphs"
+    assert np.isfinite(oa) and np.isfinite(oc)
+    w1 = torch.cat([p.detach().reshape(-1) for p in ag.act.parameters()])
+    assert torch.isfinite(w1).all() and not torch.equal(w0, w1)
+    # a few more rounds: the residual must not destroy the prior controller's return (sanity of the composed agent)
+    for _ in range(6):
+        ag.explore_env(env, buf, 50 * N, 1.0, 0.99)
+        ag.update_net(buf, 50 * N, 512, 1)
+    ag._obs = None
+    r1 = get_episode_return_vec(env, ag.eval_policy).mean()
+    assert np.isfinite(r1) and r1 > 2.0 * r0, f"return collapsed: prior {r0:.1f} -> {r1:.1f}"   # returns are negative
+    env.close()
