@@ -49,6 +49,8 @@ class DataParallel:
         self.rank, self.world, self.local_rank = rank, world, local_rank
         self.device = device
         self._flat = None
+        # RCCL collectives are kernels on the current stream and can be captured into a HIP graph; gloo's are host calls
+        self.graph_capturable = td.is_initialized() and td.get_backend() == "nccl"
 
     def lane_offset(self, lanes_per_rank):
         """Global id of this rank's lane 0 (the env kernels' Philox counter word / Mt19937 seed offset)."""

@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage: tools/gpu_profiles.sh <tag>  -- the round's evidence: bench lines, rocprofv3 kernel stats, PMC traffic, env PMC sweep
+TAG=$1; OUT=gpurun_out; mkdir -p $OUT
+timeout -k 10 200 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+tail -c 200 $OUT/${TAG}_bench.json
+PIME_FORCE_DP=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 timeout -k 10 200 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_dp.json 2> $OUT/${TAG}_bench_dp.err || exit 1
+python -c "import json,sys; d=json.loads(open('$OUT/${TAG}_bench_dp.json').read().strip().splitlines()[-1]); print('forced-DP (1 rank):', d['value'])"
+grep -i "refused\|graph" $OUT/${TAG}_bench_dp.err | head -3
+timeout -k 10 200 python bench.py --workload wt --no-cpu-baseline > $OUT/${TAG}_bench_water_tank.json 2>/dev/null || exit 1
+timeout -k 10 300 bash tools/profile_bench.sh $TAG || exit 1
+timeout -k 10 400 bash tools/pmc_traffic.sh $OUT/${TAG}_pmc_hbm_traffic.json bench.py --steps 2 --warmup 1 --no-cpu-baseline || exit 1
+timeout -k 10 400 bash tools/env_pmc.sh $OUT/${TAG}_env_pmc.json || exit 1
