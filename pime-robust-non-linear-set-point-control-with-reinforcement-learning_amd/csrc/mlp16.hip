@@ -524,6 +524,7 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const region = lds + S.region;
     double* const wsum = reinterpret_cast<double*>(lds + S.wsum);   // [wave][6]
+    const float asl = ACTOR ? a.a_std_log[0] : 0.f;
     stage_small16<T>(lds, S, a.img_fwd, L, tid);
     if (tid < k16Waves * 6) wsum[tid] = 0.0;
     __syncthreads();
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
                 dout = gl * invB;   // unscaled: the slab reduction applies 1/(std+1e-5) (agent.py:652)
                 if (g == 0) { s0 = l; m1 = (double)in_rsum; m2 = (double)in_rsum * (double)in_rsum; }
             } else {
-                const float asl = a.a_std_log[0], inv_sigma = __expf(-asl);
+                const float inv_sigma = __expf(-asl);   // asl: loaded at kernel entry
                 const float z = (y - in_action) * inv_sigma;
                 const float logp = -(asl + kLogSqrt2Pi + 0.5f * z * z);           // compute_logprob
                 const float ratio = __expf(logp - in_logprob);
@@ -595,11 +596,13 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
         }
         {
             float ghb = g == 0 ? dout : 0.f;   // head bias gradient
-            s0 = wave_sum(s0); s1 = wave_sum(s1); gstd = wave_sum(gstd); ghb = wave_sum(ghb);
+            s0 = wave_total_dpp(s0); ghb = wave_total_dpp(ghb);   // totals valid in lane 63
             if constexpr (!ACTOR) {
                 for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+            } else {
+                s1 = wave_total_dpp(s1); gstd = wave_total_dpp(gstd);
             }
-            if (lane == 0) {
+            if (lane == 63) {
                 double* w = wsum + wave * 6;
                 w[0] += s0; w[1] += s1; w[2] += gstd; w[3] += ghb; w[4] += m1; w[5] += m2;
             }

@@ -132,28 +132,27 @@ __device__ inline void pack_forward_image(const PackArgs& a, float* __restrict__
 // Copy a packed image (n4 float4s) from HBM/L2 into LDS with every load of a batch in flight before the first LDS
 // write.  The naive `dst[i] = src[i]` loop compiles to load -> wait -> ds_write per iteration, i.e. 16 exposed L2
 // round trips (~16 us) for a 131 KB image with 512 threads; batching 8 loads per thread leaves two.
+template <int K>
+__device__ __forceinline__ void stage_batches(float4* __restrict__ dst, const float4* __restrict__ src, int n4, int nthr, int& i) {
+    for (; i + (K - 1) * nthr < n4; i += nthr * K) {   // full batches only: no guards, v[] stays in registers
+        float4 v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = src[i + k * nthr];
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[i + k * nthr] = v[k];
+    }
+}
 __device__ __forceinline__ void stage_image(float* __restrict__ lds, const float* __restrict__ image, int n4) {
-    constexpr int kBatch = 8;
     const float4* src = reinterpret_cast<const float4*>(image);
     float4* dst = reinterpret_cast<float4*>(lds);
     const int nthr = blockDim.x;
     int i = threadIdx.x;
-    for (; i + (kBatch - 1) * nthr < n4; i += nthr * kBatch) {  // full batches: no guards, v[] stays in registers
-        float4 v[kBatch];
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) v[k] = src[i + k * nthr];
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) dst[i + k * nthr] = v[k];
-    }
-    if (i < n4) {  // last, partial batch: same idea with guards (a plain loop would expose one round trip per element)
-        float4 v[kBatch];
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k)
-            if (i + k * nthr < n4) v[k] = src[i + k * nthr];
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k)
-            if (i + k * nthr < n4) dst[i + k * nthr] = v[k];
-    }
+    // batches of 8, then the remainder in batches of 4 / 2 / 1 (a guarded partial batch of 8 made hipcc keep v[] on the stack:
+    // 144 B of scratch per lane in every kernel that stages an image, and scratch reloads wait on the shared vmcnt counter)
+    stage_batches<8>(dst, src, n4, nthr, i);
+    stage_batches<4>(dst, src, n4, nthr, i);
+    stage_batches<2>(dst, src, n4, nthr, i);
+    stage_batches<1>(dst, src, n4, nthr, i);
 }
 
 // tanh for the hidden layers in 7 VALU ops, two of them transcendental (ocml's tanhf inlined 64x per layer drove the

@@ -101,6 +101,21 @@ __device__ __forceinline__ void head_backward(const float* __restrict__ w, int l
         for (int r = 0; r < 16; ++r) d[t][r] = w[(t * 16 + r) * 2 + h] * dout;
 }
 
+// Sum over the 64 lanes on the DPP path (6 VALU ops, no LDS crossbar); the total is valid in LANE 63 only.
+// (__shfl_xor compiles to ds_bpermute: six dependent LDS-pipe round trips per sum, ~0.5 us per sum and wave.)
+__device__ __forceinline__ float wave_total_dpp(float v) {
+#define PIME_DPP_ADD(x, ctrl, row_mask) \
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, row_mask, 0xf, true))
+    PIME_DPP_ADD(v, 0x111, 0xf);  // row_shr:1
+    PIME_DPP_ADD(v, 0x112, 0xf);  // row_shr:2
+    PIME_DPP_ADD(v, 0x114, 0xf);  // row_shr:4
+    PIME_DPP_ADD(v, 0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds the row sum
+    PIME_DPP_ADD(v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the half sums
+    PIME_DPP_ADD(v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef PIME_DPP_ADD
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

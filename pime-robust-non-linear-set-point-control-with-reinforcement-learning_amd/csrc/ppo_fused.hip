@@ -486,40 +486,44 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     const int Do = a.D - a.Di;
 
     PIME_MARK(0);
+    const float asl = CRITIC ? 0.f : a.a_std_log[0];
     for (int e = tid; e < kFusedWaves * md; e += kFusedThreads) hacc[e] = 0.f;
     // small segments live in LDS for the whole kernel.  All their loads are issued before the first LDS write: one
-    // L2 round trip instead of one per segment (7 segments cost the modular actor 10 us).
+    // L2 round trip instead of one per segment (7 segments cost the modular actor 10 us).  Named registers, not an array:
+    // hipcc put a float4 v[NS] on the stack (144 B of scratch per lane; every reload waits on the shared vmcnt counter).
     {
-        constexpr int NS = MODULAR ? 7 : 5;
-        const float* src[NS];
-        float* dst[NS];
-        int n4[NS];
-        auto seg = [&](int k, int ldsoff, int imgoff, int floats) { dst[k] = lds + ldsoff; src[k] = a.img_fwd + imgoff; n4[k] = floats / 4; };
+#define PIME_SEG_LOAD(k, imgoff, floats)                                                       \
+    const int n4_##k = (floats) / 4;                                                            \
+    const float4* src_##k = reinterpret_cast<const float4*>(a.img_fwd + (imgoff));              \
+    float4 v_##k = make_float4(0.f, 0.f, 0.f, 0.f);                                             \
+    if (tid < n4_##k) v_##k = src_##k[tid];
+#define PIME_SEG_STORE(k, ldsoff)                                                               \
+    {                                                                                           \
+        float4* dst_ = reinterpret_cast<float4*>(lds + (ldsoff));                               \
+        if (tid < n4_##k) dst_[tid] = v_##k;                                                    \
+        for (int i = tid + kFusedThreads; i < n4_##k; i += kFusedThreads) dst_[i] = src_##k[i]; /* wide first layers only */ \
+    }
         if constexpr (MODULAR) {
-            seg(0, F.first0, L.off[0], md * (Do + 1));
-            seg(1, F.first1, L.off[3], md * (a.Di + 1));
-            seg(2, F.bias[0], L.off[2], H * 32);
-            seg(3, F.bias[1], L.off[5], H * 32);
-            seg(4, F.bias[2], L.off[7], md);
-            seg(5, F.headw, L.off[8], md);
-            seg(6, F.headb, L.off[9], 4);
+            PIME_SEG_LOAD(0, L.off[0], md * (Do + 1))
+            PIME_SEG_LOAD(1, L.off[3], md * (a.Di + 1))
+            PIME_SEG_LOAD(2, L.off[2], H * 32)
+            PIME_SEG_LOAD(3, L.off[5], H * 32)
+            PIME_SEG_LOAD(4, L.off[7], md)
+            PIME_SEG_LOAD(5, L.off[8], md)
+            PIME_SEG_LOAD(6, L.off[9], 4)
+            PIME_SEG_STORE(0, F.first0) PIME_SEG_STORE(1, F.first1) PIME_SEG_STORE(2, F.bias[0]) PIME_SEG_STORE(3, F.bias[1])
+            PIME_SEG_STORE(4, F.bias[2]) PIME_SEG_STORE(5, F.headw) PIME_SEG_STORE(6, F.headb)
         } else {
-            seg(0, F.first0, L.off[0], md * (a.D + 1));
-            seg(1, F.bias[0], L.off[2], md);
-            seg(2, F.bias[1], L.off[4], md);
-            seg(3, F.headw, L.off[5], md);
-            seg(4, F.headb, L.off[6], 4);
+            PIME_SEG_LOAD(0, L.off[0], md * (a.D + 1))
+            PIME_SEG_LOAD(1, L.off[2], md)
+            PIME_SEG_LOAD(2, L.off[4], md)
+            PIME_SEG_LOAD(3, L.off[5], md)
+            PIME_SEG_LOAD(4, L.off[6], 4)
+            PIME_SEG_STORE(0, F.first0) PIME_SEG_STORE(1, F.bias[0]) PIME_SEG_STORE(2, F.bias[1]) PIME_SEG_STORE(3, F.headw)
+            PIME_SEG_STORE(4, F.headb)
         }
-        float4 v[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-            if (tid < n4[k]) v[k] = reinterpret_cast<const float4*>(src[k])[tid];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            if (tid < n4[k]) reinterpret_cast<float4*>(dst[k])[tid] = v[k];
-            for (int i = tid + kFusedThreads; i < n4[k]; i += kFusedThreads)   // wide first layers only
-                reinterpret_cast<float4*>(dst[k])[i] = reinterpret_cast<const float4*>(src[k])[i];
-        }
+#undef PIME_SEG_LOAD
+#undef PIME_SEG_STORE
     }
     // scalar sums (losses, d/d a_std_log, head bias gradient, target moments): reduced over the wave right where they
     // are produced and kept in LDS, not in loop-carried registers (which hipcc spills around the MFMA phases)
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                     m2 = (double)in_rsum * (double)in_rsum;
                 }
             } else {
-                const float asl = a.a_std_log[0], inv_sigma = __expf(-asl);
+                const float inv_sigma = __expf(-asl);   // asl = a_std_log, loaded at kernel entry (an L2 round trip here is exposed)
                 const float z = (y - in_action) * inv_sigma;
                 const float logp = -(asl + kLogSqrt2Pi + 0.5f * z * z);           // compute_logprob
                 const float ratio = __expf(logp - in_logprob);
@@ -651,33 +655,35 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
         }
         {
             float ghb = h == 0 ? dout : 0.f;   // head bias gradient
-            s0 = wave_sum(s0); s1 = wave_sum(s1); gstd = wave_sum(gstd); ghb = wave_sum(ghb);
+            s0 = wave_total_dpp(s0); ghb = wave_total_dpp(ghb);   // totals valid in lane 63
             if constexpr (CRITIC) {
                 for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+            } else {
+                s1 = wave_total_dpp(s1); gstd = wave_total_dpp(gstd);
             }
-            if (lane == 0) {
+            if (lane == 63) {
                 double* w = wsum + wave * 6;
                 w[0] += s0; w[1] += s1; w[2] += gstd; w[3] += ghb; w[4] += m1; w[5] += m2;
             }
         }
         // Head: dZ of the last hidden layer, and the head weight gradient gW[f] += sum_s dOut[s] * H_last[s][f].  H_last
         // is still in registers; the sum over the tile's samples is a DPP reduction over the lanes.
-        {
-            f32x16 dl[T];
-            head_backward<T>(lds + F.headw, lane, dout, dl);
-            times_act_grad<T, ACT>(dl, hl);
+        {   // one 32-feature tile at a time: 16 live temporaries instead of a whole T-tile dl (the actor kernel sits at the
+            // 256-VGPR cap; spill reloads here queue behind the 64 stash stores just issued on the same vmcnt counter)
+            const float* hw = lds + F.headw + h;
 #pragma unroll
-            for (int t = 0; t < T; ++t)
+            for (int t = 0; t < T; ++t) {
+                PIME_NO_HOIST();
+                f32x16 dl;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hl[t][r] = half_sum_dpp(dout * hl[t][r]);
-            if (li == 31) {   // this wave's own slots: no atomics, the sums stay reproducible
-#pragma unroll
-                for (int t = 0; t < T; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) hacc[wave * md + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] += hl[t][r];
+                for (int r = 0; r < 16; ++r) {
+                    const float hv = hl[t][r];
+                    dl[r] = hw[(t * 16 + r) * 2] * dout * act_grad_from_output<ACT>(hv);   // head_backward . act'
+                    const float hs = half_sum_dpp(dout * hv);
+                    if (li == 31) hacc[wave * md + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] += hs;   // own slots: reproducible
+                }
+                hl[t] = dl;
             }
-#pragma unroll
-            for (int t = 0; t < T; ++t) hl[t] = dl[t];
         }
         // ---------------------------------------------------------------------------------- backward + weight gradients
         __syncthreads();  // forward images dead, stash visible to the whole workgroup
