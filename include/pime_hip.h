@@ -252,6 +252,25 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
                             float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
                             float* loss_sums, pime_stream stream);
 
+/* The same call with the optimizer step fused into its last launch (the slab reduction): gradients of the minibatch, then
+ * torch.optim.Adam's update of every parameter (pime_adam_step semantics) -- one launch and one launch boundary less per
+ * optimizer step.  replaces agent.py:632-657 (gather ... backward ... optimizer.step()).  param / grad are the two flat tensors
+ * every pime_ppo_net params / grads pointer is a view into, at equal offsets; gradients of parameters outside them (frozen ones
+ * routed to a scratch tensor) are left without an update.  Not available when a net takes the split pipeline (PIME_ERR_ARG);
+ * data-parallel callers, who all-reduce the gradients first, use pime_ppo_minibatch_grad + pime_adam_step. */
+typedef struct pime_adam {
+    float* param;       /* [dev] float32[n] */
+    float* grad;        /* [dev] float32[n] */
+    float* exp_avg;     /* [dev] float32[n] */
+    float* exp_avg_sq;  /* [dev] float32[n] */
+    float* step;        /* [dev] float32[2], as pime_adam_step */
+    int64_t n;
+    float lr, beta1, beta2, eps;
+} pime_adam;
+int pime_ppo_minibatch_step(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* batch,
+                            float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
+                            float* loss_sums, const pime_adam* opt, pime_stream stream);
+
 /* -- fused rollout ---------------------------------------------------------------------------------------------
  * replaces: the whole per-step loop of AgentResidual*.explore_env for one episode chunk (elegantrl/agent_residual.py:
  * 52-69: select_action -> env.step(np.tanh(action) + state @ priorK) -> buffer.append_buffer), as ONE launch: policy

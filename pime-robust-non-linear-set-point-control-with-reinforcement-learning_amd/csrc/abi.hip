@@ -45,8 +45,13 @@ int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
 int64_t fused_stash_floats(int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
+struct ReduceAdam {   // ppo_fused.hip
+    float *flat_grad, *flat_param, *exp_avg, *exp_avg_sq, *step;
+    long long n;
+    float lr, b1, b2, eps;
+};
 int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, bool, bool, bool, bool, int, int, float* const*,
-                       float* const*, float*, float*, double*, float*, int, int64_t*, hipStream_t);
+                       float* const*, float*, float*, double*, float*, int, int64_t*, const ReduceAdam*, hipStream_t);
 int fused_grid(int);
 // mlp16.hip: the streamed 16x16x4 family (width 256; widths 64 / 128 under PIME_MLP16=1)
 bool family16(int, int);
@@ -661,9 +666,9 @@ int pime_ppo_repack(const pime_ppo_net* actor, const pime_ppo_net* critic, pime_
     return PIME_OK;
 }
 
-int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b,
-                            float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
-                            float* loss_sums, pime_stream stream) {
+static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b, float ratio_clip,
+                          float lambda_entropy, float* critic_scale, double* moments, float* loss_sums, const pime_adam* opt,
+                          pime_stream stream) {
     if (int rc = check_net(actor, true)) return rc;
     if (int rc = check_net(critic, false)) return rc;
     PIME_REQUIRE(b && b->state && b->action && b->logprob && b->adv && b->r_sum && b->indices && b->B >= 1,
@@ -687,6 +692,15 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         else mode[k] = (force_split || !fused_fits(n->kind, n->D, n->Di, n->md)) ? SPLIT : FUSED;
     }
     const bool any_split = mode[0] == SPLIT || mode[1] == SPLIT, any_slab = mode[0] != SPLIT || mode[1] != SPLIT;
+    ReduceAdam adam{};
+    if (opt) {
+        PIME_REQUIRE(!any_split, "pime_ppo_minibatch_step: the optimizer step is fused into the slab reduction, which these nets "
+                     "do not use (split pipeline): call pime_ppo_minibatch_grad + pime_adam_step");
+        PIME_REQUIRE(opt->param && opt->grad && opt->exp_avg && opt->exp_avg_sq && opt->step && opt->n >= 1,
+                     "pime_ppo_minibatch_step: bad pime_adam");
+        adam = ReduceAdam{opt->grad, opt->param, opt->exp_avg, opt->exp_avg_sq, opt->step, (long long)opt->n, opt->lr, opt->beta1,
+                          opt->beta2, opt->eps};
+    }
     static const bool tracing = std::getenv("PIME_FUSED_TRACE") != nullptr;  // tuning aid: phase marks of one workgroup
     static long long* trace_dev = nullptr;
     if (tracing && !trace_dev) {
@@ -765,13 +779,27 @@ int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* criti
         if (int rc = launch_grad_reduce(slab_args[0], slab_args[1], critic->kind, critic->md, actor->kind, actor->md,
                                         mode[0] == F16, mode[1] == F16, mode[0] != SPLIT, mode[1] != SPLIT, nslabs[0], nslabs[1],
                                         critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, loss_sums + 3,
-                                        b->flags & PIME_PPO_OVERWRITE_GRADS, mode[0] != SPLIT ? b->index_row : nullptr, s))
+                                        b->flags & PIME_PPO_OVERWRITE_GRADS, mode[0] != SPLIT ? b->index_row : nullptr,
+                                        opt ? &adam : nullptr, s))
             return rc;
     }
     if (mode[0] == SPLIT)   // scales the split critic's gradients, advances the index-table row
         return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, loss_sums + 3,
                                    b->index_row, s);
     return PIME_OK;
+}
+
+int pime_ppo_minibatch_grad(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b,
+                            float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
+                            float* loss_sums, pime_stream stream) {
+    return minibatch_impl(actor, critic, b, ratio_clip, lambda_entropy, critic_scale, moments, loss_sums, nullptr, stream);
+}
+
+int pime_ppo_minibatch_step(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b,
+                            float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
+                            float* loss_sums, const pime_adam* opt, pime_stream stream) {
+    PIME_REQUIRE(opt != nullptr, "pime_ppo_minibatch_step: NULL pime_adam");
+    return minibatch_impl(actor, critic, b, ratio_clip, lambda_entropy, critic_scale, moments, loss_sums, opt, stream);
 }
 
 }  // extern "C"

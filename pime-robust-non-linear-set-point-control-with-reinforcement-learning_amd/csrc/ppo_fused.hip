@@ -882,7 +882,17 @@ struct ReduceSeg {
     int perm_tb;       // 0: slab in tensor order; TB > 0: block-major accumulator order with TB column tiles (slab_layout16)
     int ldw, ncols;    // perm_tb > 0: row length and valid columns of the destination tensor
 };
+// Optional optimizer step fused into the reduction (pime_ppo_minibatch_step): the gradient tensors are views into ONE flat
+// buffer and the parameters views into another at the same offsets, so the element a thread has just reduced is also the
+// element it updates (torch.optim.Adam semantics, as adam_kernel).  A whole launch and its boundary less per optimizer step.
+struct ReduceAdam {
+    float *flat_grad, *flat_param, *exp_avg, *exp_avg_sq, *step;   // step[0] counter, step[1] arrival counter (scratch)
+    long long n;
+    float lr, b1, b2, eps;
+};
+
 struct ReduceArgs {
+    ReduceAdam adam;    // flat_grad == nullptr: no optimizer step
     ReduceSeg seg[24];
     int nseg, nslabs[2], B, moments_off, overwrite;   // nslabs per net (the two nets may come from different kernel families)
     int has_critic;     // 0: the critic went through the split pipeline (critic_scale_kernel finishes it): no scale, no cursor
@@ -907,6 +917,27 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
     }
     if (si >= a.nseg) return;
     const ReduceSeg sg = a.seg[si];
+    float t_new = 0.f, step_size = 0.f, bc2_sqrt = 1.f;
+    if (a.adam.flat_grad) {   // every thread reads the OLD step count; the last workgroup to finish stores the new one
+        t_new = a.adam.step[0] + 1.0f;
+        const double t = (double)t_new;
+        step_size = a.adam.lr / (float)(1.0 - pow((double)a.adam.b1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)a.adam.b2, t));
+    }
+    auto emit = [&](float* q, float g) {   // store the finished gradient element and, if asked, apply Adam to its parameter
+        const float gv = a.overwrite ? g : *q + g;
+        *q = gv;
+        if (a.adam.flat_grad) {
+            const long long off = q - a.adam.flat_grad;
+            if (off >= 0 && off < a.adam.n) {   // (gradients of frozen parameters land in a dump buffer outside the flat one)
+                const float mi = a.adam.exp_avg[off] + (gv - a.adam.exp_avg[off]) * (1.0f - a.adam.b1);
+                const float vi = a.adam.exp_avg_sq[off] * a.adam.b2 + gv * gv * (1.0f - a.adam.b2);
+                a.adam.exp_avg[off] = mi;
+                a.adam.exp_avg_sq[off] = vi;
+                a.adam.flat_param[off] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + a.adam.eps));
+            }
+        }
+    };
     if (wave == 0 && !a.has_critic) {
         if (lane == 0) scale_sh = 1.0f;
     } else if (wave == 0) {  // critic scale from the moments (every workgroup: same slabs, same order, same value)
@@ -965,13 +996,20 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
             const int blk = unit >> 6, ln = unit & 63;
             const int row = (blk / sg.perm_tb) * 16 + 4 * (ln >> 4), col = (blk % sg.perm_tb) * 16 + (ln & 15);
             if (col < sg.ncols)
-                for (int k = 0; k < 4; ++k) {
-                    float* q = &sg.dst[(row + k) * sg.ldw + col];
-                    *q = a.overwrite ? o[k] : *q + o[k];
-                }
+                for (int k = 0; k < 4; ++k) emit(&sg.dst[(row + k) * sg.ldw + col], o[k]);
         } else {
             for (int k = 0; k < 4; ++k)
-                if (unit * 4 + k < sg.n) sg.dst[unit * 4 + k] = a.overwrite ? o[k] : sg.dst[unit * 4 + k] + o[k];
+                if (unit * 4 + k < sg.n) emit(&sg.dst[unit * 4 + k], o[k]);
+        }
+    }
+    if (a.adam.flat_grad) {
+        __syncthreads();
+        if (tid == 0) {
+            unsigned int* arrivals = reinterpret_cast<unsigned int*>(a.adam.step + 1);
+            if (atomicAdd(arrivals, 1u) == gridDim.x - 1) {
+                *arrivals = 0;
+                a.adam.step[0] = t_new;
+            }
         }
     }
 }
@@ -1009,8 +1047,10 @@ int fused_grid(int B) {
 
 int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
                        bool f16_c, bool f16_a, bool use_c, bool use_a, int nslabs_c, int nslabs_a, float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
-                       double* moments_out, float* scale_sum, int overwrite, int64_t* index_row, hipStream_t s) {
+                       double* moments_out, float* scale_sum, int overwrite, int64_t* index_row, const ReduceAdam* adam,
+                       hipStream_t s) {
     ReduceArgs r{};
+    if (adam) r.adam = *adam;
     int poff[13], psize[12], chunks = 0;
     auto add = [&](float* dst, int off, int n, int net, int perm_tb = 0, int ldw = 0, int ncols = 0) {
         r.seg[r.nseg++] = ReduceSeg{dst, off, n, net, perm_tb, ldw, ncols};

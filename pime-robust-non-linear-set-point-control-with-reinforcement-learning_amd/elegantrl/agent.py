@@ -407,13 +407,35 @@ class AgentPPO(AgentBase):
                 torch.randint(buf_len, size=(n_steps, batch_size), device=dev, out=st.table[:n_steps])
             st.row.zero_()
 
+        # Single GPU: the Adam step rides in the gradient call's last launch (the slab reduction; pime_ppo_minibatch_step).
+        # Data parallel (the all-reduce sits between gradients and Adam), the bench's gradient-only event bracket, a torch
+        # optimizer, or nets on the split pipeline keep the separate Adam launch.
+        from ..ops import FlatAdam
+        fuse_adam = (self.dp is None and self.launch_timer is None and isinstance(self.optimizer, FlatAdam)
+                     and getattr(fused, "adam_fusable", True))
+
         def grads():   # overwrite: no zeroing launch; the running sum of the critic scale lands in loss_sums[3]
             fused(buf_state, action, st.logprob, st.adv, st.r_sum, st.table if use_table else st.idx, self.ratio_clip,
-                  self.lambda_entropy, st.scale, overwrite=True, index_row=st.row if use_table else None)
+                  self.lambda_entropy, st.scale, overwrite=True, index_row=st.row if use_table else None,
+                  adam=self.optimizer if fuse_adam else None)
 
         def apply():
-            self.optimizer.step()
+            if not fuse_adam:
+                self.optimizer.step()
             fused.repack()
+
+        if fuse_adam and not getattr(fused, "adam_probed", False):   # does the library fuse the step for these nets?
+            from ..native import PimeError
+            fused.adam_probed = True
+            snap = [t.clone() for t in (fused.flat_param, self.optimizer.exp_avg, self.optimizer.exp_avg_sq,
+                                        self.optimizer.step_count, fused.loss_sums, st.row)]
+            try:
+                grads()
+            except PimeError:
+                fused.adam_fusable, fuse_adam = False, False
+            for dst, src in zip((fused.flat_param, self.optimizer.exp_avg, self.optimizer.exp_avg_sq,
+                                 self.optimizer.step_count, fused.loss_sums, st.row), snap):
+                dst.copy_(src)   # the probe must leave no trace
 
         def capture(*thunks):
             torch.cuda.synchronize(dev)
@@ -430,8 +452,8 @@ class AgentPPO(AgentBase):
         # build that refuses collectives under capture) the agent falls back to the two-graph sequence for good.
         in_graph_dp = self.dp is not None and self.use_graph_collective and getattr(self.dp, "graph_capturable", False)
         one_graph = self.use_single_graph and (self.dp is None or in_graph_dp) and use_table and self.launch_timer is None
-        if st.mode != (use_table, one_graph):   # the captured graphs bake in which index source they read
-            st.mode, st.graph_a, st.graph_b, st.graph_full = (use_table, one_graph), None, None, None
+        if st.mode != (use_table, one_graph, fuse_adam):   # the captured graphs bake in the index source and the step form
+            st.mode, st.graph_a, st.graph_b, st.graph_full = (use_table, one_graph, fuse_adam), None, None, None
         last = None
         for step in range(n_steps):
             if not use_table:
@@ -446,7 +468,7 @@ class AgentPPO(AgentBase):
                         except RuntimeError as exc:
                             print(f"| all-reduce inside the HIP graph refused ({exc}); using the two-graph step sequence")
                             self.use_graph_collective, one_graph = False, False
-                            st.mode = (use_table, one_graph)
+                            st.mode = (use_table, one_graph, fuse_adam)
                             torch.cuda.synchronize(dev)
                             st.graph_a, st.graph_b = capture(grads), capture(apply)
                     elif one_graph:

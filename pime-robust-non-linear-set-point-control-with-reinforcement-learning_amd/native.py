@@ -48,6 +48,12 @@ class PpoBatch(C.Structure):
 PPO_OVERWRITE_GRADS = 1
 
 
+class Adam(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("step", C.c_void_p), ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float)]
+
+
 class EnvCfg(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("n_envs", C.c_int32), ("device_id", C.c_int32), ("state_mode", C.c_int32),
@@ -101,6 +107,7 @@ _SIGNATURES = {
     "pime_rollout": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pime_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     "pime_ppo_minibatch_grad": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
+    "pime_ppo_minibatch_step": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

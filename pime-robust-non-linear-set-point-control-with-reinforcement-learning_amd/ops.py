@@ -225,7 +225,7 @@ class FusedPPOGrad:
         self.flat_grad.zero_()
 
     def __call__(self, state, action, logprob, adv, r_sum, indices, ratio_clip, lambda_entropy, critic_scale,
-                 overwrite=False, index_row=None):
+                 overwrite=False, index_row=None, adam=None):
         """Accumulates (overwrite=True: writes) d(obj_united)/d(theta) of the minibatch `indices` into the .grad views;
         loss_sums[3] accumulates the critic scale of every call.  index_row (int64 [1] on the device): `indices` is then a
         table [rows, B]; the call uses row index_row[0] and advances it (so a captured graph can be replayed per step).  All tensors float32
@@ -241,6 +241,17 @@ class FusedPPOGrad:
                                 flags=native.PPO_OVERWRITE_GRADS if overwrite else 0,
                                 index_row=index_row.data_ptr() if index_row is not None else None)
         with torch.cuda.device(self.device):
+            if adam is not None:   # gradients AND the Adam step, fused into the slab reduction (pime_ppo_minibatch_step)
+                assert adam.param is self.flat_param and adam.grad is self.flat_grad
+                opt = native.Adam(param=adam.param.data_ptr(), grad=adam.grad.data_ptr(), exp_avg=adam.exp_avg.data_ptr(),
+                                  exp_avg_sq=adam.exp_avg_sq.data_ptr(), step=adam.step_count.data_ptr(), n=adam.param.numel(),
+                                  lr=adam.lr, beta1=adam.betas[0], beta2=adam.betas[1], eps=adam.eps)
+                native.check(native.lib().pime_ppo_minibatch_step(C.byref(actor), C.byref(critic), C.byref(batch),
+                                                                  C.c_float(ratio_clip), C.c_float(lambda_entropy),
+                                                                  native.ptr(critic_scale), native.ptr(self.moments),
+                                                                  native.ptr(self.loss_sums), C.byref(opt), _stream(state)),
+                             "pime_ppo_minibatch_step")
+                return
             native.check(native.lib().pime_ppo_minibatch_grad(C.byref(actor), C.byref(critic), C.byref(batch),
                                                               C.c_float(ratio_clip), C.c_float(lambda_entropy),
                                                               native.ptr(critic_scale), native.ptr(self.moments),

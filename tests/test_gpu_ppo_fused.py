@@ -268,3 +268,44 @@ def test_fused_rollout_matches_stepwise_rollout(env_name, algo):
             alive &= dy <= 1e-5
         np.testing.assert_allclose(fs[alive], ss[alive], rtol=1e-4, atol=1e-4)
     assert alive.mean() > 0.95
+
+
+@pytest.mark.parametrize("kind,md,D", [("modular", 128, 3), ("resid", 64, 4), ("resid", 256, 30), ("resid", 128, 30)])
+def test_adam_fused_into_the_slab_reduction_equals_the_separate_step(kind, md, D):
+    """pime_ppo_minibatch_step (gradients + Adam in the slab reduction) against pime_ppo_minibatch_grad + pime_adam_step:
+    the same gradient element feeds the same update arithmetic, so parameters, moments and step counter are bit-equal."""
+    from pime_amd import ops
+    B = 4096
+    outs = []
+    for fuse in (False, True):
+        act, cri = _make(kind, md, D, seed=7)
+        state, action, logprob, adv, r_sum = _data(3 * B, D, act, seed=3)
+        fused = ops.FusedPPOGrad(act, cri, B)
+        adam = fused.make_optimizer(1e-3)
+        scale = torch.zeros(1, device=DEV)
+        for step in range(3):
+            idx = torch.randint(3 * B, (B,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(10 + step))
+            fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, 0.2, 0.02, scale, overwrite=True,
+                  adam=adam if fuse else None)
+            if not fuse:
+                adam.step()
+            fused.repack()
+        torch.cuda.synchronize()
+        outs.append((fused.flat_param.clone(), adam.exp_avg.clone(), adam.exp_avg_sq.clone(), adam.step_count.clone(),
+                     fused.flat_grad.clone()))
+    for a, b, name in zip(outs[0], outs[1], ("param", "exp_avg", "exp_avg_sq", "step", "grad")):
+        assert torch.equal(a, b), f"{name} differs between the fused and the separate optimizer step"
+    assert float(outs[1][3][0]) == 3.0 and float(outs[1][3][1]) == 0.0
+
+
+def test_split_pipeline_refuses_the_fused_step():
+    from pime_amd import native, ops
+    B, D = 1024, 30
+    act, cri = _make("modular", 128, D, seed=11)      # wide modular actor -> split pipeline
+    state, action, logprob, adv, r_sum = _data(3 * B, D, act, seed=5)
+    fused = ops.FusedPPOGrad(act, cri, B)
+    adam = fused.make_optimizer(1e-3)
+    idx = torch.randint(3 * B, (B,), device=DEV)
+    with pytest.raises(native.PimeError, match="split pipeline"):
+        fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, 0.2, 0.02, torch.zeros(1, device=DEV),
+              overwrite=True, adam=adam)
