@@ -43,8 +43,12 @@ enum pime_status {
 
 enum pime_kind { PIME_ENV_PH = 0, PIME_ENV_WT = 1 };
 /* PIME_STATE_F64: every state word float64 (reference precision).  PIME_STATE_MIXED: float32 state; the pH
- * reaction-invariant x and the discretised plant (A,B,C) stay float64 so the LUT index is the reference's. */
-enum pime_state_mode { PIME_STATE_F64 = 0, PIME_STATE_MIXED = 1 };
+ * reaction-invariant x and the discretised plant (A,B,C) stay float64 so the LUT index is the reference's.
+ * PIME_STATE_MIXED16 (BASELINE.json config 5 "fp16 state" = SURVEY.md §8(d) cfg 5): as MIXED with the integrated error I STORED
+ * as IEEE binary16 and, through the *_h entry points, observations and rewards written as binary16 (48 instead of 68 bytes of
+ * algorithmic traffic per pH env-step); all arithmetic stays float32 / float64.  What it costs in accuracy is stated with
+ * pime_env_step_h. */
+enum pime_state_mode { PIME_STATE_F64 = 0, PIME_STATE_MIXED = 1, PIME_STATE_MIXED16 = 2 };
 enum pime_reward { PIME_REWARD_DISTANCE = 0, PIME_REWARD_SQUARE = 1, PIME_REWARD_SPARSE = 2 };
 enum pime_dtype { PIME_F32 = 0, PIME_F64 = 1 };
 
@@ -140,6 +144,18 @@ int pime_env_step(pime_env* env, const void* action, int32_t action_dtype, const
 int pime_env_step_residual(pime_env* env, const float* a_pre, const float* obs_in, const double* priorK,
                            const double* noise, int32_t auto_reset, const double* reset_draws, float* obs,
                            float* reward, uint8_t* done, pime_stream stream);
+
+/* The same three calls with binary16 observation / reward buffers ([dev] uint16_t = IEEE binary16 bits, torch.float16), for
+ * handles in PIME_STATE_MIXED16 mode (PIME_ERR_ARG otherwise).  obs_in of the residual form is the binary16 observation the
+ * policy saw.  Accuracy: every stored word is the float32 value rounded to nearest binary16 (relative 2^-11 = 4.9e-4: pH 11 ->
+ * +-0.004, reward -64 -> +-0.03); the dynamics (x, the LUT index, h1, h2) are untouched, but the integrated error accumulates one
+ * binary16 rounding per step (|I| <= 25: <= 0.008 per step, random-walk growth), and with it the prior PI controller's action. */
+int pime_env_reset_h(pime_env* env, const uint8_t* mask, const double* draws, uint16_t* obs, pime_stream stream);
+int pime_env_step_h(pime_env* env, const float* action, const double* noise, int32_t auto_reset, const double* reset_draws,
+                    uint16_t* obs, uint16_t* reward, uint8_t* done, pime_stream stream);
+int pime_env_step_residual_h(pime_env* env, const float* a_pre, const uint16_t* obs_in, const double* priorK,
+                             const double* noise, int32_t auto_reset, const double* reset_draws, uint16_t* obs,
+                             uint16_t* reward, uint8_t* done, pime_stream stream);
 
 /* replaces: attribute reads/writes on the env object (set_state/set_r/set_params/get_changable_parameters/
  * reset_changable_parameters: ph.py:233-270, nonlinear_watertank.py:205-212,896-900).  synchronous.

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "env_state.hpp"
@@ -21,14 +22,21 @@ void set_error(const char* fmt, ...) {
 }
 
 // launchers defined in env_kernels.hip / gae_scan.hip / mlp_mfma.hip
-template <typename S> int launch_ph_reset(const PhParams&, const PhPtrs<S>&, const uint8_t*, const double*, float*, hipStream_t);
-template <typename S> int launch_ph_step(const PhParams&, const PhPtrs<S>&, const void*, int, bool, const float*, const PriorK&,
-                                         const double*, float*, float*, uint8_t*, hipStream_t);
-template <typename S> int launch_ph_observe(const PhParams&, const PhPtrs<S>&, float*, hipStream_t);
-template <typename S> int launch_wt_reset(const WtParams&, const WtPtrs<S>&, const uint8_t*, const double*, float*, hipStream_t);
-template <typename S> int launch_wt_step(const WtParams&, const WtPtrs<S>&, const void*, int, bool, const float*, const PriorK&,
-                                         const double*, const double*, float*, float*, uint8_t*, hipStream_t);
-template <typename S> int launch_wt_observe(const WtParams&, const WtPtrs<S>&, float*, hipStream_t);
+// (S, SI, OT): arithmetic / storage type of the slow state words, storage type of the integrated error, output buffer type
+template <typename S, typename SI, typename OT>
+int launch_ph_reset(const PhParams&, const PhPtrs<S, SI>&, const uint8_t*, const double*, OT*, hipStream_t);
+template <typename S, typename SI, typename OT>
+int launch_ph_step(const PhParams&, const PhPtrs<S, SI>&, const void*, int, bool, const OT*, const PriorK&, const double*, OT*, OT*,
+                   uint8_t*, hipStream_t);
+template <typename S, typename SI, typename OT>
+int launch_ph_observe(const PhParams&, const PhPtrs<S, SI>&, OT*, hipStream_t);
+template <typename S, typename SI, typename OT>
+int launch_wt_reset(const WtParams&, const WtPtrs<S, SI>&, const uint8_t*, const double*, OT*, hipStream_t);
+template <typename S, typename SI, typename OT>
+int launch_wt_step(const WtParams&, const WtPtrs<S, SI>&, const void*, int, bool, const OT*, const PriorK&, const double*,
+                   const double*, OT*, OT*, uint8_t*, hipStream_t);
+template <typename S, typename SI, typename OT>
+int launch_wt_observe(const WtParams&, const WtPtrs<S, SI>&, OT*, hipStream_t);
 int launch_gae_scan(const float*, const float*, const float*, int, int, float, int, float*, float*, hipStream_t);
 int64_t mlp_packed_floats(int, int, int, int);
 int mlp_check(int, int, int, int);
@@ -84,6 +92,8 @@ struct pime_env {
     PhPtrs<float> ph32{};
     WtPtrs<double> wt64{};
     WtPtrs<float> wt32{};
+    PhPtrs<float, half_t> ph16{};   // PIME_STATE_MIXED16: as ph32 / wt32 with the integrated error stored as binary16
+    WtPtrs<float, half_t> wt16{};
 };
 
 namespace {
@@ -100,19 +110,19 @@ struct Carver {
     }
 };
 
-template <typename S>
-void carve_ph(Carver& c, PhPtrs<S>& p, int n, int table_len, S** table_out) {
+template <typename S, typename SI>
+void carve_ph(Carver& c, PhPtrs<S, SI>& p, int n, int table_len, S** table_out) {
     p.x = c.take<double>(n); p.A = c.take<double>(n); p.B = c.take<double>(n); p.C = c.take<double>(n);
     p.qww = c.take<double>(n); p.qc = c.take<double>(n);
-    p.I = c.take<S>(n); p.r = c.take<S>(n); p.last_a = c.take<S>(n);
+    p.I = c.take<SI>(n); p.r = c.take<S>(n); p.last_a = c.take<S>(n);
     p.t = c.take<int32_t>(n); p.episode = c.take<int32_t>(n);
     *table_out = c.take<S>(table_len);
     p.table = *table_out;
 }
 
-template <typename S>
-void carve_wt(Carver& c, WtPtrs<S>& p, int n, int obs_dim, int num_stack) {
-    p.h1 = c.take<S>(n); p.h2 = c.take<S>(n); p.r = c.take<S>(n); p.I = c.take<S>(n);
+template <typename S, typename SI>
+void carve_wt(Carver& c, WtPtrs<S, SI>& p, int n, int obs_dim, int num_stack) {
+    p.h1 = c.take<S>(n); p.h2 = c.take<S>(n); p.r = c.take<S>(n); p.I = c.take<SI>(n);
     p.a1 = c.take<S>(n); p.a2 = c.take<S>(n); p.kp = c.take<S>(n);
     p.frames = num_stack > 0 ? c.take<S>((size_t)n * obs_dim) : nullptr;
     p.head = num_stack > 0 ? c.take<int32_t>(n) : nullptr;
@@ -123,7 +133,8 @@ int check_cfg(const pime_env_cfg* c) {
     PIME_REQUIRE(c != nullptr, "cfg is NULL");
     PIME_REQUIRE(c->kind == PIME_ENV_PH || c->kind == PIME_ENV_WT, "unknown env kind %d", c->kind);
     PIME_REQUIRE(c->n_envs >= 1, "n_envs = %d", c->n_envs);
-    PIME_REQUIRE(c->state_mode == PIME_STATE_F64 || c->state_mode == PIME_STATE_MIXED, "unknown state_mode %d", c->state_mode);
+    PIME_REQUIRE(c->state_mode == PIME_STATE_F64 || c->state_mode == PIME_STATE_MIXED || c->state_mode == PIME_STATE_MIXED16,
+                 "unknown state_mode %d", c->state_mode);
     PIME_REQUIRE(c->reward_type >= PIME_REWARD_DISTANCE && c->reward_type <= PIME_REWARD_SPARSE, "unknown reward_type %d",
                  c->reward_type);
     PIME_REQUIRE(c->max_steps >= 1, "max_steps = %d", c->max_steps);
@@ -173,7 +184,7 @@ int use_device(const pime_env* e) {
 // device array <-> host double conversions for field I/O
 struct FieldRef {
     void* ptr = nullptr;
-    int type = 0;  // 0 double, 1 float, 2 int32
+    int type = 0;  // 0 double, 1 float, 2 int32, 3 binary16
     bool ph_params = false, read_only = false, is_y = false;
 };
 
@@ -183,10 +194,12 @@ int resolve_field(pime_env* e, int field, FieldRef* out) {
 #define SPTR(member) (f64 ? (void*)e->ph64.member : (void*)e->ph32.member)
 #define WPTR(member) (f64 ? (void*)e->wt64.member : (void*)e->wt32.member)
     const int st = f64 ? 0 : 1;
+    const int sti = e->cfg.state_mode == PIME_STATE_MIXED16 ? 3 : st;   // the integrated error: binary16 in MIXED16 (ph32 / wt32
+                                                                        // alias every other array of ph16 / wt16)
     if (e->cfg.kind == PIME_ENV_PH) {
         switch (field) {
             case PIME_PH_X: r = {e->ph64.x, 0}; break;
-            case PIME_PH_I: r = {SPTR(I), st}; break;
+            case PIME_PH_I: r = {sti == 3 ? (void*)e->ph16.I : SPTR(I), sti}; break;
             case PIME_PH_R: r = {SPTR(r), st}; break;
             case PIME_PH_Y: r = {nullptr, 0, false, true, true}; break;
             case PIME_PH_A: r = {e->ph64.A, 0}; break;
@@ -205,7 +218,7 @@ int resolve_field(pime_env* e, int field, FieldRef* out) {
             case PIME_WT_R: r = {WPTR(r), st}; break;
             case PIME_WT_I:
                 if (e->cfg.num_stack > 0) { set_error("the Stacking variant has no integrator"); return PIME_ERR_ARG; }
-                r = {WPTR(I), st}; break;
+                r = {sti == 3 ? (void*)e->wt16.I : WPTR(I), sti}; break;
             case PIME_WT_A1: r = {WPTR(a1), st}; break;
             case PIME_WT_A2: r = {WPTR(a2), st}; break;
             case PIME_WT_KP: r = {WPTR(kp), st}; break;
@@ -229,6 +242,11 @@ int d2h_as_double(const FieldRef& f, int n, double* out, hipStream_t s) {
         PIME_HIP_TRY(hipMemcpyAsync(tmp.data(), f.ptr, sizeof(float) * n, hipMemcpyDeviceToHost, s));
         PIME_HIP_TRY(hipStreamSynchronize(s));
         for (int i = 0; i < n; ++i) out[i] = tmp[i];
+    } else if (f.type == 3) {
+        std::vector<half_t> tmp(n);
+        PIME_HIP_TRY(hipMemcpyAsync(tmp.data(), f.ptr, sizeof(half_t) * n, hipMemcpyDeviceToHost, s));
+        PIME_HIP_TRY(hipStreamSynchronize(s));
+        for (int i = 0; i < n; ++i) out[i] = (double)(float)tmp[i];
     } else {
         std::vector<int32_t> tmp(n);
         PIME_HIP_TRY(hipMemcpyAsync(tmp.data(), f.ptr, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
@@ -246,6 +264,11 @@ int h2d_from_double(const FieldRef& f, int n, const double* in, hipStream_t s) {
         std::vector<float> tmp(n);
         for (int i = 0; i < n; ++i) tmp[i] = (float)in[i];
         PIME_HIP_TRY(hipMemcpyAsync(f.ptr, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice, s));
+        PIME_HIP_TRY(hipStreamSynchronize(s));
+    } else if (f.type == 3) {
+        std::vector<half_t> tmp(n);
+        for (int i = 0; i < n; ++i) tmp[i] = (half_t)(float)in[i];
+        PIME_HIP_TRY(hipMemcpyAsync(f.ptr, tmp.data(), sizeof(half_t) * n, hipMemcpyHostToDevice, s));
         PIME_HIP_TRY(hipStreamSynchronize(s));
     } else {
         std::vector<int32_t> tmp(n);
@@ -343,13 +366,30 @@ pime_env* pime_env_create(const pime_env_cfg* cfg) {
         if (cfg->kind == PIME_ENV_PH) {
             if (f64) { double* t; carve_ph(c, e->ph64, n, cfg->ph_table_len, &t); table_dev = t; }
             else {
-                float* t; carve_ph(c, e->ph32, n, cfg->ph_table_len, &t); table_dev = t;
+                float* t;
+                if (cfg->state_mode == PIME_STATE_MIXED16) {   // ph32 aliases every array but I (which it must not touch)
+                    carve_ph(c, e->ph16, n, cfg->ph_table_len, &t);
+                    const PhPtrs<float, half_t>& h = e->ph16;
+                    e->ph32.x = h.x; e->ph32.A = h.A; e->ph32.B = h.B; e->ph32.C = h.C; e->ph32.qww = h.qww; e->ph32.qc = h.qc;
+                    e->ph32.r = h.r; e->ph32.last_a = h.last_a; e->ph32.I = nullptr; e->ph32.t = h.t; e->ph32.episode = h.episode;
+                    e->ph32.table = h.table;
+                } else {
+                    carve_ph(c, e->ph32, n, cfg->ph_table_len, &t);
+                }
+                table_dev = t;
                 // shared float64 arrays are addressed through ph64 by the field accessors
                 e->ph64.x = e->ph32.x; e->ph64.A = e->ph32.A; e->ph64.B = e->ph32.B; e->ph64.C = e->ph32.C;
                 e->ph64.qww = e->ph32.qww; e->ph64.qc = e->ph32.qc; e->ph64.t = e->ph32.t; e->ph64.episode = e->ph32.episode;
             }
         } else {
             if (f64) carve_wt(c, e->wt64, n, e->obs_dim, cfg->num_stack);
+            else if (cfg->state_mode == PIME_STATE_MIXED16) {
+                carve_wt(c, e->wt16, n, e->obs_dim, cfg->num_stack);
+                const WtPtrs<float, half_t>& h = e->wt16;
+                e->wt32.h1 = h.h1; e->wt32.h2 = h.h2; e->wt32.r = h.r; e->wt32.a1 = h.a1; e->wt32.a2 = h.a2; e->wt32.kp = h.kp;
+                e->wt32.I = nullptr; e->wt32.frames = h.frames; e->wt32.head = h.head; e->wt32.t = h.t; e->wt32.episode = h.episode;
+                e->wt64.t = h.t; e->wt64.episode = h.episode;
+            }
             else { carve_wt(c, e->wt32, n, e->obs_dim, cfg->num_stack); e->wt64.t = e->wt32.t; e->wt64.episode = e->wt32.episode; }
         }
         if (pass == 0) {
@@ -399,19 +439,43 @@ int32_t pime_env_obs_dim(const pime_env* e) { return e ? e->obs_dim : 0; }
 int32_t pime_env_num_envs(const pime_env* e) { return e ? e->cfg.n_envs : 0; }
 int32_t pime_env_reset_draw_width(const pime_env* e) { return e ? (e->cfg.kind == PIME_ENV_PH ? 4 : 6) : 0; }
 
-int pime_env_reset(pime_env* e, const uint8_t* mask, const double* draws, float* obs, pime_stream stream) {
+// OT = float: the regular entry points (every state mode); OT = binary16: the *_h entry points (PIME_STATE_MIXED16 only)
+extern "C++" {
+template <typename OT>
+static int reset_common(pime_env* e, const uint8_t* mask, const double* draws, OT* obs, pime_stream stream) {
     PIME_REQUIRE(e != nullptr && obs != nullptr, "pime_env_reset: NULL handle or obs");
     if (int rc = use_device(e)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     e->was_reset = true;
-    const bool f64 = e->cfg.state_mode == PIME_STATE_F64;
-    if (e->cfg.kind == PIME_ENV_PH)
-        return f64 ? launch_ph_reset(e->ph, e->ph64, mask, draws, obs, s) : launch_ph_reset(e->ph, e->ph32, mask, draws, obs, s);
-    return f64 ? launch_wt_reset(e->wt, e->wt64, mask, draws, obs, s) : launch_wt_reset(e->wt, e->wt32, mask, draws, obs, s);
+    const int mode = e->cfg.state_mode;
+    if constexpr (std::is_same<OT, half_t>::value) {
+        PIME_REQUIRE(mode == PIME_STATE_MIXED16, "binary16 observations need an env handle in PIME_STATE_MIXED16 mode");
+        return e->cfg.kind == PIME_ENV_PH ? launch_ph_reset(e->ph, e->ph16, mask, draws, obs, s)
+                                          : launch_wt_reset(e->wt, e->wt16, mask, draws, obs, s);
+    } else {
+        if (e->cfg.kind == PIME_ENV_PH)
+            return mode == PIME_STATE_F64 ? launch_ph_reset(e->ph, e->ph64, mask, draws, obs, s)
+                 : mode == PIME_STATE_MIXED ? launch_ph_reset(e->ph, e->ph32, mask, draws, obs, s)
+                                            : launch_ph_reset(e->ph, e->ph16, mask, draws, obs, s);
+        return mode == PIME_STATE_F64 ? launch_wt_reset(e->wt, e->wt64, mask, draws, obs, s)
+             : mode == PIME_STATE_MIXED ? launch_wt_reset(e->wt, e->wt32, mask, draws, obs, s)
+                                        : launch_wt_reset(e->wt, e->wt16, mask, draws, obs, s);
+    }
 }
 
-static int step_common(pime_env* e, const void* act, int act_dtype, bool residual, const float* obs_in, const double* priorK,
-                       const double* noise, int auto_reset, const double* reset_draws, float* obs, float* reward, uint8_t* done,
+}  // extern "C++"
+
+int pime_env_reset(pime_env* e, const uint8_t* mask, const double* draws, float* obs, pime_stream stream) {
+    return reset_common<float>(e, mask, draws, obs, stream);
+}
+int pime_env_reset_h(pime_env* e, const uint8_t* mask, const double* draws, uint16_t* obs, pime_stream stream) {
+    return reset_common<half_t>(e, mask, draws, reinterpret_cast<half_t*>(obs), stream);
+}
+
+extern "C++" {
+template <typename OT>
+static int step_common(pime_env* e, const void* act, int act_dtype, bool residual, const OT* obs_in, const double* priorK,
+                       const double* noise, int auto_reset, const double* reset_draws, OT* obs, OT* reward, uint8_t* done,
                        pime_stream stream) {
     PIME_REQUIRE(e != nullptr, "NULL env handle");
     PIME_REQUIRE(act && obs && reward && done, "pime_env_step: NULL action/obs/reward/done");
@@ -424,38 +488,64 @@ static int step_common(pime_env* e, const void* act, int act_dtype, bool residua
     }
     if (int rc = use_device(e)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool f64 = e->cfg.state_mode == PIME_STATE_F64;
+    const int mode = e->cfg.state_mode;
+    constexpr bool kHalf = std::is_same<OT, half_t>::value;
+    if (kHalf) PIME_REQUIRE(mode == PIME_STATE_MIXED16, "binary16 observations need an env handle in PIME_STATE_MIXED16 mode");
     if (e->cfg.kind == PIME_ENV_PH) {
         PIME_REQUIRE(noise == nullptr, "the pH env has no process noise input");
         PhParams p = e->ph;
         p.auto_reset = auto_reset ? 1 : 0;
-        return f64 ? launch_ph_step(p, e->ph64, act, act_dtype, residual, obs_in, K, reset_draws, obs, reward, done, s)
-                   : launch_ph_step(p, e->ph32, act, act_dtype, residual, obs_in, K, reset_draws, obs, reward, done, s);
+        if constexpr (kHalf) return launch_ph_step(p, e->ph16, act, act_dtype, residual, obs_in, K, reset_draws, obs, reward, done, s);
+        else
+            return mode == PIME_STATE_F64 ? launch_ph_step(p, e->ph64, act, act_dtype, residual, obs_in, K, reset_draws, obs, reward, done, s)
+                 : mode == PIME_STATE_MIXED ? launch_ph_step(p, e->ph32, act, act_dtype, residual, obs_in, K, reset_draws, obs, reward, done, s)
+                                            : launch_ph_step(p, e->ph16, act, act_dtype, residual, obs_in, K, reset_draws, obs, reward, done, s);
     }
     WtParams p = e->wt;
     p.auto_reset = auto_reset ? 1 : 0;
-    return f64 ? launch_wt_step(p, e->wt64, act, act_dtype, residual, obs_in, K, noise, reset_draws, obs, reward, done, s)
-               : launch_wt_step(p, e->wt32, act, act_dtype, residual, obs_in, K, noise, reset_draws, obs, reward, done, s);
+    if constexpr (kHalf) return launch_wt_step(p, e->wt16, act, act_dtype, residual, obs_in, K, noise, reset_draws, obs, reward, done, s);
+    else
+        return mode == PIME_STATE_F64 ? launch_wt_step(p, e->wt64, act, act_dtype, residual, obs_in, K, noise, reset_draws, obs, reward, done, s)
+             : mode == PIME_STATE_MIXED ? launch_wt_step(p, e->wt32, act, act_dtype, residual, obs_in, K, noise, reset_draws, obs, reward, done, s)
+                                        : launch_wt_step(p, e->wt16, act, act_dtype, residual, obs_in, K, noise, reset_draws, obs, reward, done, s);
 }
+
+}  // extern "C++"
 
 int pime_env_step(pime_env* e, const void* action, int32_t action_dtype, const double* noise, int32_t auto_reset,
                   const double* reset_draws, float* obs, float* reward, uint8_t* done, pime_stream stream) {
-    return step_common(e, action, action_dtype, false, nullptr, nullptr, noise, auto_reset, reset_draws, obs, reward, done, stream);
+    return step_common<float>(e, action, action_dtype, false, nullptr, nullptr, noise, auto_reset, reset_draws, obs, reward, done, stream);
 }
 
 int pime_env_step_residual(pime_env* e, const float* a_pre, const float* obs_in, const double* priorK, const double* noise,
                            int32_t auto_reset, const double* reset_draws, float* obs, float* reward, uint8_t* done,
                            pime_stream stream) {
-    return step_common(e, a_pre, PIME_F32, true, obs_in, priorK, noise, auto_reset, reset_draws, obs, reward, done, stream);
+    return step_common<float>(e, a_pre, PIME_F32, true, obs_in, priorK, noise, auto_reset, reset_draws, obs, reward, done, stream);
+}
+
+int pime_env_step_h(pime_env* e, const float* action, const double* noise, int32_t auto_reset, const double* reset_draws,
+                    uint16_t* obs, uint16_t* reward, uint8_t* done, pime_stream stream) {
+    return step_common<half_t>(e, action, PIME_F32, false, nullptr, nullptr, noise, auto_reset, reset_draws,
+                               reinterpret_cast<half_t*>(obs), reinterpret_cast<half_t*>(reward), done, stream);
+}
+
+int pime_env_step_residual_h(pime_env* e, const float* a_pre, const uint16_t* obs_in, const double* priorK, const double* noise,
+                             int32_t auto_reset, const double* reset_draws, uint16_t* obs, uint16_t* reward, uint8_t* done,
+                             pime_stream stream) {
+    return step_common<half_t>(e, a_pre, PIME_F32, true, reinterpret_cast<const half_t*>(obs_in), priorK, noise, auto_reset,
+                               reset_draws, reinterpret_cast<half_t*>(obs), reinterpret_cast<half_t*>(reward), done, stream);
 }
 
 int pime_env_observe(pime_env* e, float* obs, pime_stream stream) {
     PIME_REQUIRE(e != nullptr && obs != nullptr, "pime_env_observe: NULL handle or obs");
     if (int rc = use_device(e)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool f64 = e->cfg.state_mode == PIME_STATE_F64;
-    if (e->cfg.kind == PIME_ENV_PH) return f64 ? launch_ph_observe(e->ph, e->ph64, obs, s) : launch_ph_observe(e->ph, e->ph32, obs, s);
-    return f64 ? launch_wt_observe(e->wt, e->wt64, obs, s) : launch_wt_observe(e->wt, e->wt32, obs, s);
+    const int mode = e->cfg.state_mode;
+    if (e->cfg.kind == PIME_ENV_PH)
+        return mode == PIME_STATE_F64 ? launch_ph_observe(e->ph, e->ph64, obs, s)
+             : mode == PIME_STATE_MIXED ? launch_ph_observe(e->ph, e->ph32, obs, s) : launch_ph_observe(e->ph, e->ph16, obs, s);
+    return mode == PIME_STATE_F64 ? launch_wt_observe(e->wt, e->wt64, obs, s)
+         : mode == PIME_STATE_MIXED ? launch_wt_observe(e->wt, e->wt32, obs, s) : launch_wt_observe(e->wt, e->wt16, obs, s);
 }
 
 int pime_env_read_field(pime_env* e, int32_t field, double* out, pime_stream stream) {

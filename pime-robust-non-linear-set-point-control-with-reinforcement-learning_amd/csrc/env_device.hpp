@@ -37,19 +37,19 @@ struct PhLane {
     bool plant_changed;  // (A,B,C,qww,qc) were rewritten by a resampling reset and must be stored
 };
 
-template <typename S>
-__device__ __forceinline__ void ph_lane_load(const PhParams& p, const PhPtrs<S>& st, int i, PhLane<S>& L) {
+template <typename S, typename SI>
+__device__ __forceinline__ void ph_lane_load(const PhParams& p, const PhPtrs<S, SI>& st, int i, PhLane<S>& L) {
     L.x = st.x[i]; L.A = st.A[i]; L.B = st.B[i]; L.C = st.C[i];
-    L.I = st.I[i]; L.r = st.r[i];
+    L.I = (S)st.I[i]; L.r = st.r[i];
     L.t = st.t[i]; L.episode = st.episode[i];
     L.last_a = p.has_punish ? st.last_a[i] : S(0);
     L.qww = L.qc = 0.0;
     L.plant_changed = false;
 }
 
-template <typename S>
-__device__ __forceinline__ void ph_lane_store(const PhParams& p, const PhPtrs<S>& st, int i, const PhLane<S>& L) {
-    st.x[i] = L.x; st.I[i] = L.I; st.r[i] = L.r; st.t[i] = L.t; st.episode[i] = L.episode;
+template <typename S, typename SI>
+__device__ __forceinline__ void ph_lane_store(const PhParams& p, const PhPtrs<S, SI>& st, int i, const PhLane<S>& L) {
+    st.x[i] = L.x; st.I[i] = (SI)L.I; st.r[i] = L.r; st.t[i] = L.t; st.episode[i] = L.episode;
     if (p.has_punish) st.last_a[i] = L.last_a;
     if (L.plant_changed) {
         st.A[i] = L.A; st.B[i] = L.B; st.C[i] = L.C; st.qww[i] = L.qww; st.qc[i] = L.qc;
@@ -138,19 +138,19 @@ struct WtLane {
     bool plant_changed;
 };
 
-template <typename S>
-__device__ __forceinline__ void wt_lane_load(const WtParams& p, const WtPtrs<S>& st, int i, WtLane<S>& L) {
+template <typename S, typename SI>
+__device__ __forceinline__ void wt_lane_load(const WtParams& p, const WtPtrs<S, SI>& st, int i, WtLane<S>& L) {
     L.h1 = st.h1[i]; L.h2 = st.h2[i]; L.r = st.r[i];
-    L.I = p.num_stack == 0 ? st.I[i] : S(0);
+    L.I = p.num_stack == 0 ? (S)st.I[i] : S(0);
     L.a1 = st.a1[i]; L.a2 = st.a2[i]; L.kp = st.kp[i];
     L.t = st.t[i]; L.episode = st.episode[i];
     L.plant_changed = false;
 }
 
-template <typename S>
-__device__ __forceinline__ void wt_lane_store(const WtParams& p, const WtPtrs<S>& st, int i, const WtLane<S>& L) {
+template <typename S, typename SI>
+__device__ __forceinline__ void wt_lane_store(const WtParams& p, const WtPtrs<S, SI>& st, int i, const WtLane<S>& L) {
     st.h1[i] = L.h1; st.h2[i] = L.h2; st.r[i] = L.r; st.t[i] = L.t; st.episode[i] = L.episode;
-    if (p.num_stack == 0) st.I[i] = L.I;
+    if (p.num_stack == 0) st.I[i] = (SI)L.I;
     if (L.plant_changed) { st.a1[i] = L.a1; st.a2[i] = L.a2; st.kp[i] = L.kp; }
 }
 

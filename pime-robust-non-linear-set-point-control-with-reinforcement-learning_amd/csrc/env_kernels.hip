@@ -18,9 +18,12 @@ namespace pime {
 
 // ============================================================================================ pH
 // (lane arithmetic in env_device.hpp; the kernels below are load -> step/reset -> store)
-template <typename S>
-__global__ void ph_reset_kernel(PhParams p, PhPtrs<S> st, const uint8_t* __restrict__ mask,
-                                const double* __restrict__ draws, float* __restrict__ obs) {
+// Template parameters of every kernel below: S = arithmetic / storage type of the slow state words, SI = storage type of the
+// integrated error (S, or binary16 in PIME_STATE_MIXED16), OT = type of the observation / reward buffers (float, or binary16
+// through the *_h entry points: SURVEY §8(d) cfg 5 "fp16 storage for obs / reward / I, f32 math, f64 x").
+template <typename S, typename SI, typename OT>
+__global__ void ph_reset_kernel(PhParams p, PhPtrs<S, SI> st, const uint8_t* __restrict__ mask,
+                                const double* __restrict__ draws, OT* __restrict__ obs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     if (mask && !mask[i]) return;
@@ -29,18 +32,18 @@ __global__ void ph_reset_kernel(PhParams p, PhPtrs<S> st, const uint8_t* __restr
     float o[3];
     ph_lane_reset<S>(p, st.table, p.env_offset + (uint32_t)i, draws ? draws + 4 * (size_t)i : nullptr, L, o);
     ph_lane_store<S>(p, st, i, L);
-    obs[3 * (size_t)i + 0] = o[0]; obs[3 * (size_t)i + 1] = o[1]; obs[3 * (size_t)i + 2] = o[2];
+    obs[3 * (size_t)i + 0] = (OT)o[0]; obs[3 * (size_t)i + 1] = (OT)o[1]; obs[3 * (size_t)i + 2] = (OT)o[2];
 }
 
-template <typename S, typename ActT, bool RESIDUAL>
-__global__ void ph_step_kernel(PhParams p, PhPtrs<S> st, const ActT* __restrict__ act,
-                               const float* __restrict__ obs_in, PriorK K, const double* __restrict__ reset_draws,
-                               float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done) {
+template <typename S, typename SI, typename ActT, typename OT, bool RESIDUAL>
+__global__ void ph_step_kernel(PhParams p, PhPtrs<S, SI> st, const ActT* __restrict__ act,
+                               const OT* __restrict__ obs_in, PriorK K, const double* __restrict__ reset_draws,
+                               OT* __restrict__ obs, OT* __restrict__ reward, uint8_t* __restrict__ done) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     double a;
     if constexpr (RESIDUAL) {
-        const float o_in[3] = {obs_in[3 * (size_t)i], obs_in[3 * (size_t)i + 1], obs_in[3 * (size_t)i + 2]};
+        const float o_in[3] = {(float)obs_in[3 * (size_t)i], (float)obs_in[3 * (size_t)i + 1], (float)obs_in[3 * (size_t)i + 2]};
         a = ph_residual_action((float)act[i], o_in, K);
     } else {
         a = (double)act[i];
@@ -49,35 +52,35 @@ __global__ void ph_step_kernel(PhParams p, PhPtrs<S> st, const ActT* __restrict_
     ph_lane_load<S>(p, st, i, L);
     float o[3], rew;
     const bool d = ph_lane_step<S>(p, st.table, a, L, o, rew);
-    reward[i] = rew;
+    reward[i] = (OT)rew;
     done[i] = (uint8_t)d;
     if (d && p.auto_reset)
         ph_lane_reset<S>(p, st.table, p.env_offset + (uint32_t)i, reset_draws ? reset_draws + 4 * (size_t)i : nullptr, L, o);
     ph_lane_store<S>(p, st, i, L);
-    obs[3 * (size_t)i + 0] = o[0]; obs[3 * (size_t)i + 1] = o[1]; obs[3 * (size_t)i + 2] = o[2];
+    obs[3 * (size_t)i + 0] = (OT)o[0]; obs[3 * (size_t)i + 1] = (OT)o[1]; obs[3 * (size_t)i + 2] = (OT)o[2];
 }
 
-template <typename S>
-__global__ void ph_observe_kernel(PhParams p, PhPtrs<S> st, float* __restrict__ obs) {
+template <typename S, typename SI, typename OT>
+__global__ void ph_observe_kernel(PhParams p, PhPtrs<S, SI> st, OT* __restrict__ obs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
-    obs[3 * (size_t)i + 0] = (float)ph_lookup<S>(p, st.table, st.C[i], st.x[i]);
-    obs[3 * (size_t)i + 1] = (float)st.r[i];
-    obs[3 * (size_t)i + 2] = (float)st.I[i];
+    obs[3 * (size_t)i + 0] = (OT)(float)ph_lookup<S>(p, st.table, st.C[i], st.x[i]);
+    obs[3 * (size_t)i + 1] = (OT)(float)st.r[i];
+    obs[3 * (size_t)i + 2] = (OT)(float)st.I[i];
 }
 
 // ============================================================================================ water tank
 // Stacking variant (nonlinear_watertank.py:1056-1208): frame ring in SoA order with a per-lane head (env_state.hpp).
-template <typename S>
-__device__ __forceinline__ void wt_frames_fill(const WtParams& p, const WtPtrs<S>& st, int i, const WtLane<S>& L) {
+template <typename S, typename SI>
+__device__ __forceinline__ void wt_frames_fill(const WtParams& p, const WtPtrs<S, SI>& st, int i, const WtLane<S>& L) {
     const size_t n = (size_t)p.n;   // every frame = the first frame (:1181-1183)
     for (int s = 0; s < p.num_stack; ++s) {
         st.frames[(3 * s + 0) * n + i] = L.h1; st.frames[(3 * s + 1) * n + i] = L.h2; st.frames[(3 * s + 2) * n + i] = L.r;
     }
     st.head[i] = 0;
 }
-template <typename S>
-__device__ __forceinline__ void wt_frames_push(const WtParams& p, const WtPtrs<S>& st, int i, const WtLane<S>& L) {
+template <typename S, typename SI>
+__device__ __forceinline__ void wt_frames_push(const WtParams& p, const WtPtrs<S, SI>& st, int i, const WtLane<S>& L) {
     const size_t n = (size_t)p.n;   // deque(maxlen=S).append([h1,h2,r]) (:1143-1144): overwrite the oldest slot
     const int h = st.head[i];
     st.frames[(3 * h + 0) * n + i] = L.h1; st.frames[(3 * h + 1) * n + i] = L.h2; st.frames[(3 * h + 2) * n + i] = L.r;
@@ -89,9 +92,9 @@ __device__ __forceinline__ void wt_frames_push(const WtParams& p, const WtPtrs<S
 //   Stacking:   np.array(frames).reshape(1,-1)[0], oldest first (:1162-1164) = 3S floats per lane.  Written lane by lane
 //               that is a 12 S-byte stride between neighbouring lanes; instead the block's rows are assembled in LDS
 //               ([blockDim][3S] + a live flag per row) and leave as one contiguous, coalesced run.
-template <typename S>
-__device__ __forceinline__ void wt_write_obs(const WtParams& p, const WtPtrs<S>& st, int i, bool live, S h1, S h2, S r, S I,
-                                             float* __restrict__ obs, float* __restrict__ lds) {
+template <typename S, typename SI, typename OT>
+__device__ __forceinline__ void wt_write_obs(const WtParams& p, const WtPtrs<S, SI>& st, int i, bool live, S h1, S h2, S r, S I,
+                                             OT* __restrict__ obs, float* __restrict__ lds) {
     if (p.num_stack > 0) {
         const int D = p.obs_dim;
         int* flag = reinterpret_cast<int*>(lds + blockDim.x * D);
@@ -110,16 +113,16 @@ __device__ __forceinline__ void wt_write_obs(const WtParams& p, const WtPtrs<S>&
         __syncthreads();
         const size_t base = (size_t)blockIdx.x * blockDim.x * D;
         for (int e = threadIdx.x; e < (int)blockDim.x * D; e += blockDim.x)
-            if (flag[e / D]) obs[base + e] = lds[e];
+            if (flag[e / D]) obs[base + e] = (OT)lds[e];
     } else if (live) {
-        float4 o = make_float4((float)h1, (float)h2, (float)r, (float)I);
-        *reinterpret_cast<float4*>(obs + 4 * (size_t)i) = o;
+        OT* o = obs + 4 * (size_t)i;
+        o[0] = (OT)(float)h1; o[1] = (OT)(float)h2; o[2] = (OT)(float)r; o[3] = (OT)(float)I;   // one 16-B (8-B) store per lane
     }
 }
 
-template <typename S>
-__global__ void wt_reset_kernel(WtParams p, WtPtrs<S> st, const uint8_t* __restrict__ mask,
-                                const double* __restrict__ draws, float* __restrict__ obs) {
+template <typename S, typename SI, typename OT>
+__global__ void wt_reset_kernel(WtParams p, WtPtrs<S, SI> st, const uint8_t* __restrict__ mask,
+                                const double* __restrict__ draws, OT* __restrict__ obs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < p.n && (!mask || mask[i]);
@@ -133,11 +136,11 @@ __global__ void wt_reset_kernel(WtParams p, WtPtrs<S> st, const uint8_t* __restr
     wt_write_obs<S>(p, st, i, live, L.h1, L.h2, L.r, L.I, obs, lds);
 }
 
-template <typename S, typename ActT, bool RESIDUAL>
-__global__ void wt_step_kernel(WtParams p, WtPtrs<S> st, const ActT* __restrict__ act,
-                               const float* __restrict__ obs_in, PriorK K, const double* __restrict__ noise,
-                               const double* __restrict__ reset_draws, float* __restrict__ obs,
-                               float* __restrict__ reward, uint8_t* __restrict__ done) {
+template <typename S, typename SI, typename ActT, typename OT, bool RESIDUAL>
+__global__ void wt_step_kernel(WtParams p, WtPtrs<S, SI> st, const ActT* __restrict__ act,
+                               const OT* __restrict__ obs_in, PriorK K, const double* __restrict__ noise,
+                               const double* __restrict__ reset_draws, OT* __restrict__ obs,
+                               OT* __restrict__ reward, uint8_t* __restrict__ done) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < p.n;
@@ -146,7 +149,7 @@ __global__ void wt_step_kernel(WtParams p, WtPtrs<S> st, const ActT* __restrict_
         double a;
         if constexpr (RESIDUAL) {  // agent_residual.py:61
             double dot = 0.0;
-            for (int j = 0; j < p.obs_dim; ++j) dot += (double)obs_in[(size_t)i * p.obs_dim + j] * K.k[j];
+            for (int j = 0; j < p.obs_dim; ++j) dot += (double)(float)obs_in[(size_t)i * p.obs_dim + j] * K.k[j];
             a = (double)tanhf((float)act[i]) + dot;
         } else {
             a = (double)act[i];
@@ -157,7 +160,7 @@ __global__ void wt_step_kernel(WtParams p, WtPtrs<S> st, const ActT* __restrict_
         wt_lane_noise<S>(p, gid, L, noise ? noise + 2 * (size_t)i : nullptr, z1n, z2n);
         float rew;
         const bool d = wt_lane_step<S>(p, a, z1n, z2n, L, rew);
-        reward[i] = rew;
+        reward[i] = (OT)rew;
         done[i] = (uint8_t)d;
         if (d && p.auto_reset) {
             wt_lane_reset<S>(p, gid, reset_draws ? reset_draws + 6 * (size_t)i : nullptr, L);
@@ -171,13 +174,13 @@ __global__ void wt_step_kernel(WtParams p, WtPtrs<S> st, const ActT* __restrict_
     wt_write_obs<S>(p, st, i, live, L.h1, L.h2, L.r, L.I, obs, lds);
 }
 
-template <typename S>
-__global__ void wt_observe_kernel(WtParams p, WtPtrs<S> st, float* __restrict__ obs) {
+template <typename S, typename SI, typename OT>
+__global__ void wt_observe_kernel(WtParams p, WtPtrs<S, SI> st, OT* __restrict__ obs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < p.n;
     const int k = live ? i : 0;
-    wt_write_obs<S>(p, st, i, live, st.h1[k], st.h2[k], st.r[k], p.num_stack > 0 ? S(0) : st.I[k], obs, lds);
+    wt_write_obs<S>(p, st, i, live, st.h1[k], st.h2[k], st.r[k], p.num_stack > 0 ? S(0) : (S)st.I[k], obs, lds);
 }
 
 // ============================================================================================ launchers
@@ -192,96 +195,98 @@ static inline dim3 lane_grid(int n, int& block) {
     return dim3((unsigned)((n + block - 1) / block));
 }
 
-template <typename S>
-int launch_ph_reset(const PhParams& p, const PhPtrs<S>& st, const uint8_t* mask, const double* draws, float* obs,
+template <typename S, typename SI, typename OT>
+int launch_ph_reset(const PhParams& p, const PhPtrs<S, SI>& st, const uint8_t* mask, const double* draws, OT* obs,
                     hipStream_t s) {
     int block;
     const dim3 grid = lane_grid(p.n, block);
-    hipLaunchKernelGGL(ph_reset_kernel<S>, grid, dim3(block), 0, s, p, st, mask, draws, obs);
+    hipLaunchKernelGGL((ph_reset_kernel<S, SI, OT>), grid, dim3(block), 0, s, p, st, mask, draws, obs);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 
-template <typename S>
-int launch_ph_step(const PhParams& p, const PhPtrs<S>& st, const void* act, int act_dtype, bool residual,
-                   const float* obs_in, const PriorK& K, const double* reset_draws, float* obs, float* reward,
+template <typename S, typename SI, typename OT>
+int launch_ph_step(const PhParams& p, const PhPtrs<S, SI>& st, const void* act, int act_dtype, bool residual,
+                   const OT* obs_in, const PriorK& K, const double* reset_draws, OT* obs, OT* reward,
                    uint8_t* done, hipStream_t s) {
     int block;
     const dim3 grid = lane_grid(p.n, block);
     if (residual)
-        hipLaunchKernelGGL((ph_step_kernel<S, float, true>), grid, dim3(block), 0, s, p, st, (const float*)act, obs_in,
+        hipLaunchKernelGGL((ph_step_kernel<S, SI, float, OT, true>), grid, dim3(block), 0, s, p, st, (const float*)act, obs_in,
                            K, reset_draws, obs, reward, done);
     else if (act_dtype == PIME_F32)
-        hipLaunchKernelGGL((ph_step_kernel<S, float, false>), grid, dim3(block), 0, s, p, st, (const float*)act,
+        hipLaunchKernelGGL((ph_step_kernel<S, SI, float, OT, false>), grid, dim3(block), 0, s, p, st, (const float*)act,
                            obs_in, K, reset_draws, obs, reward, done);
     else
-        hipLaunchKernelGGL((ph_step_kernel<S, double, false>), grid, dim3(block), 0, s, p, st, (const double*)act,
+        hipLaunchKernelGGL((ph_step_kernel<S, SI, double, OT, false>), grid, dim3(block), 0, s, p, st, (const double*)act,
                            obs_in, K, reset_draws, obs, reward, done);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 
-template <typename S>
-int launch_ph_observe(const PhParams& p, const PhPtrs<S>& st, float* obs, hipStream_t s) {
+template <typename S, typename SI, typename OT>
+int launch_ph_observe(const PhParams& p, const PhPtrs<S, SI>& st, OT* obs, hipStream_t s) {
     int block;
     const dim3 grid = lane_grid(p.n, block);
-    hipLaunchKernelGGL(ph_observe_kernel<S>, grid, dim3(block), 0, s, p, st, obs);
+    hipLaunchKernelGGL((ph_observe_kernel<S, SI, OT>), grid, dim3(block), 0, s, p, st, obs);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 
-template <typename S>
-int launch_wt_reset(const WtParams& p, const WtPtrs<S>& st, const uint8_t* mask, const double* draws, float* obs,
+template <typename S, typename SI, typename OT>
+int launch_wt_reset(const WtParams& p, const WtPtrs<S, SI>& st, const uint8_t* mask, const double* draws, OT* obs,
                     hipStream_t s) {
     int block;
     const dim3 grid = lane_grid(p.n, block);
-    hipLaunchKernelGGL(wt_reset_kernel<S>, grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st, mask, draws, obs);
+    hipLaunchKernelGGL((wt_reset_kernel<S, SI, OT>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st, mask, draws, obs);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 
-template <typename S>
-int launch_wt_step(const WtParams& p, const WtPtrs<S>& st, const void* act, int act_dtype, bool residual,
-                   const float* obs_in, const PriorK& K, const double* noise, const double* reset_draws, float* obs,
-                   float* reward, uint8_t* done, hipStream_t s) {
+template <typename S, typename SI, typename OT>
+int launch_wt_step(const WtParams& p, const WtPtrs<S, SI>& st, const void* act, int act_dtype, bool residual,
+                   const OT* obs_in, const PriorK& K, const double* noise, const double* reset_draws, OT* obs,
+                   OT* reward, uint8_t* done, hipStream_t s) {
     int block;
     const dim3 grid = lane_grid(p.n, block);
     if (residual)
-        hipLaunchKernelGGL((wt_step_kernel<S, float, true>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st,
+        hipLaunchKernelGGL((wt_step_kernel<S, SI, float, OT, true>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st,
                            (const float*)act, obs_in, K, noise, reset_draws, obs, reward, done);
     else if (act_dtype == PIME_F32)
-        hipLaunchKernelGGL((wt_step_kernel<S, float, false>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st,
+        hipLaunchKernelGGL((wt_step_kernel<S, SI, float, OT, false>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st,
                            (const float*)act, obs_in, K, noise, reset_draws, obs, reward, done);
     else
-        hipLaunchKernelGGL((wt_step_kernel<S, double, false>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st,
+        hipLaunchKernelGGL((wt_step_kernel<S, SI, double, OT, false>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st,
                            (const double*)act, obs_in, K, noise, reset_draws, obs, reward, done);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 
-template <typename S>
-int launch_wt_observe(const WtParams& p, const WtPtrs<S>& st, float* obs, hipStream_t s) {
+template <typename S, typename SI, typename OT>
+int launch_wt_observe(const WtParams& p, const WtPtrs<S, SI>& st, OT* obs, hipStream_t s) {
     int block;
     const dim3 grid = lane_grid(p.n, block);
-    hipLaunchKernelGGL(wt_observe_kernel<S>, grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st, obs);
+    hipLaunchKernelGGL((wt_observe_kernel<S, SI, OT>), grid, dim3(block), wt_obs_lds_bytes(p, block), s, p, st, obs);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 
-// explicit instantiations used by abi.hip
-#define PIME_INST(S)                                                                                               \
-    template int launch_ph_reset<S>(const PhParams&, const PhPtrs<S>&, const uint8_t*, const double*, float*,     \
-                                    hipStream_t);                                                                  \
-    template int launch_ph_step<S>(const PhParams&, const PhPtrs<S>&, const void*, int, bool, const float*,       \
-                                   const PriorK&, const double*, float*, float*, uint8_t*, hipStream_t);           \
-    template int launch_ph_observe<S>(const PhParams&, const PhPtrs<S>&, float*, hipStream_t);                     \
-    template int launch_wt_reset<S>(const WtParams&, const WtPtrs<S>&, const uint8_t*, const double*, float*,     \
-                                    hipStream_t);                                                                  \
-    template int launch_wt_step<S>(const WtParams&, const WtPtrs<S>&, const void*, int, bool, const float*,       \
-                                   const PriorK&, const double*, const double*, float*, float*, uint8_t*,          \
-                                   hipStream_t);                                                                   \
-    template int launch_wt_observe<S>(const WtParams&, const WtPtrs<S>&, float*, hipStream_t);
-PIME_INST(double)
-PIME_INST(float)
+// explicit instantiations used by abi.hip: (S, SI, OT) = f64 state, f32 state, f32 state + binary16 I with float / binary16 outputs
+#define PIME_INST(S, SI, OT)                                                                                           \
+    template int launch_ph_reset<S, SI, OT>(const PhParams&, const PhPtrs<S, SI>&, const uint8_t*, const double*, OT*, \
+                                            hipStream_t);                                                              \
+    template int launch_ph_step<S, SI, OT>(const PhParams&, const PhPtrs<S, SI>&, const void*, int, bool, const OT*,   \
+                                           const PriorK&, const double*, OT*, OT*, uint8_t*, hipStream_t);             \
+    template int launch_ph_observe<S, SI, OT>(const PhParams&, const PhPtrs<S, SI>&, OT*, hipStream_t);                \
+    template int launch_wt_reset<S, SI, OT>(const WtParams&, const WtPtrs<S, SI>&, const uint8_t*, const double*, OT*, \
+                                            hipStream_t);                                                              \
+    template int launch_wt_step<S, SI, OT>(const WtParams&, const WtPtrs<S, SI>&, const void*, int, bool, const OT*,   \
+                                           const PriorK&, const double*, const double*, OT*, OT*, uint8_t*,            \
+                                           hipStream_t);                                                               \
+    template int launch_wt_observe<S, SI, OT>(const WtParams&, const WtPtrs<S, SI>&, OT*, hipStream_t);
+PIME_INST(double, double, float)
+PIME_INST(float, float, float)
+PIME_INST(float, half_t, float)
+PIME_INST(float, half_t, half_t)
 
 }  // namespace pime

@@ -16,10 +16,15 @@ struct PhParams {
 
 // S = storage/arithmetic type of the "slow" state words (double: PIME_STATE_F64, float: PIME_STATE_MIXED).
 // x and the ZOH plant stay float64 in both modes so that k = rint(C*x*1e5) is the reference's index.
-template <typename S>
+// SI = storage type of the integrated error I: S, or IEEE binary16 under S = float (PIME_STATE_MIXED16: BASELINE.json config
+// 5's "fp16 state" = SURVEY §8(d) cfg 5 "fp16 storage for obs / reward / I, f32 math, f64 x"; binary16 is a storage format
+// here, never an arithmetic type).
+using half_t = _Float16;
+template <typename S, typename SI = S>
 struct PhPtrs {
     double *x, *A, *B, *C, *qww, *qc;
-    S *I, *r, *last_a;
+    S *r, *last_a;
+    SI* I;
     int32_t *t, *episode;
     const S* table;
 };
@@ -34,9 +39,10 @@ struct WtParams {
     double a1_lo, a1_hi, a2_lo, a2_hi, kp_lo, kp_hi, h_lo, h_hi, r_lo, r_hi;
 };
 
-template <typename S>
+template <typename S, typename SI = S>
 struct WtPtrs {
-    S *h1, *h2, *r, *I, *a1, *a2, *kp;
+    S *h1, *h2, *r, *a1, *a2, *kp;
+    SI* I;
     // Stacking variant only: the last num_stack frames [h1, h2, r] as a RING in SoA order, frames[(slot * 3 + c) * n + lane],
     // and the per-lane slot of the OLDEST frame (the deque's left end, nonlinear_watertank.py:1143-1144): a step overwrites that
     // slot and advances head, instead of shifting 3 (S - 1) words per lane; every access is a contiguous wave-wide segment.

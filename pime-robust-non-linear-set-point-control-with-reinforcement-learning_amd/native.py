@@ -15,7 +15,7 @@ CSRC = os.path.join(PACKAGE_DIR, "csrc")
 OK = 0
 ABI_VERSION = 8
 ENV_PH, ENV_WT = 0, 1
-STATE_F64, STATE_MIXED = 0, 1
+STATE_F64, STATE_MIXED, STATE_MIXED16 = 0, 1, 2
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
 F32, F64 = 0, 1
 MLP_CRITIC, MLP_PLAIN_ACTOR, MLP_MODULAR_ACTOR = 0, 1, 2
@@ -87,6 +87,9 @@ _SIGNATURES = {
     "pime_env_reset": (C.c_int, [_vp, _u8p, _vp, _vp, _vp]),
     "pime_env_step": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pime_env_step_residual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "pime_env_reset_h": (C.c_int, [_vp, _u8p, _vp, _vp, _vp]),
+    "pime_env_step_h": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "pime_env_step_residual_h": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pime_env_read_field": (C.c_int, [_vp, _i32, _vp, _vp]),
     "pime_env_write_field": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "pime_env_set_punish": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),

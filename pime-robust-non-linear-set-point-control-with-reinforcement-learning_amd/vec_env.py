@@ -20,7 +20,7 @@ import torch
 
 from . import gym_compat, native
 
-_STATE_MODES = {"f64": native.STATE_F64, "mixed": native.STATE_MIXED}
+_STATE_MODES = {"f64": native.STATE_F64, "mixed": native.STATE_MIXED, "mixed16": native.STATE_MIXED16}
 
 
 # ------------------------------------------------------------------------------------------------ draw sources
@@ -240,6 +240,65 @@ class VecControlEnv:
                                                       native.ptr(noise), int(auto_reset), native.ptr(reset_draws),
                                                       native.ptr(obs), native.ptr(rew), native.ptr(done), self._stream()),
                      "pime_env_step_residual")
+        return obs, rew, done
+
+    # -- binary16 observation / reward buffers (state_mode "mixed16": BASELINE.json config 5) -----------------------------
+    def _half_buffers(self):
+        if getattr(self, "_obs_h", None) is None:
+            if self.cfg.state_mode != native.STATE_MIXED16:
+                raise native.PimeError("binary16 observations need state_mode='mixed16'")
+            N, D = self.num_envs, self.obs_dim
+            self._obs_h = torch.zeros((N, D), dtype=torch.float16, device=self.device)
+            self._reward_h = torch.zeros((N,), dtype=torch.float16, device=self.device)
+        return self._obs_h, self._reward_h
+
+    def reset_h(self, mask=None, out=None):
+        """`reset` writing float16 observations (pime_env_reset_h)."""
+        obs = self._half_buffers()[0] if out is None else out
+        assert obs.dtype == torch.float16
+        if mask is None:
+            lanes, mask_dev = range(self.num_envs), None
+            self._t_all, self._t_lanes = 0, None
+        else:
+            m = torch.as_tensor(mask).to(torch.uint8)
+            lanes = np.nonzero(m.cpu().numpy())[0]
+            mask_dev = m.to(self.device)
+            self._lane_steps()[lanes] = 0
+        draws = self._dev64(self.draws.reset_draws(self, lanes)) if self.draws.injects else None
+        native.check(self._lib.pime_env_reset_h(self._h, native.ptr(mask_dev), native.ptr(draws), native.ptr(obs),
+                                                self._stream()), "pime_env_reset_h")
+        self._was_reset = True
+        return obs
+
+    def step_h(self, action, auto_reset=True, out_obs=None, out_reward=None, out_done=None):
+        """`step` with float16 observation / reward buffers (pime_env_step_h); action float32 [N]."""
+        a = action.reshape(-1).to(torch.float32).contiguous()
+        obs_h, rew_h = self._half_buffers()
+        obs = obs_h if out_obs is None else out_obs
+        rew = rew_h if out_reward is None else out_reward
+        done = self.done if out_done is None else out_done
+        noise, reset_draws = self._pre_step(auto_reset)
+        native.check(self._lib.pime_env_step_h(self._h, native.ptr(a), native.ptr(noise), int(auto_reset), native.ptr(reset_draws),
+                                               native.ptr(obs), native.ptr(rew), native.ptr(done), self._stream()),
+                     "pime_env_step_h")
+        return obs, rew, done
+
+    def step_residual_h(self, a_pre, obs_in, priorK=None, auto_reset=True, out_obs=None, out_reward=None, out_done=None):
+        """`step_residual` with float16 buffers: obs_in is the float16 observation the policy saw (pime_env_step_residual_h)."""
+        a = a_pre.reshape(-1).to(torch.float32).contiguous()
+        obs_in = obs_in.contiguous()
+        assert obs_in.dtype == torch.float16 and tuple(obs_in.shape) == (self.num_envs, self.obs_dim)
+        k = np.ascontiguousarray(-self.K if priorK is None else np.asarray(priorK, dtype=np.float64).reshape(-1))
+        obs_h, rew_h = self._half_buffers()
+        obs = obs_h if out_obs is None else out_obs
+        assert obs.data_ptr() != obs_in.data_ptr(), "obs_in and the output obs must not alias"
+        rew = rew_h if out_reward is None else out_reward
+        done = self.done if out_done is None else out_done
+        noise, reset_draws = self._pre_step(auto_reset)
+        native.check(self._lib.pime_env_step_residual_h(self._h, native.ptr(a), native.ptr(obs_in), native.ptr(k),
+                                                        native.ptr(noise), int(auto_reset), native.ptr(reset_draws),
+                                                        native.ptr(obs), native.ptr(rew), native.ptr(done), self._stream()),
+                     "pime_env_step_residual_h")
         return obs, rew, done
 
     @property

@@ -1,0 +1,85 @@
+"""BASELINE.json config 5, the part one GPU can run: a mixed pH + water-tank batch with domain-randomised (1.5x wider) ensemble
+ranges and "fp16 state" -- `state_mode="mixed16"`: the integrated error stored as IEEE binary16, observations and rewards
+written as binary16 through the *_h entry points, float32 / float64 arithmetic (SURVEY.md §8(d) cfg 5).
+
+Checked against the fp64 oracle stepped with the SAME env actions.  Tolerances (stated in include/pime_hip.h): a stored word
+is the float32 value rounded to nearest binary16 (relative 2^-11); the pH dynamics (x, LUT index) and the tank levels are not
+stored in binary16, so y / h1 / h2 / r stay within ONE binary16 rounding of the oracle on every step; the integrated error
+accumulates one rounding per step (<= 0.008 at |I| <= 25), so I is compared with a random-walk bound; the reward with the
+rounding of its own magnitude."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H = 2.0 ** -11     # binary16 relative rounding
+
+
+def test_mixed_ph_and_tank_batch_in_fp16_storage():
+    import oracle
+    from pime_amd import gym_control
+    N, seed = 2048, 9
+    wide = dict(qww_V=(0.0025, 0.0175), qc_V=(0.00125, 0.00275))              # 1.5x the registered widths
+    wide_wt = dict(a1=(0.001275, 0.002625), a2=(0.001275, 0.002625), Kp=(0.045, 0.195))
+    ph = gym_control.make_vec(gym_control.PH_V35, N, device=DEV, state_mode="mixed16", seed=seed, **wide)
+    wt = gym_control.make_vec(gym_control.WT_INTEGRATOR, N, device=DEV, state_mode="mixed16", seed=seed, reward_type="distance",
+                              max_step=60, **wide_wt)
+    rph = oracle.OraclePH(N, oracle.ph_table(), seed=seed)
+    rph.set_ranges(wide["qww_V"], wide["qc_V"])
+    rwt = oracle.OracleWT(N, max_steps=60, reward_type="distance", seed=seed)
+    rwt.set_ranges(wide_wt["a1"], wide_wt["a2"], wide_wt["Kp"])
+    s_ph, s_wt = torch.cuda.Stream(), torch.cuda.Stream()      # the two halves of the batch advance side by side
+    with torch.cuda.stream(s_ph):
+        o_ph = ph.reset_h().clone()
+    with torch.cuda.stream(s_wt):
+        o_wt = wt.reset_h().clone()
+    torch.cuda.synchronize()
+    assert o_ph.dtype == torch.float16 and o_wt.dtype == torch.float16
+    e_ph, e_wt = rph.reset(), rwt.reset()
+    np.testing.assert_array_equal(o_ph.cpu().numpy(), e_ph.astype(np.float16))     # float32 oracle obs rounded once
+    np.testing.assert_array_equal(o_wt.cpu().numpy(), e_wt.astype(np.float16))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    Kph, Kwt = -ph.K, -wt.K
+    for t in range(60):
+        # prior controller + exploration residual, computed from the ORACLE's float observation so both sides get the same action
+        a_ph = np.tanh(torch.randn(N, generator=g).numpy() * 0.6) + e_ph.astype(np.float64) @ Kph
+        a_wt = np.tanh(torch.randn(N, generator=g).numpy() * 0.6) + e_wt.astype(np.float64) @ Kwt
+        with torch.cuda.stream(s_ph):
+            if t < 50:
+                got_ph = [x.clone() for x in ph.step_h(torch.as_tensor(a_ph, dtype=torch.float32, device=DEV), auto_reset=False)]
+        with torch.cuda.stream(s_wt):
+            got_wt = [x.clone() for x in wt.step_h(torch.as_tensor(a_wt, dtype=torch.float32, device=DEV), auto_reset=False)]
+        torch.cuda.synchronize()
+        if t < 50:
+            e_ph, _, r_ph, d_ph = rph.step(a_ph.astype(np.float32).astype(np.float64))
+            o, r, d = (x.cpu().numpy().astype(np.float64) for x in got_ph)
+            # y: same LUT cell except where the float32 action moved C*x*1e5 across a rounding boundary (one cell = 0.0296)
+            dy = np.abs(o[:, 0] - e_ph[:, 0])
+            assert (dy <= H * np.abs(e_ph[:, 0]) + 0.0297).all() and (dy <= H * np.abs(e_ph[:, 0]) + 1e-6).mean() > 0.97
+            np.testing.assert_allclose(o[:, 1], e_ph[:, 1], rtol=H, atol=0)
+            ok = dy <= H * np.abs(e_ph[:, 0]) + 1e-6
+            bound_I = 0.008 * np.sqrt(t + 1) * 3 + H * np.abs(e_ph[:, 2])           # one binary16 rounding per step, random walk
+            assert (np.abs(o[ok, 2] - e_ph[ok, 2]) <= bound_I[ok]).all()
+            np.testing.assert_allclose(r[ok], r_ph[ok], rtol=2 * H, atol=1e-3)
+            assert d.astype(bool).tolist() == d_ph.tolist()
+            rph.set("I", o[:, 2])            # continue from the stored (rounded) integrator, as the device does
+        e_wt, _, r_wt, d_wt = rwt.step(a_wt.astype(np.float32).astype(np.float64))
+        o, r, d = (x.cpu().numpy().astype(np.float64) for x in got_wt)
+        np.testing.assert_allclose(o[:, :3], e_wt[:, :3], rtol=H, atol=2e-3)           # levels: f32 Euler + one rounding
+        assert (np.abs(o[:, 3] - e_wt[:, 3]) <= 0.008 * np.sqrt(t + 1) * 3 + H * np.abs(e_wt[:, 3]) + 2e-3 * (t + 1)).all()
+        np.testing.assert_allclose(r, r_wt, rtol=2 * H, atol=3e-3)
+        assert d.astype(bool).tolist() == d_wt.tolist()
+        for name, col in (("h1", 0), ("h2", 1), ("I", 3)):   # re-sync the oracle: per-step errors must not compound
+            rwt.set(name, wt.get_field(name) if name != "I" else o[:, 3])
+        e_wt = np.stack([rwt.get("h1"), rwt.get("h2"), rwt.get("r"), rwt.get("I")], axis=1).astype(np.float32)
+    # field I/O of the binary16 word, and the float32 entry points on the same handle
+    I_dev = ph.get_field("I")
+    assert np.array_equal(I_dev, I_dev.astype(np.float16).astype(np.float64))
+    ph.set_field("I", np.full(N, 1.2345678))
+    assert np.allclose(ph.get_field("I"), np.float16(1.2345678))
+    obs32 = ph.observe()
+    assert obs32.dtype == torch.float32 and torch.allclose(obs32[:, 2], torch.full((N,), float(np.float16(1.2345678)), device=DEV))
+    with pytest.raises(Exception):
+        gym_control.make_vec(gym_control.PH_V35, 8, device=DEV, state_mode="mixed").reset_h()
+    ph.close(); wt.close()

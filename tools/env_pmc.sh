@@ -19,16 +19,17 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != c or "step_kernel" not in r["Kernel_Name"]:
             continue
-        k = (r["Kernel_Name"].split("(")[0][:60], int(r["Grid_Size"]))
+        k = (r["Kernel_Name"].split("(")[0][:90], int(r["Grid_Size"]))
         res[k][c] += float(r["Counter_Value"])
         if c == "FETCH_SIZE":
             res[k]["launches"] += 1
             res[k]["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-ALG = {"ph": {"contract_76B": 76, "kernel_97B": 97}, "wt": {"contract_84B": 84, "kernel_93B": 93}}
+ALG = {"ph": {"contract_76B": 76, "kernel_97B": 97}, "wt": {"contract_84B": 84, "kernel_93B": 93},
+       "ph16": {"contract_64B": 64, "kernel_79B": 79}}   # binary16 I / obs / reward (state_mode mixed16), f64 x
 out = []
 for (name, lanes), v in sorted(res.items()):
     n = max(v["launches"], 1)
-    kind = "ph" if "ph_step" in name else "wt"
+    kind = ("ph16" if "_Float16" in name else "ph") if "ph_step" in name else "wt"
     rd, wr, us = 2 * v["FETCH_SIZE"] / n * 1024, v["WRITE_SIZE"] / n * 1024, v["ns"] / n / 1e3
     row = {"kernel": name, "lanes": lanes, "launches": v["launches"], "us_per_launch_profiled": us,
            "hbm_read_bytes_per_lane": rd / lanes, "hbm_write_bytes_per_lane": wr / lanes,

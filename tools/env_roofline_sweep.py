@@ -11,13 +11,17 @@ import torch  # noqa: E402
 
 from pime_amd import gym_control  # noqa: E402
 
-BYTES = {"ph": 97, "wt": 93}
+BYTES = {"ph": 97, "wt": 93, "ph16": 79}   # ph16: state_mode "mixed16" (binary16 I / obs / reward), DESIGN.md §4
 PEAK = 8000.0
 
-for kind, env_id, kw in (("ph", gym_control.PH_V35, {}), ("wt", gym_control.WT_INTEGRATOR, dict(reward_type="distance"))):
+for kind, env_id, kw in (("ph", gym_control.PH_V35, {}), ("wt", gym_control.WT_INTEGRATOR, dict(reward_type="distance")),
+                         ("ph16", gym_control.PH_V35, {})):
     for n in (16384, 65536, 262144, 1 << 20, 1 << 22):
-        env = gym_control.make_vec(env_id, n, device="cuda:0", state_mode="mixed", seed=0, **kw)
-        obs_a = env.reset().clone()
+        half = kind == "ph16"
+        env = gym_control.make_vec(env_id, n, device="cuda:0", state_mode="mixed16" if half else "mixed", seed=0, **kw)
+        if half:
+            env.step_residual = env.step_residual_h
+        obs_a = (env.reset_h() if half else env.reset()).clone()
         obs_b = torch.empty_like(obs_a)
         a_pre = torch.randn(n, device="cuda:0") * 0.6
         for _ in range(5):
