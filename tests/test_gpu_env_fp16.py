@@ -18,13 +18,13 @@ H = 2.0 ** -11     # binary16 relative rounding
 
 def test_mixed_ph_and_tank_batch_in_fp16_storage():
     import oracle
-    from pime_amd import gym_control
+    from pime_amd.vec_env import VecPH, VecWaterTank
     N, seed = 2048, 9
-    wide = dict(qww_V=(0.0025, 0.0175), qc_V=(0.00125, 0.00275))              # 1.5x the registered widths
-    wide_wt = dict(a1=(0.001275, 0.002625), a2=(0.001275, 0.002625), Kp=(0.045, 0.195))
-    ph = gym_control.make_vec(gym_control.PH_V35, N, device=DEV, state_mode="mixed16", seed=seed, **wide)
-    wt = gym_control.make_vec(gym_control.WT_INTEGRATOR, N, device=DEV, state_mode="mixed16", seed=seed, reward_type="distance",
-                              max_step=60, **wide_wt)
+    # 1.5x the registered widths; the pH range keeps C*x inside the 100 000-entry titration table (the reference raises beyond it)
+    wide = dict(qww_V=(0.0045, 0.0165), qc_V=(0.00125, 0.00275))
+    wide_wt = dict(a1=(0.0012, 0.0027), a2=(0.0012, 0.0027), Kp=(0.045, 0.195))
+    ph = VecPH(N, device=DEV, state_mode="mixed16", seed=seed, **wide)
+    wt = VecWaterTank(N, device=DEV, state_mode="mixed16", seed=seed, reward_type="distance", max_step=60, **wide_wt)
     rph = oracle.OraclePH(N, oracle.ph_table(), seed=seed)
     rph.set_ranges(wide["qww_V"], wide["qc_V"])
     rwt = oracle.OracleWT(N, max_steps=60, reward_type="distance", seed=seed)
@@ -81,5 +81,5 @@ def test_mixed_ph_and_tank_batch_in_fp16_storage():
     obs32 = ph.observe()
     assert obs32.dtype == torch.float32 and torch.allclose(obs32[:, 2], torch.full((N,), float(np.float16(1.2345678)), device=DEV))
     with pytest.raises(Exception):
-        gym_control.make_vec(gym_control.PH_V35, 8, device=DEV, state_mode="mixed").reset_h()
+        VecPH(8, device=DEV, state_mode="mixed").reset_h()
     ph.close(); wt.close()
