@@ -54,6 +54,8 @@ def make_vec(env_id, num_envs, device="cuda", **overrides):
     spec = gym.spec(env_id)
     kw = dict(spec._kwargs)
     vec_kw = {k: overrides.pop(k) for k in ("state_mode", "seed", "env_offset", "draws", "resample_every") if k in overrides}
+    if env_id.startswith("PH1D"):   # ensemble ranges: class constants in the reference (ph.py:357-358), sweepable here
+        vec_kw.update({k: overrides.pop(k) for k in ("qww_V", "qc_V") if k in overrides})
     kw.update(overrides)
     if env_id.startswith("PH1D"):
         return VecPH(num_envs, device=device, reward_type=kw["reward_type"], max_episode_steps=kw["max_episode_steps"],
