@@ -479,8 +479,8 @@ def main():
                         "achieved": ro_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ro_tf / F32_MFMA_PEAK_TFLOPS,
                         "traffic": None, "avg_launch_ms": ms_env,
                         "note": "one 32-lane tile per SIMD, serial 512-MFMA chain per env step: latency bound by design; the "
-                                "step-per-launch env kernels reach 5.0 TB/s (pH) / 2.5 TB/s (WT) at >= 1M lanes, "
-                                "profiles/r01_e_env_roofline_sweep.jsonl"}
+                                "step-per-launch env kernels move 5.1 TB/s (pH) / 3.1 TB/s (WT) of PMC-counted HBM traffic at 4M "
+                                "lanes, profiles/r02_p_env_pmc.json"}
     else:
         n_env, ms_env = ks["ph_step_kernel (fused residual)"]
         env_gbs = PH_STEP_BYTES * LANES / (ms_env * 1e-3) / 1e9

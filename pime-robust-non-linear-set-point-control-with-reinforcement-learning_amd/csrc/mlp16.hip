@@ -40,7 +40,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int k16Threads = 256;
 constexpr int k16Waves = 4;     // one wave per SIMD; a second workgroup on the CU supplies each SIMD's second wave
 constexpr int k16Group = 64;    // samples per workgroup pass: 4 tiles of 16
-constexpr int k16Rounds = k16Waves / 2;
 
 // ---- images ------------------------------------------------------------------------------------------------------------
 // MFMA layer image [k-step][quad q][lane][4]: element e of lane (i, g) of quad q at k-step ks is W[16(4q + e) + i][k(ks, g)],
@@ -735,12 +734,8 @@ int grid16(int B, int md, int D) {
 template <int T, int ACT>
 static int launch_fwd16(const float* x, int M, int D, const float* img, float* out, hipStream_t s) {
     const size_t lds_bytes = sizeof(float) * (size_t)lds16<T>(D, false).total;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp16_forward_kernel<T, ACT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsLimit lds_limit;  // per instantiation
+    PIME_RAISE_LDS(lds_limit, (mlp16_forward_kernel<T, ACT>), 160 * 1024);
     const int ngroups = (M + k16Group - 1) / k16Group;
     const int cap = 256 * wgs_per_cu<T>(lds_bytes);
     hipLaunchKernelGGL((mlp16_forward_kernel<T, ACT>), dim3(ngroups < cap ? ngroups : cap), dim3(k16Threads), lds_bytes, s, x, M,
@@ -763,12 +758,8 @@ template <int T, bool ACTOR>
 static int launch_grad16(const PpoArgs& a, hipStream_t s) {
     const size_t lds_bytes = sizeof(float) * (size_t)lds16<T>(a.D, true).total;
     PIME_REQUIRE(lds_bytes <= 160 * 1024, "16-tile PPO kernel needs %zu B of LDS", lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo16_kernel<T, ACTOR>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsLimit lds_limit;  // per instantiation
+    PIME_RAISE_LDS(lds_limit, (ppo16_kernel<T, ACTOR>), 160 * 1024);
     hipLaunchKernelGGL((ppo16_kernel<T, ACTOR>), dim3(grid16(a.B, T * 16, a.D)), dim3(k16Threads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;

@@ -121,12 +121,8 @@ template <int T, int KIND>
 static int launch_fwd(const float* x, int M, int D, int Di, const float* packed, float* out, hipStream_t s) {
     const MlpLayout L = mlp_layout(KIND, D, Di, T * 32);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_forward_kernel<T, KIND>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsLimit lds_limit;  // per instantiation
+    PIME_RAISE_LDS(lds_limit, (mlp_forward_kernel<T, KIND>), 160 * 1024);
     PIME_REQUIRE(lds_bytes <= 160 * 1024, "packed MLP image (%zu B) exceeds the 160 KB LDS", lds_bytes);
     const int ntiles = (M + 31) / 32, waves = kMlpThreads / 64;
     int grid = (ntiles + waves - 1) / waves;

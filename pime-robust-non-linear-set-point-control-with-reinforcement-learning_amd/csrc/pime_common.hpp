@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -27,6 +28,24 @@ void set_error(const char* fmt, ...);
             ::pime::set_error(__VA_ARGS__); \
             return PIME_ERR_ARG;         \
         }                                \
+    } while (0)
+
+// hipFuncSetAttribute acts on the current device: one bit per device ordinal records where a kernel's dynamic-LDS limit has
+// been raised, so that a process driving several GPUs raises it on each (one static LdsLimit per kernel instantiation).
+struct LdsLimit {
+    std::atomic<unsigned long long> raised{0};
+};
+
+#define PIME_RAISE_LDS(once, kernel, bytes)                                                                     \
+    do {                                                                                                        \
+        int _dev = 0;                                                                                           \
+        PIME_HIP_TRY(hipGetDevice(&_dev));                                                                      \
+        const unsigned long long _bit = 1ull << (_dev & 63);                                                    \
+        if (!((once).raised.load(std::memory_order_relaxed) & _bit)) {                                          \
+            PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                             \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));        \
+            (once).raised.fetch_or(_bit, std::memory_order_relaxed);                                            \
+        }                                                                                                       \
     } while (0)
 
 // ---- Philox4x32-10 (Salmon et al., SC'11).  Counter layout: (global env id, episode, slot, stream). -------

@@ -1106,12 +1106,8 @@ static int launch_fused(const PpoArgs& a, hipStream_t s) {
     const FusedLds F = fused_lds(KIND, a.D, a.Di, T);
     const size_t lds_bytes = sizeof(float) * (size_t)F.total;
     PIME_REQUIRE(lds_bytes <= 160 * 1024, "fused PPO kernel needs %zu B of LDS (> 160 KB) for state_dim %d", lds_bytes, a.D);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_fused_kernel<T, KIND>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsLimit lds_limit;  // per instantiation
+    PIME_RAISE_LDS(lds_limit, (ppo_fused_kernel<T, KIND>), 160 * 1024);
     const int grid = fused_grid(a.B);
     hipLaunchKernelGGL((ppo_fused_kernel<T, KIND>), dim3(grid), dim3(kFusedThreads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());

@@ -544,12 +544,8 @@ static int launch_net(const PpoArgs& a, hipStream_t s) {
     const BwdLayout Lb = bwd_layout(KIND, a.D, a.Di, T * 32);
     const size_t lds_bytes = sizeof(float) * (size_t)(L.total > Lb.total ? L.total : Lb.total);
     PIME_REQUIRE(lds_bytes <= 160 * 1024, "PPO net image (%zu B) exceeds the 160 KB LDS", lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_fwd_bwd_kernel<T, KIND>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsLimit lds_limit;  // per instantiation
+    PIME_RAISE_LDS(lds_limit, (ppo_fwd_bwd_kernel<T, KIND>), 160 * 1024);
     const int ntiles = (a.B + 31) / 32, waves = kTrainThreads / 64;
     int grid = (ntiles + waves - 1) / waves;
     if (grid > 256) grid = 256;
@@ -620,15 +616,11 @@ int build_dw_jobs(int kind, int md, const PpoArgs& a, const float* const* params
 }
 
 int launch_dw(const DwArgs& args, int B, hipStream_t s) {
-    static bool attr_set = false;
+    static LdsLimit lds_limit;  // per instantiation
     int din_max = 1;
     for (int i = 0; i < args.njobs; ++i) din_max = args.job[i].Din > din_max ? args.job[i].Din : din_max;
     const size_t lds_bytes = sizeof(float) * (size_t)dw_lds_floats(din_max);
-    if (!attr_set) {
-        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_dw_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * dw_lds_floats(kDwMaxDin))));
-        attr_set = true;
-    }
+    PIME_RAISE_LDS(lds_limit, ppo_dw_kernel, (int)(sizeof(float) * dw_lds_floats(kDwMaxDin)));
     const int ntiles = (B + 31) / 32;
     const int chunks = (ntiles + args.tiles_per_wg - 1) / args.tiles_per_wg;
     hipLaunchKernelGGL(ppo_dw_kernel, dim3(chunks, args.njobs), dim3(kDwThreads), lds_bytes, s, args);

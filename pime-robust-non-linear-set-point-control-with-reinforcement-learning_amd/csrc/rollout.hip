@@ -163,12 +163,8 @@ template <int T, int KIND, int ENV, int STACK>
 static int launch_rollout_t(const RolloutArgs& a, hipStream_t s) {
     const MlpLayout L = mlp_layout(KIND, ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), ENV == 2 ? 0 : 1, T * 32);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PIME_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<T, KIND, ENV, STACK>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsLimit lds_limit;  // per instantiation
+    PIME_RAISE_LDS(lds_limit, (rollout_kernel<T, KIND, ENV, STACK>), 160 * 1024);
     const int tiles = (a.n + 31) / 32, per_wg = kRolloutThreads / 64;
     hipLaunchKernelGGL((rollout_kernel<T, KIND, ENV, STACK>), dim3((tiles + per_wg - 1) / per_wg), dim3(kRolloutThreads),
                        lds_bytes, s, a);
