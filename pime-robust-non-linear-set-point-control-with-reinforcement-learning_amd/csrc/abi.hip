@@ -794,9 +794,9 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
     static const bool tracing = std::getenv("PIME_FUSED_TRACE") != nullptr;  // tuning aid: phase marks of one workgroup
     static long long* trace_dev = nullptr;
     if (tracing && !trace_dev) {
-        PIME_HIP_TRY(hipMalloc(&trace_dev, 2 * 64 * sizeof(long long)));
+        PIME_HIP_TRY(hipMalloc(&trace_dev, (2 * 64 + 2 * 1024) * sizeof(long long)));   // marks of one workgroup + [net][workgroup][start, end]
     }
-    if (tracing) PIME_HIP_TRY(hipMemsetAsync(trace_dev, 0, 2 * 64 * sizeof(long long), s));
+    if (tracing) PIME_HIP_TRY(hipMemsetAsync(trace_dev, 0, (2 * 64 + 2 * 1024) * sizeof(long long), s));
     if (mode[0] == SPLIT) PIME_HIP_TRY(hipMemsetAsync(moments, 0, 2 * sizeof(double), s));  // atomics accumulate into it
     if (b->flags & PIME_PPO_OVERWRITE_GRADS) {   // the atomics of the split pipeline need zeroed targets
         for (int k = 0; k < 2; ++k) {
@@ -828,6 +828,7 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
         for (int i = 0; i < np; ++i) a.grad[i] = n->grads[i];
         a.trace = (tracing && mode[k] != SPLIT) ? trace_dev + 64 * k : nullptr;
         a.trace_wg = tracing ? std::atoi(std::getenv("PIME_FUSED_TRACE")) : 0;
+        a.trace_span = a.trace ? trace_dev + 128 + 1024 * k : nullptr;
         int psize[12];
         if (mode[k] == F16) {
             a.slab = n->workspace;
@@ -851,7 +852,7 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
         if (int rc = launch_dw(dw, b->B, s)) return rc;
     }
     if (tracing && any_slab) {
-        long long t[128];
+        static long long t[128 + 2048];
         PIME_HIP_TRY(hipStreamSynchronize(s));
         PIME_HIP_TRY(hipMemcpy(t, trace_dev, sizeof(t), hipMemcpyDeviceToHost));
         for (int k = 0; k < 2; ++k) {
@@ -861,6 +862,22 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
             for (int i = 32; i < 40; ++i)
                 if (t[64 * k + i]) std::fprintf(stderr, " c%d=%lld", i - 32, t[64 * k + i]);
             std::fprintf(stderr, "\n");
+            // every workgroup's start / end (100 MHz wall clock): launch skew, the slowest workgroup, the whole span
+            const long long* sp = t + 128 + 1024 * k;
+            long long s0 = 0, s1 = 0, e0 = 0, e1 = 0, dmin = 0, dmax = 0;
+            int n = 0;
+            for (int w = 0; w < 512; ++w) {
+                if (!sp[2 * w] || !sp[2 * w + 1]) continue;
+                const long long st = sp[2 * w], en = sp[2 * w + 1], d = en - st;
+                if (!n) { s0 = s1 = st; e0 = e1 = en; dmin = dmax = d; }
+                s0 = st < s0 ? st : s0; s1 = st > s1 ? st : s1; e0 = en < e0 ? en : e0; e1 = en > e1 ? en : e1;
+                dmin = d < dmin ? d : dmin; dmax = d > dmax ? d : dmax;
+                ++n;
+            }
+            if (n)
+                std::fprintf(stderr, "[pime trace] %s: %d workgroups: starts spread %.1f us, per-workgroup time %.1f .. %.1f us, "
+                             "first start -> last end %.1f us\n", k ? "actor " : "critic", n, (s1 - s0) * 0.01, dmin * 0.01, dmax * 0.01,
+                             (e1 - s0) * 0.01);
         }
     }
     if (any_slab) {

@@ -486,6 +486,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     const int Do = a.D - a.Di;
 
     PIME_MARK(0);
+    if (a.trace_span && threadIdx.x == 0 && blockIdx.x < 512) a.trace_span[2 * blockIdx.x] = wall_clock64();
     const float asl = CRITIC ? 0.f : a.a_std_log[0];
     for (int e = tid; e < kFusedWaves * md; e += kFusedThreads) hacc[e] = 0.f;
     // small segments live in LDS for the whole kernel.  All their loads are issued before the first LDS write: one
@@ -845,6 +846,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     }
 
     PIME_MARK(12);
+    if (a.trace_span && threadIdx.x == 0 && blockIdx.x < 512) a.trace_span[2 * blockIdx.x + 1] = wall_clock64();
     // ---- workgroup totals of the scalar sums, combined in a fixed order (the slabs make the gradients reproducible
     // bit for bit; only the loss sums, which are for logging, use atomics)
     __syncthreads();

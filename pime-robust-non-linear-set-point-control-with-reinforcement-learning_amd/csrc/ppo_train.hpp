@@ -23,6 +23,7 @@ struct PpoArgs {
     float* g_std;      // actor: gradient of a_std_log (accumulated)
     int stagger;       // start delay of waves 4-7 in units of s_sleep(127) (8128 cycles)
     int trace_wg;      // workgroup whose marks are recorded
+    long long* trace_span;  // tuning aid: [workgroup][2] start / end wall clock of every workgroup
     long long* trace;  // tuning aid (PIME_FUSED_TRACE): wall-clock marks of workgroup 0 / wave 0, NULL in production
     float* grad[12];   // split pipeline: gradient tensors in nn.Linear (W, b) order, accumulated with atomics
     float* slab;       // fused kernel: per-workgroup partial gradients [gridDim.x][slab_stride] (slab_layout order)

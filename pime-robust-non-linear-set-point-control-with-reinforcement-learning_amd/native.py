@@ -9,7 +9,7 @@ import subprocess
 
 from ._pkg import PACKAGE_DIR
 
-LIB_PATH = os.path.join(PACKAGE_DIR, "libpime_hip.so")
+LIB_PATH = os.environ.get("PIME_LIB_PATH") or os.path.join(PACKAGE_DIR, "libpime_hip.so")   # override: kernel A/B runs only
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
