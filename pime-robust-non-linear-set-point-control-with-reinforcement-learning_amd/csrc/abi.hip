@@ -861,6 +861,8 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
                 if (t[64 * k + i]) std::fprintf(stderr, " m%d=%.1f", i, (double)(t[64 * k + i] - t[64 * k]) * 0.01);
             for (int i = 32; i < 40; ++i)
                 if (t[64 * k + i]) std::fprintf(stderr, " c%d=%lld", i - 32, t[64 * k + i]);
+            for (int i = 40; i < 56; ++i)   // sub-marks of one job (16-tile family: the passes of the first sliced weight gradient)
+                if (t[64 * k + i]) std::fprintf(stderr, " p%d=%.1f", i - 40, (double)(t[64 * k + i] - t[64 * k]) * 0.01);
             std::fprintf(stderr, "\n");
             // every workgroup's start / end (100 MHz wall clock): launch skew, the slowest workgroup, the whole span
             const long long* sp = t + 128 + 1024 * k;

@@ -401,6 +401,132 @@ __device__ __forceinline__ void dw16(float* __restrict__ X, int lane, int wave, 
     }
 }
 
+// ---- width 256: the weight gradient of a T x T layer with the operands published ONCE ---------------------------------------
+// dw16<16, 16, 2> re-publishes both operands in each of its four passes (two rounds each: the 64-row image of both operands does
+// not fit beside nothing), and in a round only two of the four waves publish while the others wait at the barrier: with one
+// wave per SIMD and ~30 SIMD cycles per ds_write_b128 (tools/dw_round_bench.hip) that was ~45 % of the job (r02_i trace: 30-33 us
+// per job against 13.7 us of MFMAs).  Here pass p needs the SAME 64 A features in every wave (a0 = 4p) and each wave its own 64 B
+// features (b0 = 4 wave) in every pass: the whole B image (64 samples x 256 features) is published once, the A image one
+// 64-feature slice per pass into two alternating buffers (the slice of pass p+1 is written while pass p multiplies): every wave
+// publishes its own 16 samples at the same time (no skew), 6 barriers per job instead of 16.
+// Both images keep the four tiles of a 64-feature group INTERLEAVED (position 4 i + x for feature 16 x + i): a publishing lane
+// holds exactly those four values (v[4q+x][r], x = 0..3) -> one ds_write_b128; a reading lane gets its four A (B) operands of a
+// k-step as ONE ds_read_b128 instead of four ds_read_b32 (LDS instructions cost the SIMD issue slots, not bytes).
+template <int T>
+struct Dw16Sliced {
+    static_assert(T == 4 * k16Waves, "one 4-tile B patch per wave");
+    static constexpr int NA = 4, NB = 4, PASSES = T / NA, ROWS = k16Waves * 16, NKS = ROWS / 4;
+    // row pitch = 4 (mod 32) floats: eight consecutive rows of one ds_write_b128 pass land on 32 distinct banks; the b128 operand
+    // reads are contiguous over eight lanes whatever the pitch
+    static constexpr int PB = T * 16 + 4, PAS = NA * 16 + 4;
+    static constexpr int FLOATS = ROWS * PB + 2 * ROWS * PAS;
+};
+
+template <int T>
+__device__ __forceinline__ void dw16_sliced(float* __restrict__ X, int lane, int wave, const f32x4 (&va)[T], const f32x4 (&vb)[T],
+                                            float* __restrict__ gW, float* __restrict__ gb, bool accum, long long* tr = nullptr) {
+    using P = Dw16Sliced<T>;
+    constexpr int NA = P::NA, NB = P::NB, PB = P::PB, PAS = P::PAS, NKS = P::NKS;
+    const int i = lane & 15, kk = lane >> 4;   // reading: feature i of a block, k index kk; publishing: sample i, register group kk
+    float* const Bimg = X;
+    float* const Aimg = X + P::ROWS * PB;
+    const int row = wave * 16 + i;
+    auto pub_a = [&](int p, float* buf) {   // tiles 4p .. 4p+3 of this lane's sample
+        float* rp = buf + row * PAS + 16 * kk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<f32x4*>(rp + 4 * r) = f32x4{va[4 * p][r], va[4 * p + 1][r], va[4 * p + 2][r], va[4 * p + 3][r]};
+    };
+    auto slab_ptr = [&](int p, int x, int y) {
+        int off = (((p * NA + x) * T + wave * NB + y) * 64 + lane) * 4;   // slab_layout16: block-major, accumulator order
+        asm volatile("" : "+v"(off));
+        return reinterpret_cast<f32x4*>(gW + off);
+    };
+    if (tr && lane == 0 && wave == 0) tr[0] = wall_clock64();
+    PIME16_BARRIER();   // X free
+    {
+        float* rp = Bimg + row * PB + 16 * kk;
+#pragma unroll
+        for (int q = 0; q < T / 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<f32x4*>(rp + 64 * q + 4 * r) = f32x4{vb[4 * q][r], vb[4 * q + 1][r], vb[4 * q + 2][r], vb[4 * q + 3][r]};
+    }
+    pub_a(0, Aimg);
+    // accumulators start from what an earlier group of this workgroup stored; the loads for pass p+1 are issued during pass p
+    f32x4 nxt[NA][NB];
+    if (accum) {
+#pragma unroll
+        for (int x = 0; x < NA; ++x)
+#pragma unroll
+            for (int y = 0; y < NB; ++y) nxt[x][y] = *slab_ptr(0, x, y);
+    }
+    PIME16_BARRIER();
+#pragma unroll
+    for (int p = 0; p < P::PASSES; ++p) {
+        if (p + 1 < P::PASSES) pub_a(p + 1, Aimg + ((p + 1) & 1) * P::ROWS * PAS);
+        f32x4 acc[NA][NB];
+#pragma unroll
+        for (int x = 0; x < NA; ++x)
+#pragma unroll
+            for (int y = 0; y < NB; ++y) acc[x][y] = accum ? nxt[x][y] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (accum && p + 1 < P::PASSES) {
+#pragma unroll
+            for (int x = 0; x < NA; ++x)
+#pragma unroll
+                for (int y = 0; y < NB; ++y) nxt[x][y] = *slab_ptr(p + 1, x, y);
+        }
+        const float* Ap = Aimg + (p & 1) * P::ROWS * PAS + kk * PAS + 4 * i;
+        const float* Bp = Bimg + kk * PB + wave * (NB * 16) + 4 * i;
+        f32x4 av[2], bv[2];
+        f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        av[0] = *reinterpret_cast<const f32x4*>(Ap);
+        bv[0] = *reinterpret_cast<const f32x4*>(Bp);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+            for (int x = 0; x < NA; ++x) {
+#pragma unroll
+                for (int y = 0; y < NB; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][x], bv[ks & 1][y], acc[x][y], 0, 0, 0);
+                if (x == 1) {   // half-way: the next k-step's two operand reads
+                    if (ks + 1 < NKS) {
+                        av[(ks + 1) & 1] = *reinterpret_cast<const f32x4*>(Ap + 4 * (ks + 1) * PAS);
+                        bv[(ks + 1) & 1] = *reinterpret_cast<const f32x4*>(Bp + 4 * (ks + 1) * PB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (wave == 0) bsum += av[ks & 1];   // bias gradient: the column sums of A, needed once per A block (wave 0: b0 = 0)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // one 16-byte store per lane and block (a wave writes 1 KB contiguous).  The 16 stores of a pass are 16.8 MB chip-wide
+        // when all workgroups reach them together and take ~2.3 us to leave (r02 sub-marks): the width-256 gradient is bound by
+        // this slab traffic (256 KB per 64-sample group and layer); spreading them over the next pass's k-steps only moves the
+        // stall into the MFMA loop (tried: 1 149 -> 1 163 us).
+#pragma unroll
+        for (int x = 0; x < NA; ++x) {
+#pragma unroll
+            for (int y = 0; y < NB; ++y) *slab_ptr(p, x, y) = acc[x][y];
+        }
+        if (gb && wave == 0) {
+#pragma unroll
+            for (int x = 0; x < NA; ++x) {
+                float bs = bsum[x];
+                bs += __shfl_xor(bs, 16);
+                bs += __shfl_xor(bs, 32);
+                if (kk == 0) {
+                    float* qd = &gb[(p * NA + x) * 16 + i];
+                    *qd = accum ? *qd + bs : bs;
+                }
+            }
+        }
+        PIME16_BARRIER();   // pass p's reads are done (its A buffer may be rewritten); slice p+1 is visible
+        if (tr && lane == 0 && wave == 0) tr[1 + p] = wall_clock64();
+    }
+}
+
 template <int TA, int TB, int RT>
 __host__ __device__ constexpr int dw16_lds_floats() { return RT * 16 * (Dw16Plan<TA, TB>::PA + Dw16Plan<TA, TB>::PB); }
 
@@ -443,7 +569,8 @@ __host__ __device__ inline Lds16 lds16(int D, bool grad) {
     int region = layer16_lds_floats<T>();
     if (grad) {
         constexpr int RT = T <= 8 ? 4 : 2;
-        const int dwf = dw16_lds_floats<T, T, RT>();
+        int dwf = dw16_lds_floats<T, T, RT>();
+        if constexpr (T == 4 * k16Waves) dwf = dwf > Dw16Sliced<T>::FLOATS ? dwf : Dw16Sliced<T>::FLOATS;
         region = region > dwf ? region : dwf;
         const int hacc = k16Waves * md;
         region = region > hacc ? region : hacc;
@@ -631,7 +758,11 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
         // ------------------------------------------------------------------------------------------ backward
         PIME16_MARK(4);
         PIME_NO_HOIST();
-        dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{h3, g}, PubAcc16<T>{h2, g}, sl + a.poff[4], sl + a.poff[5], accum);   // net.4
+        if constexpr (T == 4 * k16Waves)
+            dw16_sliced<T>(region, lane, wave, h3, h2, sl + a.poff[4], sl + a.poff[5], accum,
+                           (a.trace && blockIdx.x == a.trace_wg && !accum) ? a.trace + 40 : nullptr);                      // net.4
+        else
+            dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{h3, g}, PubAcc16<T>{h2, g}, sl + a.poff[4], sl + a.poff[5], accum);
         f32x4 d2[T];
         PIME16_BARRIER();
         PIME16_MARK(5);
@@ -644,7 +775,10 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
         f32x4(&h1)[T] = h2;   // h2 is dead: its registers take the recomputed first-layer activation
         PIME_NO_HOIST();
         first16<T, ACT>(lds + S.w0, lds + S.b0, L.KS0, lane, xr, h1);
-        dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{d2, g}, PubAcc16<T>{h1, g}, sl + a.poff[2], sl + a.poff[3], accum);   // net.2
+        if constexpr (T == 4 * k16Waves)
+            dw16_sliced<T>(region, lane, wave, d2, h1, sl + a.poff[2], sl + a.poff[3], accum);                              // net.2
+        else
+            dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{d2, g}, PubAcc16<T>{h1, g}, sl + a.poff[2], sl + a.poff[3], accum);
         f32x4(&d1)[T] = h3;   // dZ3 is dead
         PIME16_BARRIER();
         PIME16_MARK(7);
