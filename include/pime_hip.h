@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 8
+#define PIME_ABI_VERSION 9
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -282,7 +282,17 @@ typedef struct pime_adam {
     float* step;        /* [dev] float32[2], as pime_adam_step */
     int64_t n;
     float lr, beta1, beta2, eps;
+    const int32_t* image_map;   /* [dev] int32[2 n] from pime_ppo_image_map, or NULL.  Not NULL: the launch that updates a
+                                 * parameter also writes its new value into the nets' img_fwd / img_bwd, so that NO
+                                 * pime_ppo_repack is needed after the step (one launch less per optimizer step) */
 } pime_adam;
+/* For every element j of the flat parameter tensor: image_map[2j] = its position in its net's img_fwd, image_map[2j+1] = its
+ * position in img_bwd (-1: not in that image, e.g. hidden-layer biases in the transposed image).  The images are permutations of
+ * the parameters (plus zero padding); the map is derived by running the library's own pack kernels on index-coded parameters, so it
+ * follows whichever kernel family serves each net.  Allocates and frees scratch memory and synchronises the stream: call it once
+ * per (nets, flat tensor), outside any graph capture.  PIME_ERR_ARG if a parameter straddles the flat tensor's ends. */
+int pime_ppo_image_map(const pime_ppo_net* actor, const pime_ppo_net* critic, const float* flat_param, int64_t n,
+                       int32_t* image_map, pime_stream stream);
 int pime_ppo_minibatch_step(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* batch,
                             float ratio_clip, float lambda_entropy, float* critic_scale, double* moments,
                             float* loss_sums, const pime_adam* opt, pime_stream stream);

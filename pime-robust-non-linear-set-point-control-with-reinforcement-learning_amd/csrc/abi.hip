@@ -53,11 +53,6 @@ int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
 int64_t fused_stash_floats(int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
-struct ReduceAdam {   // ppo_fused.hip
-    float *flat_grad, *flat_param, *exp_avg, *exp_avg_sq, *step;
-    long long n;
-    float lr, b1, b2, eps;
-};
 int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, bool, bool, bool, bool, int, int, float* const*,
                        float* const*, float*, float*, double*, float*, int, int64_t*, const ReduceAdam*, hipStream_t);
 int fused_grid(int);
@@ -756,6 +751,102 @@ int pime_ppo_repack(const pime_ppo_net* actor, const pime_ppo_net* critic, pime_
     return PIME_OK;
 }
 
+// ---- image map: where every flat parameter element sits in the packed images ----------------------------------------------
+__global__ void code_fill_kernel(float* codes, long long n, long long total) {
+    for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < total; j += (long long)gridDim.x * blockDim.x)
+        codes[j] = j < n ? (float)(j + 1) : 0.f;   // element j is coded j + 1 (exact in float32 below 2^24); 0 = padding / frozen
+}
+__global__ void image_invert_kernel(const float* img, long long floats, int32_t* map, int which, int* dup) {
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < floats; e += (long long)gridDim.x * blockDim.x) {
+        const float c = img[e];
+        if (c >= 1.f) {
+            const long long j = (long long)c - 1;
+            if (atomicExch(&map[2 * j + which], (int32_t)e) != -1) atomicAdd(dup, 1);   // an element packed twice: not a permutation
+        }
+    }
+}
+
+int pime_ppo_image_map(const pime_ppo_net* actor, const pime_ppo_net* critic, const float* flat_param, int64_t n,
+                       int32_t* image_map, pime_stream stream) {
+    if (int rc = check_net(actor, true)) return rc;
+    if (int rc = check_net(critic, false)) return rc;
+    PIME_REQUIRE(flat_param && image_map && n >= 1 && n < (1 << 24), "pime_ppo_image_map: bad flat tensor (1 <= n < 2^24)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const pime_ppo_net* nets[2] = {critic, actor};
+    // index-coded stand-ins of the parameters: the same offsets inside `codes` as inside the flat tensor; parameters outside
+    // the flat tensor (frozen ones) read the zero tail
+    int64_t tail = 1;
+    const float* fake[2][12];
+    for (int k = 0; k < 2; ++k) {
+        const pime_ppo_net* nk = nets[k];
+        const int np = nk->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
+        int poff[13], psize[12];
+        slab_layout(nk->kind, nk->D, nk->Di, nk->md, poff, psize);   // psize: the parameters' element counts
+        for (int i = 0; i < np; ++i) tail = psize[i] > tail ? psize[i] : tail;
+    }
+    float* codes = nullptr;
+    PIME_HIP_TRY(hipMalloc(&codes, sizeof(float) * (size_t)(n + tail)));
+    auto fail = [&](int rc) { (void)hipFree(codes); return rc; };
+    for (int k = 0; k < 2; ++k) {
+        const pime_ppo_net* nk = nets[k];
+        const int np = nk->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
+        int poff[13], psize[12];
+        slab_layout(nk->kind, nk->D, nk->Di, nk->md, poff, psize);
+        for (int i = 0; i < np; ++i) {
+            const float* p = nk->params[i];
+            const long long off = p - flat_param;
+            if (p >= flat_param && p < flat_param + n) {
+                if (off + psize[i] > n) {
+                    set_error("pime_ppo_image_map: parameter %d of the %s straddles the end of the flat tensor", i, k ? "actor" : "critic");
+                    return fail(PIME_ERR_ARG);
+                }
+                fake[k][i] = codes + off;
+            } else {
+                fake[k][i] = codes + n;
+            }
+        }
+    }
+    hipLaunchKernelGGL(code_fill_kernel, dim3(64), dim3(256), 0, s, codes, (long long)n, (long long)(n + tail));
+    if (hipMemsetAsync(image_map, 0xff, sizeof(int32_t) * 2 * (size_t)n, s) != hipSuccess) return fail(PIME_ERR_DEVICE);
+    int* dup = nullptr;
+    if (hipMalloc(&dup, sizeof(int)) != hipSuccess) return fail(PIME_ERR_DEVICE);
+    (void)hipMemsetAsync(dup, 0, sizeof(int), s);
+    float* scratch[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int64_t floats[2][2];
+    auto cleanup = [&](int rc) {
+        for (int k = 0; k < 2; ++k)
+            for (int w = 0; w < 2; ++w) (void)hipFree(scratch[k][w]);
+        (void)hipFree(dup);
+        return fail(rc);
+    };
+    pime_ppo_net coded[2];
+    for (int k = 0; k < 2; ++k) {
+        const pime_ppo_net* nk = nets[k];
+        floats[k][0] = ppo_fwd_image_floats(nk->kind, nk->D, nk->Di, nk->md);
+        floats[k][1] = pime_ppo_bwd_image_floats(nk->kind, nk->D, nk->Di, nk->md);
+        for (int w = 0; w < 2; ++w)
+            if (floats[k][w] <= 0 || hipMalloc(&scratch[k][w], sizeof(float) * (size_t)floats[k][w]) != hipSuccess ||
+                hipMemsetAsync(scratch[k][w], 0, sizeof(float) * (size_t)floats[k][w], s) != hipSuccess)   // padding the pack kernels
+                return cleanup(PIME_ERR_DEVICE);                                                        // never write must read 0
+        coded[k] = *nk;
+        coded[k].params = fake[k];
+        coded[k].img_fwd = scratch[k][0];
+        coded[k].img_bwd = scratch[k][1];
+    }
+    if (int rc = pime_ppo_repack(&coded[1], &coded[0], stream)) return cleanup(rc);   // the library's own pack kernels, per family
+    for (int k = 0; k < 2; ++k)
+        for (int w = 0; w < 2; ++w)
+            hipLaunchKernelGGL(image_invert_kernel, dim3(128), dim3(256), 0, s, scratch[k][w], (long long)floats[k][w], image_map, w, dup);
+    int ndup = 0;
+    if (hipMemcpyAsync(&ndup, dup, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return cleanup(PIME_ERR_DEVICE);
+    if (ndup) {
+        set_error("pime_ppo_image_map: %d parameter elements are packed more than once: the images are not permutations", ndup);
+        return cleanup(PIME_ERR_ARG);
+    }
+    return cleanup(PIME_OK);
+}
+
 static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b, float ratio_clip,
                           float lambda_entropy, float* critic_scale, double* moments, float* loss_sums, const pime_adam* opt,
                           pime_stream stream) {
@@ -789,7 +880,9 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
         PIME_REQUIRE(opt->param && opt->grad && opt->exp_avg && opt->exp_avg_sq && opt->step && opt->n >= 1,
                      "pime_ppo_minibatch_step: bad pime_adam");
         adam = ReduceAdam{opt->grad, opt->param, opt->exp_avg, opt->exp_avg_sq, opt->step, (long long)opt->n, opt->lr, opt->beta1,
-                          opt->beta2, opt->eps};
+                          opt->beta2, opt->eps, opt->image_map,
+                          {{const_cast<float*>(critic->img_fwd), const_cast<float*>(critic->img_bwd)},
+                           {const_cast<float*>(actor->img_fwd), const_cast<float*>(actor->img_bwd)}}};
     }
     static const bool tracing = std::getenv("PIME_FUSED_TRACE") != nullptr;  // tuning aid: phase marks of one workgroup
     static long long* trace_dev = nullptr;

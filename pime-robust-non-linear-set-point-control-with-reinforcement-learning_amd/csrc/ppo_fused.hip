@@ -887,12 +887,6 @@ struct ReduceSeg {
 // Optional optimizer step fused into the reduction (pime_ppo_minibatch_step): the gradient tensors are views into ONE flat
 // buffer and the parameters views into another at the same offsets, so the element a thread has just reduced is also the
 // element it updates (torch.optim.Adam semantics, as adam_kernel).  A whole launch and its boundary less per optimizer step.
-struct ReduceAdam {
-    float *flat_grad, *flat_param, *exp_avg, *exp_avg_sq, *step;   // step[0] counter, step[1] arrival counter (scratch)
-    long long n;
-    float lr, b1, b2, eps;
-};
-
 struct ReduceArgs {
     ReduceAdam adam;    // flat_grad == nullptr: no optimizer step
     ReduceSeg seg[24];
@@ -926,6 +920,7 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
         step_size = a.adam.lr / (float)(1.0 - pow((double)a.adam.b1, t));
         bc2_sqrt = (float)sqrt(1.0 - pow((double)a.adam.b2, t));
     }
+    const int net_of_seg = sg.net;
     auto emit = [&](float* q, float g) {   // store the finished gradient element and, if asked, apply Adam to its parameter
         const float gv = a.overwrite ? g : *q + g;
         *q = gv;
@@ -936,7 +931,13 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
                 const float vi = a.adam.exp_avg_sq[off] * a.adam.b2 + gv * gv * (1.0f - a.adam.b2);
                 a.adam.exp_avg[off] = mi;
                 a.adam.exp_avg_sq[off] = vi;
-                a.adam.flat_param[off] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + a.adam.eps));
+                const float pn = a.adam.flat_param[off] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + a.adam.eps));
+                a.adam.flat_param[off] = pn;
+                if (a.adam.image_map) {   // the packed images are permutations of the parameters: keep them current here
+                    const int2 m = reinterpret_cast<const int2*>(a.adam.image_map)[off];
+                    if (m.x >= 0) a.adam.img[net_of_seg][0][m.x] = pn;
+                    if (m.y >= 0) a.adam.img[net_of_seg][1][m.y] = pn;
+                }
             }
         }
     };

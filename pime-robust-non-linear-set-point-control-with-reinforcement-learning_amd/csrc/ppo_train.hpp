@@ -30,6 +30,16 @@ struct PpoArgs {
     int slab_stride, poff[13];  // float offsets of the params inside a slab; poff[np] = scalar slot (g_std / moments)
 };
 
+// The optimizer step fused into ppo_grad_reduce_kernel (pime_ppo_minibatch_step): torch.optim.Adam on the element just reduced
+// and, with an image map, the element's new value written straight into the packed images (no re-pack launch).
+struct ReduceAdam {
+    float *flat_grad, *flat_param, *exp_avg, *exp_avg_sq, *step;   // step[0] counter, step[1] arrival counter (scratch)
+    long long n;
+    float lr, b1, b2, eps;
+    const int32_t* image_map;   // [2 n]: position in img[net][0] / img[net][1] of every flat element, -1 = none; NULL = re-pack later
+    float* img[2][2];           // [0 critic, 1 actor][0 forward, 1 transposed]
+};
+
 struct DwJob {
     const float* a_stash;  // dZ stash base (NULL => head job: the A "tile" is the dOut vector in feature 0)
     int a_nt, a_t0, a_tiles;

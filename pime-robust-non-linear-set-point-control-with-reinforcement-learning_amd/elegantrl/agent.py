@@ -419,10 +419,14 @@ class AgentPPO(AgentBase):
                   self.lambda_entropy, st.scale, overwrite=True, index_row=st.row if use_table else None,
                   adam=self.optimizer if fuse_adam else None)
 
+        # With the image map the fused step writes every new parameter value into the packed images as well: no re-pack launch.
+        images_follow = fuse_adam and fused.images_follow_step
+
         def apply():
             if not fuse_adam:
                 self.optimizer.step()
-            fused.repack()
+            if not images_follow:
+                fused.repack()
 
         if fuse_adam and not getattr(fused, "adam_probed", False):   # does the library fuse the step for these nets?
             from ..native import PimeError
@@ -432,10 +436,12 @@ class AgentPPO(AgentBase):
             try:
                 grads()
             except PimeError:
-                fused.adam_fusable, fuse_adam = False, False
+                fused.adam_fusable, fuse_adam, images_follow = False, False, False
             for dst, src in zip((fused.flat_param, self.optimizer.exp_avg, self.optimizer.exp_avg_sq,
                                  self.optimizer.step_count, fused.loss_sums, st.row), snap):
                 dst.copy_(src)   # the probe must leave no trace
+            if images_follow:
+                fused.repack()   # ... nor in the packed images it updated
 
         def capture(*thunks):
             torch.cuda.synchronize(dev)
@@ -474,7 +480,8 @@ class AgentPPO(AgentBase):
                     elif one_graph:
                         st.graph_full = capture(grads, apply)
                     else:
-                        st.graph_a, st.graph_b = capture(grads), capture(apply)
+                        st.graph_a = capture(grads)
+                        st.graph_b = None if images_follow else capture(apply)   # nothing left to launch after a fused step
                 except RuntimeError as exc:  # keep training on the eager launch sequence
                     print(f"| HIP graph capture failed ({exc}); continuing with eager launches")
                     self.use_hip_graphs = False

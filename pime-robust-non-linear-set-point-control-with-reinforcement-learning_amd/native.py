@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PIME_LIB_PATH") or os.path.join(PACKAGE_DIR, "libpime
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
-ABI_VERSION = 8
+ABI_VERSION = 9
 ENV_PH, ENV_WT = 0, 1
 STATE_F64, STATE_MIXED, STATE_MIXED16 = 0, 1, 2
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
@@ -51,7 +51,7 @@ PPO_OVERWRITE_GRADS = 1
 class Adam(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("step", C.c_void_p), ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("eps", C.c_float)]
+                ("eps", C.c_float), ("image_map", C.c_void_p)]
 
 
 class EnvCfg(C.Structure):
@@ -111,6 +111,7 @@ _SIGNATURES = {
     "pime_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     "pime_ppo_minibatch_grad": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     "pime_ppo_minibatch_step": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "pime_ppo_image_map": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

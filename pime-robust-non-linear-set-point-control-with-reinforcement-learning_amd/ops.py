@@ -4,6 +4,7 @@ All operands are CUDA (ROCm) tensors; launches go to torch's current stream.  No
 a CPU tensor raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -166,7 +167,33 @@ class FusedPPOGrad:
                        ws=torch.empty(n_ws, dtype=torch.float32, device=self.device))
             self.nets.append(net)
         self._structs = None
+        self._image_map = None
         self.repack()
+
+    def image_map(self):
+        """int32 [2 n]: where every element of the flat parameter tensor sits in its net's forward / transposed image
+        (pime_ppo_image_map).  With it the fused optimizer step keeps the images current by itself (`images_follow_step`) and the
+        re-pack launch after every step goes away; None if the library cannot derive it (the caller then re-packs as before).
+        PIME_NO_IMAGE_MAP=1 turns it off (A/B)."""
+        if self._image_map is None:
+            if os.environ.get("PIME_NO_IMAGE_MAP"):
+                self._image_map = False
+                return None
+            if self._structs is None:
+                self._build_structs()
+            actor, critic, _ = self._structs
+            m = torch.empty(2 * self.flat_param.numel(), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = native.lib().pime_ppo_image_map(C.byref(actor), C.byref(critic), self.flat_param.data_ptr(),
+                                                     self.flat_param.numel(), m.data_ptr(), _stream(self.flat_param))
+            self._image_map = m if rc == 0 else False
+            self.image_map_error = None if rc == 0 else native.last_error()
+        return self._image_map if self._image_map is not False else None
+
+    @property
+    def images_follow_step(self):
+        """True: a fused step (`adam=` given to __call__) also updates the packed images; no repack() needed after it."""
+        return self.image_map() is not None
 
     @staticmethod
     def supported(act, cri):
@@ -246,6 +273,9 @@ class FusedPPOGrad:
                 opt = native.Adam(param=adam.param.data_ptr(), grad=adam.grad.data_ptr(), exp_avg=adam.exp_avg.data_ptr(),
                                   exp_avg_sq=adam.exp_avg_sq.data_ptr(), step=adam.step_count.data_ptr(), n=adam.param.numel(),
                                   lr=adam.lr, beta1=adam.betas[0], beta2=adam.betas[1], eps=adam.eps)
+                imap = self.image_map()
+                if imap is not None:
+                    opt.image_map = imap.data_ptr()
                 native.check(native.lib().pime_ppo_minibatch_step(C.byref(actor), C.byref(critic), C.byref(batch),
                                                                   C.c_float(ratio_clip), C.c_float(lambda_entropy),
                                                                   native.ptr(critic_scale), native.ptr(self.moments),

@@ -309,3 +309,33 @@ def test_split_pipeline_refuses_the_fused_step():
     with pytest.raises(native.PimeError, match="split pipeline"):
         fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, 0.2, 0.02, torch.zeros(1, device=DEV),
               overwrite=True, adam=adam)
+
+
+@pytest.mark.parametrize("kind,md,D", [("modular", 128, 3), ("resid", 128, 3), ("resid", 64, 4), ("resid", 256, 3), ("resid", 128, 30)])
+def test_fused_step_keeps_the_packed_images_current(kind, md, D):
+    """pime_ppo_image_map + pime_adam.image_map: the launch that applies Adam writes every new parameter value into the nets'
+    forward / transposed images, so the re-pack launch after an optimizer step can go.  After three fused steps the images must
+    equal, bit for bit, what pime_ppo_repack lays out from the updated parameters -- for the LDS-resident family (64 / 128), the
+    16-tile family (256, and 128 on the 30-float observation) and the modular actor."""
+    from pime_amd import ops
+    act, cri = _make(kind, md, D, seed=5)
+    B = 2048
+    L = 3 * B
+    state, action, logprob, adv, r_sum = _data(L, D, act, seed=3)
+    fused = ops.FusedPPOGrad(act, cri, B)
+    opt = fused.make_optimizer(3e-4)
+    assert fused.images_follow_step, f"the library could not derive the image map: {fused.image_map_error}"
+    m = fused.image_map().view(-1, 2)
+    assert int((m[:, 0] >= 0).sum()) >= fused.flat_param.numel() - 2   # every net parameter sits in its forward image (a_std_log does not)
+    scale = torch.zeros(1, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for _ in range(3):
+        idx = torch.randint(L, (B,), device=DEV, generator=g)
+        fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, 0.2, 0.02, scale, overwrite=True, adam=opt)
+    torch.cuda.synchronize()
+    got = [(n["img_fwd"].clone(), n["img_bwd"].clone()) for n in fused.nets]
+    fused.repack()
+    torch.cuda.synchronize()
+    for (gf, gb), n in zip(got, fused.nets):
+        assert torch.equal(gf, n["img_fwd"]), "forward image drifted from the parameters"
+        assert torch.equal(gb, n["img_bwd"]), "transposed image drifted from the parameters"

@@ -65,6 +65,19 @@ __global__ __launch_bounds__(512) void rounds(float* out, const float* src, int 
             for (int i = 0; i < 8; ++i) pv[i] = fmaxf(fmaf(x2, w[i][2], fmaf(x1, w[i][1], fmaf(x0, w[i][0], w[i][3]))), 0.f);
         };
         auto publish = [&]() {
+            if constexpr (MODE & 8192) {   // bit 13: FEATURE-major images [feature][32 samples], pitch 36: ds_write_b32 publishes, b128 reads
+                float* pb = nxt + 128 * 36 + (pt * 32 + 4 * h + 8 * (pr0 >> 2)) * 36 + li;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[((e & 3) + 8 * (e >> 2)) * 36] = pv[e];
+                if (wave == ((t + 1) & 7)) {
+                    float* q = nxt + (4 * h) * 36 + li;
+#pragma unroll
+                    for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) q[(tt * 32 + (r & 3) + 8 * (r >> 2)) * 36] = az[tt][r];
+                }
+                return;
+            }
             float* p = nxt + tsize(T) + li * tpitch(T) + pt * 32 + 4 * h + 8 * (pr0 >> 2);
             if constexpr (!(MODE & 2048)) {   // bit 11: no B publish
                 *reinterpret_cast<float4*>(p) = make_float4(pv[0], pv[1], pv[2], pv[3]);
@@ -161,9 +174,10 @@ __global__ __launch_bounds__(512) void rounds(float* out, const float* src, int 
             if constexpr ((MODE & 1) && (MODE & 512)) {   // bit 9: 12 ds_read_b128 instead of 48 ds_read_b32 (sample-contiguous operand layout)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const float4 va = *reinterpret_cast<const float4*>(Ap - li + li * 36 + 4 * s);
-                    const float4 v0 = *reinterpret_cast<const float4*>(Bp - li + li * 36 + 4 * s);
-                    const float4 v1 = *reinterpret_cast<const float4*>(Bp - li + li * 36 + 4 * s + 32 * 36);
+                    const float* Af = cur + (ao * 32 + li) * 36 + 16 * h, *Bf = cur + 128 * 36 + (bi0 * 32 + li) * 36 + 16 * h;
+                    const float4 va = *reinterpret_cast<const float4*>(Af + 4 * s);
+                    const float4 v0 = *reinterpret_cast<const float4*>(Bf + 4 * s);
+                    const float4 v1 = *reinterpret_cast<const float4*>(Bf + 4 * s + 32 * 36);
                     av[4 * s] = va.x; av[4 * s + 1] = va.y; av[4 * s + 2] = va.z; av[4 * s + 3] = va.w;
                     bv[0][4 * s] = v0.x; bv[0][4 * s + 1] = v0.y; bv[0][4 * s + 2] = v0.z; bv[0][4 * s + 3] = v0.w;
                     bv[1][4 * s] = v1.x; bv[1][4 * s + 1] = v1.y; bv[1][4 * s + 2] = v1.z; bv[1][4 * s + 3] = v1.w;
@@ -229,8 +243,8 @@ static void run(float* out, const float* src, int nrounds, int grid, unsigned lo
     unsigned long long hc[2];
     hipMemcpy(hc, clk, sizeof(hc), hipMemcpyDeviceToHost);
     const double ghz = (double)hc[0] / (double)hc[1] * 0.1;   // s_memtime ticks per 100 MHz s_memrealtime tick
-    printf("grid %3d mode %4d%s%s%s%s%s%s: %.3f us per round = %.0f shader cycles at %.2f GHz (MFMA block: 4096); %.1f TFLOP/s if 256 CUs\n", grid, MODE,
-           MODE & 1 ? " reads" : "", MODE & 2 ? " pipelined" : "", MODE & 4 ? " publish" : "", MODE & 8 ? " staging" : "",
+    printf("grid %3d mode %4d%s%s%s%s%s%s%s: %.3f us per round = %.0f shader cycles at %.2f GHz (MFMA block: 4096); %.1f TFLOP/s if 256 CUs\n", grid, MODE,
+           MODE & 8192 ? " FEATURE-MAJOR" : "", MODE & 1 ? " reads" : "", MODE & 2 ? " pipelined" : "", MODE & 4 ? " publish" : "", MODE & 8 ? " staging" : "",
            MODE & 16 ? " recompute" : "", MODE & 1024 ? " early/late+deferred" : (MODE & 32 ? " early/late" : ""), us, us * ghz * 1e3, ghz,
            256.0 * 8 * 32 * 4096 / us * 1e-6);
 }
@@ -245,12 +259,14 @@ int main(int argc, char** argv) {
     hipMalloc(&clk, 16);
     for (int grid : {256}) {
         run<0>(out, src, nrounds, grid, clk);
-        run<4>(out, src, nrounds, grid, clk);
-        run<2052>(out, src, nrounds, grid, clk);
-        run<4100>(out, src, nrounds, grid, clk);
-        run<7>(out, src, nrounds, grid, clk);
-        run<2055>(out, src, nrounds, grid, clk);
-        run<4103>(out, src, nrounds, grid, clk);
+        run<5>(out, src, nrounds, grid, clk);
+        run<8709>(out, src, nrounds, grid, clk);     // 1 + 4 + 512 + 8192
+        run<13>(out, src, nrounds, grid, clk);
+        run<8717>(out, src, nrounds, grid, clk);
+        run<29>(out, src, nrounds, grid, clk);
+        run<8733>(out, src, nrounds, grid, clk);
+        run<61>(out, src, nrounds, grid, clk);
+        run<8765>(out, src, nrounds, grid, clk);
     }
     hipDeviceSynchronize();
     return 0;
