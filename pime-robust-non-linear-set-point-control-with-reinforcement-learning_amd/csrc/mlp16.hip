@@ -651,6 +651,7 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
     float* const region = lds + S.region;
     double* const wsum = reinterpret_cast<double*>(lds + S.wsum);   // [wave][6]
     const float asl = ACTOR ? a.a_std_log[0] : 0.f;
+    if (a.trace_span && tid == 0 && blockIdx.x < 512) a.trace_span[2 * blockIdx.x] = wall_clock64();
     stage_small16<T>(lds, S, a.img_fwd, L, tid);
     if (tid < k16Waves * 6) wsum[tid] = 0.0;
     __syncthreads();
@@ -797,6 +798,7 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
         PIME16_MARK(9);
     }
 
+    if (a.trace_span && tid == 0 && blockIdx.x < 512) a.trace_span[2 * blockIdx.x + 1] = wall_clock64();
     // ---- workgroup totals of the scalar sums, in a fixed order (only the logged loss sums use atomics)
     __syncthreads();
     if (tid == 0) {
