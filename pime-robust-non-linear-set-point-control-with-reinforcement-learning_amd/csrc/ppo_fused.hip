@@ -327,6 +327,38 @@ __device__ __forceinline__ void dw_store(int lane, int wave, const f32x16 (&acc)
     }
 }
 
+// The same for a job whose blocks are all inside the tensor (the md x md layers): row pitch and block origin are compile-time, no
+// per-element bounds tests, and the accumulate / overwrite decision is taken once (dw_store spends ~3 vector + 5 scalar
+// instructions and two branches per element on them: with f32 MFMAs every one of those is time on the SIMD).
+template <int AT, int BT>
+__device__ __forceinline__ void dw_store_full(int lane, int wave, const f32x16 (&acc)[DwPlan<AT, BT>::PER], float bsum,
+                                              float* __restrict__ gW, float* __restrict__ gb, bool accum) {
+    constexpr int LDW = BT * 32, PER = DwPlan<AT, BT>::PER;
+    const DwPlan<AT, BT> pl(wave);
+    if (!pl.active) return;   // fewer blocks than waves (width 64)
+    float* const q = gW + dw_base<AT, BT>(lane, wave, LDW);
+    if (!accum) {
+#pragma unroll
+        for (int n = 0; n < PER; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[n * 32 + ((r & 3) + 8 * (r >> 2)) * LDW] = acc[n][r];
+    } else {
+#pragma unroll
+        for (int n = 0; n < PER; ++n) {
+            f32x16 old;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = q[n * 32 + ((r & 3) + 8 * (r >> 2)) * LDW];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[n * 32 + ((r & 3) + 8 * (r >> 2)) * LDW] = old[r] + acc[n][r];
+        }
+    }
+    bsum += __shfl_xor(bsum, 32);  // the two k parities
+    if (pl.bi0 == 0 && lane < 32) {
+        float* qb = &gb[pl.ao * 32 + lane];
+        *qb = accum ? *qb + bsum : bsum;
+    }
+}
+
 // ---- modular actor: the two branch layers of a level share one set of rounds ---------------------------------------
 // Level 2 (other_net.2 | integrator_net.2): A = [dZo2 | dZi2] (T tiles), B = [h_o1 | h_i1] (2T tiles).  Only the
 // block-diagonal products are wanted: A tiles [0,H) x B tiles [0,T) and A tiles [H,T) x B tiles [T,2T).
@@ -356,17 +388,23 @@ struct CatB {   // tiles [0,T): other branch, [T,2T): integrator branch
     }
 };
 
-// One 32x32 accumulator block -> rows row0.. of a row-major [.. x ldw] slab tensor at column `col` (this lane's).
+// One 32x32 accumulator block -> rows row0.. of a row-major [.. x ldw] slab tensor at column `col` (this lane's).  The
+// accumulate / overwrite decision is wave-uniform: taken once, not per element.
 __device__ __forceinline__ void block_store(const f32x16& acc, float* __restrict__ gW, int ldw, int row0, int col,
                                             bool col_ok, int lane, bool accum) {
     int base = (row0 + 4 * (lane >> 5)) * ldw + col;
     asm volatile("" : "+v"(base));
-    if (col_ok) {
+    if (!col_ok) return;
+    float* const q = gW + base;
+    if (!accum) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float* q = &gW[base + ((r & 3) + 8 * (r >> 2)) * ldw];
-            *q = accum ? *q + acc[r] : acc[r];
-        }
+        for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldw] = acc[r];
+    } else {
+        f32x16 old;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = q[((r & 3) + 8 * (r >> 2)) * ldw];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldw] = old[r] + acc[r];
     }
 }
 __device__ __forceinline__ void bias_store(float bsum, float* __restrict__ gb, int lane, bool accum) {
@@ -701,7 +739,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 PIME_NO_HOIST();
                 dw_rounds<T, T>(X, lane, wave, dn0, StashB{st0, T * 1024}, acc, bsum, wbuf, a.img_bwd + Lb.off[3],
                                 T * T * 256);
-                dw_store<T, T>(lane, wave, acc, bsum, sl + a.poff[8], md, md, md, sl + a.poff[9], accum);   // net.0
+                dw_store_full<T, T>(lane, wave, acc, bsum, sl + a.poff[8], sl + a.poff[9], accum);   // net.0
             }
             PIME_LDS_BARRIER();
             PIME_MARK(5);
@@ -807,7 +845,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 PIME_NO_HOIST();
                 dw_rounds<T, T>(X, lane, wave, d, StashB{st0, T * 1024}, acc, bsum, wbuf, a.img_bwd + Lb.off[2],
                                 T * T * 256);
-                dw_store<T, T>(lane, wave, acc, bsum, sl + a.poff[4], md, md, md, sl + a.poff[5], accum);      // net.4
+                dw_store_full<T, T>(lane, wave, acc, bsum, sl + a.poff[4], sl + a.poff[5], accum);      // net.4
             }
             PIME_LDS_BARRIER();
             PIME_MARK(5);
@@ -826,7 +864,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 dw_rounds<T, T>(X, lane, wave, d2, FirstB<ACT>{lds + F.first0, xs, a.D, a.D, 0, md}, acc, bsum, wbuf,
                                 a.img_bwd + Lb.off[3], T * T * 256,
                                 (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
-                dw_store<T, T>(lane, wave, acc, bsum, sl + a.poff[2], md, md, md, sl + a.poff[3], accum);      // net.2
+                dw_store_full<T, T>(lane, wave, acc, bsum, sl + a.poff[2], sl + a.poff[3], accum);      // net.2
             }
             PIME_LDS_BARRIER();
             PIME_MARK(7);
