@@ -29,6 +29,8 @@
 #include "ppo_device.hpp"
 #include "ppo_train.hpp"
 
+#include <type_traits>
+
 namespace pime {
 
 constexpr int kFusedThreads = 512;
@@ -39,8 +41,12 @@ constexpr int kFusedWaves = kFusedThreads / 64;
 __host__ __device__ constexpr int tpitch(int nt) { return nt * 32 + 4; }
 __host__ __device__ constexpr int tsize(int nt) { return 32 * tpitch(nt); }   // floats of one 32-sample tile image
 
+// first-layer gradients on the vector ALUs up to this fan-in (first_grad_valu); its state rows are padded to 4 / 8 floats
+constexpr int kFirstValuMaxD = 7;
+__host__ __device__ constexpr int first_valu_pad(int D) { return D <= 3 ? 4 : (D <= kFirstValuMaxD ? 8 : 0); }
+
 struct FusedLds {
-    int first0, first1, bias[3], headw, headb, xs, hacc, wsum, wbuf, x, total;
+    int first0, first1, bias[3], headw, headb, xs, xsp, hacc, wsum, wbuf, x, total;
 };
 
 __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
@@ -65,6 +71,7 @@ __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
     seg(F.headw, md);
     seg(F.headb, 4);
     seg(F.xs, kFusedWaves * 32 * D);   // the group's gathered states [wave][sample][D]
+    seg(F.xsp, kFusedWaves * 32 * first_valu_pad(D));   // the same rows padded to 4 / 8 floats: (x, 1, 0 ..) for first_grad_valu
     seg(F.hacc, kFusedWaves * md);     // per-wave head weight gradients (summed in wave order at the end)
     seg(F.wsum, kFusedWaves * 6 * 2);  // per-wave float64 totals of the scalar sums
     seg(F.wbuf, T * T * 1024);
@@ -117,25 +124,56 @@ __device__ __forceinline__ void stash_get(const float* __restrict__ base, int la
 
 // ---- B-operand sources: NP consecutive registers r0..r0+NP-1 of tile t of the accumulator-layout activation tile of
 // wave `ow`, for this lane.  Any wave can produce any tile's elements, so the eight waves share the publishing work.
+// A wave publishes the SAME (t, r0) slice in every round (only the sample tile `ow` changes): `prepare` runs once in front
+// of the rounds and keeps what does not depend on `ow` in registers (Pre<NP>).
+struct NoPre {};
 struct StashB {   // a hidden activation stashed by the forward: [wave tile][t][16][64]
     static constexpr bool kLate = false;  // global loads: issue early, they land behind the MFMAs
+    template <int NP> using Pre = NoPre;
     const float* base;   // stash of the group's first tile, at the wanted activation
     int tile_stride;     // floats between consecutive tiles
     template <int NP>
-    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, float (&v)[NP]) const {
+    __device__ __forceinline__ void prepare(int, int, int, NoPre&) const {}
+    template <int NP>
+    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, const NoPre&, float (&v)[NP]) const {
         const float* p = base + (size_t)ow * tile_stride + (t * 16 + r0) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NP; ++i) v[i] = p[i * 64];
     }
 };
-template <int ACT>
+constexpr int kPreD = 4;   // fan-in up to which a wave keeps its slice of the first-layer weights in registers over the rounds
+template <int NP>
+struct FirstPre {
+    float w[NP][kPreD + 1];   // [element][input column | bias]
+};
+template <int ACT, bool HOIST = true>
 struct FirstB {   // a first-layer activation, recomputed from the group's states in LDS (same arithmetic as layer_first)
     static constexpr bool kLate = true;   // VALU / LDS work: waves 4-7 do it after their MFMAs (see dw_rounds)
+    // HOIST: the slice's weights stay in registers over the rounds; otherwise (no registers to spare: the modular actor's
+    // merged job, 16 elements per wave and round) every fetch re-reads them column by column
+    template <int NP> using Pre = std::conditional_t<HOIST, FirstPre<NP>, NoPre>;
     const float* w0;   // FIRST image [Din+1][OT][16][2]
     const float* xs;   // [wave][32][D]
     int Din, D, col0, ot32;
+    // The slice's weights: NP * (Din + 1) LDS reads once instead of once per round (as dependent reads in front of every
+    // round's MFMAs they cost ~2 000 cycles per round and wave: r02 phase trace).
     template <int NP>
-    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, float (&v)[NP]) const {
+    __device__ __forceinline__ void prepare(int t, int r0, int lane, NoPre&) const {}
+    template <int NP>
+    __device__ __forceinline__ void prepare(int t, int r0, int lane, FirstPre<NP>& p) const {
+        if (Din > kPreD) return;
+        const float* w = w0 + (t * 16 + r0) * 2 + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) p.w[i][kPreD] = w[Din * ot32 + 2 * i];
+#pragma unroll
+        for (int j = 0; j < kPreD; ++j)
+            if (j < Din) {   // one wave-uniform branch per column
+#pragma unroll
+                for (int i = 0; i < NP; ++i) p.w[i][j] = w[j * ot32 + 2 * i];
+            }
+    }
+    template <int NP>
+    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, const NoPre&, float (&v)[NP]) const {
         const float* x = xs + (ow * 32 + (lane & 31)) * D + col0;
         const float* w = w0 + (t * 16 + r0) * 2 + (lane >> 5);
 #pragma unroll
@@ -148,13 +186,44 @@ struct FirstB {   // a first-layer activation, recomputed from the group's state
 #pragma unroll
         for (int i = 0; i < NP; ++i) v[i] = activate<ACT>(v[i]);
     }
+    template <int NP>
+    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, const FirstPre<NP>& p, float (&v)[NP]) const {
+        const float* x = xs + (ow * 32 + (lane & 31)) * D + col0;
+        if (Din <= kPreD) {
+            float xv[kPreD];
+#pragma unroll
+            for (int j = 0; j < kPreD; ++j) xv[j] = x[j < Din ? j : 0];   // unconditional reads: issued together, one wait
+#pragma unroll
+            for (int i = 0; i < NP; ++i) v[i] = p.w[i][kPreD];
+#pragma unroll
+            for (int j = 0; j < kPreD; ++j)   // same order as layer_first: bias, then columns 0, 1, ...
+                if (j < Din) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) v[i] = fmaf(xv[j], p.w[i][j], v[i]);
+                }
+        } else {
+            const float* w = w0 + (t * 16 + r0) * 2 + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) v[i] = w[Din * ot32 + 2 * i];
+            for (int j = 0; j < Din; ++j) {   // j outermost: one wait per input column, not one per element
+                const float xj = x[j];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) v[i] = fmaf(xj, w[j * ot32 + 2 * i], v[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) v[i] = activate<ACT>(v[i]);
+    }
 };
 struct StateB {   // the raw state columns [col0, col0+Din) padded with zeros to one 32-feature tile
     static constexpr bool kLate = false;
+    template <int NP> using Pre = NoPre;
     const float* xs;
     int Din, D, col0;
     template <int NP>
-    __device__ __forceinline__ void fetch(int ow, int, int r0, int lane, float (&v)[NP]) const {
+    __device__ __forceinline__ void prepare(int, int, int, NoPre&) const {}
+    template <int NP>
+    __device__ __forceinline__ void fetch(int ow, int, int r0, int lane, const NoPre&, float (&v)[NP]) const {
         const float* x = xs + (ow * 32 + (lane & 31)) * D + col0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -205,7 +274,9 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
     const float4* src4 = reinterpret_cast<const float4*>(stage_src);
     float4* dst4 = reinterpret_cast<float4*>(stage_dst);
     float pv[NP], pv2[NP];
-    auto b_fetch = [&](int ow, float (&v)[NP]) { bsrc.template fetch<NP>(ow, pt, pr0, lane, v); };
+    typename BSrc::template Pre<NP> pre;   // what a wave's slice does not re-derive per round (first-layer weights)
+    bsrc.template prepare<NP>(pt, pr0, lane, pre);
+    auto b_fetch = [&](int ow, float (&v)[NP]) { bsrc.template fetch<NP>(ow, pt, pr0, lane, pre, v); };
     auto b_publish = [&](float* buf) {
         float* p = buf + tsize(AT) + li * tpitch(BT) + pt * 32 + 4 * h + 8 * (pr0 >> 2) + (pr0 & 3);
         if constexpr (NP >= 4) {
@@ -380,11 +451,14 @@ struct CatPlan {
 template <int T>
 struct CatB {   // tiles [0,T): other branch, [T,2T): integrator branch
     static constexpr bool kLate = true;
-    FirstB<1> o, i;
+    template <int NP> using Pre = NoPre;
+    FirstB<1, false> o, i;
     template <int NP>
-    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, float (&v)[NP]) const {
-        if (t < T) o.template fetch<NP>(ow, t, r0, lane, v);
-        else i.template fetch<NP>(ow, t - T, r0, lane, v);
+    __device__ __forceinline__ void prepare(int, int, int, NoPre&) const {}
+    template <int NP>
+    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, const NoPre& p, float (&v)[NP]) const {
+        if (t < T) o.template fetch<NP>(ow, t, r0, lane, p, v);
+        else i.template fetch<NP>(ow, t - T, r0, lane, p, v);
     }
 };
 
@@ -441,45 +515,68 @@ __device__ __forceinline__ void first_times_act_grad(const float* __restrict__ w
 // First-layer weight / bias gradient for a fan-in of a few columns, on the vector ALUs:
 //   gW[f][j] = sum over the group's 256 samples of dZ[s][f] * x[s][j],   gb[f] = sum_s dZ[s][f].
 // As a matrix job this is a 32-column product of which Din columns are real (90 % wasted MFMA work in eight
-// barrier-separated rounds).  Here four waves at a time publish their dZ tiles (two super-rounds), thread (f, q) reads
-// its feature's column for a quarter of each tile's samples, and the 2*Q partial sums per element are combined in a fixed
-// order (reproducible).  part: 2*Q*R*(Din+1) floats of scratch LDS.
-constexpr int kFirstValuMaxD = 8;
+// barrier-separated rounds).  f32 MFMAs and vector instructions share the SIMD's issue slots (tools/dw_round_bench.hip), so
+// what counts is the instruction count: two passes of 128 samples; the pass's four waves write their dZ tiles FEATURE-major
+// ([feature][128 samples], 16-byte groups XOR-swizzled with the feature so that both sides are conflict-free), thread
+// (feature f, slice q) then reads its samples four at a time (ds_read_b128) and the padded state rows xsp[s] = (x_0 .. x_{D-1},
+// 1, 0 ..) as one or two broadcast ds_read_b128: per sample 1/4 + 1 LDS instructions and P fmas for ALL columns and the
+// bias at once.  The Q slices are combined in a fixed order (reproducible).
 template <int T>
-__device__ __forceinline__ void first_grad_valu(float* __restrict__ X, float* __restrict__ part, int lane, int wave,
-                                                const f32x16 (&dz)[T], const float* __restrict__ xs, int D, int col0,
-                                                int Din, float* __restrict__ gW, float* __restrict__ gb, bool accum) {
-    constexpr int R = T * 32, Q = kFusedThreads / R, SPQ = 32 / Q, TSZ = tsize(T);
-    const int tid = wave * 64 + lane, o = tid % R, q = tid / R;
+__device__ __forceinline__ void first_grad_valu(float* __restrict__ X, int lane, int wave, const f32x16 (&dz)[T],
+                                                const float* __restrict__ xsp, int D, int col0, int Din,
+                                                float* __restrict__ gW, float* __restrict__ gb, bool accum) {
+    constexpr int R = T * 32, Q = kFusedThreads / R, SP = 128, GPT = SP / Q / 4;   // groups of 4 samples per thread and pass
+    static_assert(2 * SP == kFusedWaves * 32 && SP * R <= 2 * (tsize(T) + tsize(T)), "two passes over the X region");
+    const int tid = wave * 64 + lane, f = tid % R, q = tid / R, h = lane >> 5, li = lane & 31;
+    const int P = first_valu_pad(D);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll 1
-    for (int sr = 0; sr < 2; ++sr) {
+    for (int pass = 0; pass < 2; ++pass) {
         PIME_LDS_BARRIER();  // X free
-        if ((wave >> 2) == sr) put_tile<T>(X + (wave & 3) * TSZ, lane, dz);
-        PIME_LDS_BARRIER();
-        float av[4 * SPQ];
+        if ((wave >> 2) == pass) {
+            const int s = (wave & 3) * 32 + li;
+            float* p = X + (4 * h) * SP + (s & 3);
+            const int g = s >> 2;
 #pragma unroll
-        for (int slot = 0; slot < 4; ++slot)
+            for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int i = 0; i < SPQ; ++i) av[slot * SPQ + i] = X[slot * TSZ + (q * SPQ + i) * tpitch(T) + o];
-#pragma unroll 1
-        for (int j = 0; j <= Din; ++j) {   // j == Din: the bias (x = 1)
-            float acc = 0.f;
-#pragma unroll
-            for (int slot = 0; slot < 4; ++slot)
-#pragma unroll
-                for (int i = 0; i < SPQ; ++i) {
-                    const float xv = j < Din ? xs[((sr * 4 + slot) * 32 + q * SPQ + i) * D + col0 + j] : 1.0f;
-                    acc = fmaf(av[slot * SPQ + i], xv, acc);
+                for (int r = 0; r < 16; ++r) {   // feature t*32 + (r&3) + 8*(r>>2) + 4h; feature & 7 = (r&3) + 4h
+                    const int fl = (r & 3) + 8 * (r >> 2);
+                    p[(t * 32 + fl) * SP + ((g ^ ((r & 3) + 4 * h)) << 2)] = dz[t][r];
                 }
-            part[((sr * Q + q) * (Din + 1) + j) * R + o] = acc;
+        }
+        PIME_LDS_BARRIER();
+        const float* row = X + f * SP;
+        const float* xr = xsp + (pass * SP + q * (GPT * 4)) * P;
+#pragma unroll
+        for (int g = 0; g < GPT; ++g) {
+            const float4 d4 = *reinterpret_cast<const float4*>(row + (((q * GPT + g) ^ (f & 7)) << 2));
+            const float dk[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 x4 = *reinterpret_cast<const float4*>(xr + (g * 4 + k) * P);
+                acc[0] = fmaf(dk[k], x4.x, acc[0]); acc[1] = fmaf(dk[k], x4.y, acc[1]);
+                acc[2] = fmaf(dk[k], x4.z, acc[2]); acc[3] = fmaf(dk[k], x4.w, acc[3]);
+                if (P == 8) {
+                    const float4 y4 = *reinterpret_cast<const float4*>(xr + (g * 4 + k) * P + 4);
+                    acc[4] = fmaf(dk[k], y4.x, acc[4]); acc[5] = fmaf(dk[k], y4.y, acc[5]);
+                    acc[6] = fmaf(dk[k], y4.z, acc[6]); acc[7] = fmaf(dk[k], y4.w, acc[7]);
+                }
+            }
         }
     }
+    PIME_LDS_BARRIER();  // the dZ image is dead: its first 8 * Q * R floats hold the slices' partial sums
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (j < P) X[(q * 8 + j) * R + f] = acc[j];
     PIME_LDS_BARRIER();
     for (int e = tid; e < R * (Din + 1); e += kFusedThreads) {
-        const int j = e / R, f = e % R;
+        const int j = e / R, ff = e % R, col = j < Din ? col0 + j : D;   // column D of the padded rows is the constant 1: the bias
         float t = 0.f;
-        for (int p = 0; p < 2 * Q; ++p) t += part[(p * (Din + 1) + j) * R + f];
-        float* qd = j < Din ? &gW[f * Din + j] : &gb[f];
+        for (int p = 0; p < Q; ++p) t += X[(p * 8 + col) * R + ff];
+        float* qd = j < Din ? &gW[ff * Din + j] : &gb[ff];
         *qd = accum ? *qd + t : t;
     }
 }
@@ -520,6 +617,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     float* const wbuf = lds + F.wbuf;
     float* const X = lds + F.x;
     float* const xs = lds + F.xs;
+    float* const xsp = lds + F.xsp;
     float* const hacc = lds + F.hacc;   // head weight gradient of the workgroup
     const int Do = a.D - a.Di;
 
@@ -611,6 +709,14 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             if (a.D > 2) xw[2] = x2;
             if (a.D > 3) xw[3] = x3;
             for (int c = 4; c < a.D; ++c) xw[c] = xrow[c];
+            if (const int P = first_valu_pad(a.D)) {   // padded copy: columns [0, D) the state, column D the constant 1
+                auto col = [&](int c, float v) { return c < a.D ? v : (c == a.D ? 1.f : 0.f); };
+                float4* xp = reinterpret_cast<float4*>(xsp + (wave * 32 + li) * P);
+                xp[0] = make_float4(col(0, x0), col(1, x1), col(2, x2), col(3, x3));
+                if (P == 8)
+                    xp[1] = make_float4(col(4, a.D > 4 ? xrow[4] : 0.f), col(5, a.D > 5 ? xrow[5] : 0.f),
+                                        col(6, a.D > 6 ? xrow[6] : 0.f), col(7, 0.f));
+            }
         }
         __syncthreads();
         PIME_MARK(1);
@@ -757,7 +863,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 PIME_NO_HOIST();
                 dw_rounds<T, 2 * T, CatB<T>, CatPlan<T>>(
                     wbuf, lane, wave, dcat,
-                    CatB<T>{FirstB<1>{lds + F.first0, xs, Do, a.D, 0, md}, FirstB<1>{lds + F.first1, xs, a.Di, a.D, Do, md}},
+                    CatB<T>{FirstB<1, false>{lds + F.first0, xs, Do, a.D, 0, md}, FirstB<1, false>{lds + F.first1, xs, a.Di, a.D, Do, md}},
                     acc, bsum, nullptr, nullptr, 0, (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
                 const CatPlan<T> pl(wave);
                 if (pl.active) {
@@ -792,7 +898,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                     PIME_MARK(9 + br);
                     float* gW = sl + a.poff[br ? 4 : 0], *gb = sl + a.poff[br ? 5 : 1];
                     if (a.D <= kFirstValuMaxD) {
-                        first_grad_valu<T>(X, img, lane, wave, d1, xs, a.D, col0, Din, gW, gb, accum);
+                        first_grad_valu<T>(X, lane, wave, d1, xsp, a.D, col0, Din, gW, gb, accum);
                     } else {
                         f32x16 acc[DwPlan<T, 1>::PER];
                         float bsum;
@@ -815,9 +921,9 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 first_times_act_grad<T, 1>(lds + F.first1, xl + Do, a.Di, h, *reinterpret_cast<f32x16(*)[T]>(&d1[T]));  // dZi1
                 PIME_MARK(10);
                 if (a.D <= kFirstValuMaxD) {   // other_net.0, integrator_net.0 on the vector ALUs
-                    first_grad_valu<T>(X, wbuf, lane, wave, *reinterpret_cast<f32x16(*)[T]>(&d1[0]), xs, a.D, 0, Do,
+                    first_grad_valu<T>(X, lane, wave, *reinterpret_cast<f32x16(*)[T]>(&d1[0]), xsp, a.D, 0, Do,
                                        sl + a.poff[0], sl + a.poff[1], accum);
-                    first_grad_valu<T>(X, wbuf, lane, wave, *reinterpret_cast<f32x16(*)[T]>(&d1[T]), xs, a.D, Do, a.Di,
+                    first_grad_valu<T>(X, lane, wave, *reinterpret_cast<f32x16(*)[T]>(&d1[T]), xsp, a.D, Do, a.Di,
                                        sl + a.poff[4], sl + a.poff[5], accum);
                 } else {
                     // matrix form: A = [dZo1 | dZi1], B = the state columns (one tile); wave w owns A tile w; its
@@ -873,7 +979,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             first_times_act_grad<T, ACT>(lds + F.first0, xl, a.D, h, d);                            // dZ1 (H1 again)
             PIME_MARK(8);
             if (a.D <= kFirstValuMaxD) {   // net.0 on the vector ALUs (W is dead: its LDS holds the partial sums)
-                first_grad_valu<T>(X, wbuf, lane, wave, d, xs, a.D, 0, a.D, sl + a.poff[0], sl + a.poff[1], accum);
+                first_grad_valu<T>(X, lane, wave, d, xsp, a.D, 0, a.D, sl + a.poff[0], sl + a.poff[1], accum);
             } else {
                 f32x16 acc[DwPlan<T, 1>::PER];
                 float bsum;
