@@ -287,7 +287,8 @@ typedef struct pime_adam {
                                  * pime_ppo_repack is needed after the step (one launch less per optimizer step) */
 } pime_adam;
 /* For every element j of the flat parameter tensor: image_map[2j] = its position in its net's img_fwd, image_map[2j+1] = its
- * position in img_bwd (-1: not in that image, e.g. hidden-layer biases in the transposed image).  The images are permutations of
+ * position in img_bwd, each with the net in bits 28..29 (0 critic, 1 actor; -1: not in that image, e.g. hidden-layer biases in the
+ * transposed image).  The images are permutations of
  * the parameters (plus zero padding); the map is derived by running the library's own pack kernels on index-coded parameters, so it
  * follows whichever kernel family serves each net.  Allocates and frees scratch memory and synchronises the stream: call it once
  * per (nets, flat tensor), outside any graph capture.  PIME_ERR_ARG if a parameter straddles the flat tensor's ends. */
@@ -321,6 +322,10 @@ int pime_rollout(pime_env* env, int32_t kind, int32_t md, const float* packed_ac
  * different optimizers are independent. */
 int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, float* step, pime_stream stream);
+/* pime_adam_step for the nets of a PPO agent, with opt->image_map set: every new parameter value is also written into the nets'
+ * packed images, so no pime_ppo_repack follows.  For data-parallel callers, whose all-reduce sits between pime_ppo_minibatch_grad
+ * and the optimizer step (single-GPU callers get the same from pime_ppo_minibatch_step in one launch less). */
+int pime_adam_step_images(const pime_adam* opt, const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -66,7 +66,7 @@ int launch_ppo16(int, int, const PpoArgs&, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
 int launch_dw(const DwArgs&, int, hipStream_t);
 int launch_critic_scale(int, int, float* const*, const double*, int, float*, float*, int64_t*, hipStream_t);
-int launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float*, hipStream_t);
+int launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float*, const int32_t*, float* const (*)[2], hipStream_t);
 int launch_rollout(int, int, const RolloutArgs&, hipStream_t);
 
 }  // namespace pime
@@ -707,7 +707,7 @@ int pime_rollout(pime_env* e, int32_t kind, int32_t md, const float* packed_acto
 int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, float* step, pime_stream stream) {
     PIME_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && n >= 1, "pime_adam_step: bad arguments");
-    return launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, static_cast<hipStream_t>(stream));
+    return launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 static int check_net(const pime_ppo_net* n, bool actor) {
@@ -756,12 +756,12 @@ __global__ void code_fill_kernel(float* codes, long long n, long long total) {
     for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < total; j += (long long)gridDim.x * blockDim.x)
         codes[j] = j < n ? (float)(j + 1) : 0.f;   // element j is coded j + 1 (exact in float32 below 2^24); 0 = padding / frozen
 }
-__global__ void image_invert_kernel(const float* img, long long floats, int32_t* map, int which, int* dup) {
+__global__ void image_invert_kernel(const float* img, long long floats, int32_t* map, int which, int net, int* dup) {
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < floats; e += (long long)gridDim.x * blockDim.x) {
         const float c = img[e];
         if (c >= 1.f) {
             const long long j = (long long)c - 1;
-            if (atomicExch(&map[2 * j + which], (int32_t)e) != -1) atomicAdd(dup, 1);   // an element packed twice: not a permutation
+            if (atomicExch(&map[2 * j + which], (int32_t)e | (net << 28)) != -1) atomicAdd(dup, 1);   // an element packed twice: not a permutation
         }
     }
 }
@@ -836,7 +836,7 @@ int pime_ppo_image_map(const pime_ppo_net* actor, const pime_ppo_net* critic, co
     if (int rc = pime_ppo_repack(&coded[1], &coded[0], stream)) return cleanup(rc);   // the library's own pack kernels, per family
     for (int k = 0; k < 2; ++k)
         for (int w = 0; w < 2; ++w)
-            hipLaunchKernelGGL(image_invert_kernel, dim3(128), dim3(256), 0, s, scratch[k][w], (long long)floats[k][w], image_map, w, dup);
+            hipLaunchKernelGGL(image_invert_kernel, dim3(128), dim3(256), 0, s, scratch[k][w], (long long)floats[k][w], image_map, w, k, dup);
     int ndup = 0;
     if (hipMemcpyAsync(&ndup, dup, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return cleanup(PIME_ERR_DEVICE);
@@ -845,6 +845,17 @@ int pime_ppo_image_map(const pime_ppo_net* actor, const pime_ppo_net* critic, co
         return cleanup(PIME_ERR_ARG);
     }
     return cleanup(PIME_OK);
+}
+
+int pime_adam_step_images(const pime_adam* opt, const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream) {
+    if (int rc = check_net(actor, true)) return rc;
+    if (int rc = check_net(critic, false)) return rc;
+    PIME_REQUIRE(opt && opt->param && opt->grad && opt->exp_avg && opt->exp_avg_sq && opt->step && opt->n >= 1 && opt->image_map,
+                 "pime_adam_step_images: bad pime_adam (image_map must be set: pime_ppo_image_map)");
+    float* const img[2][2] = {{const_cast<float*>(critic->img_fwd), const_cast<float*>(critic->img_bwd)},
+                              {const_cast<float*>(actor->img_fwd), const_cast<float*>(actor->img_bwd)}};
+    return launch_adam(opt->param, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n, opt->lr, opt->beta1, opt->beta2, opt->eps,
+                       opt->step, opt->image_map, img, static_cast<hipStream_t>(stream));
 }
 
 static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b, float ratio_clip,

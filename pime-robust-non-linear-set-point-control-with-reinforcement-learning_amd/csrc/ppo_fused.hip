@@ -1079,8 +1079,8 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
                 a.adam.flat_param[off] = pn;
                 if (a.adam.image_map) {   // the packed images are permutations of the parameters: keep them current here
                     const int2 m = reinterpret_cast<const int2*>(a.adam.image_map)[off];
-                    if (m.x >= 0) a.adam.img[net_of_seg][0][m.x] = pn;
-                    if (m.y >= 0) a.adam.img[net_of_seg][1][m.y] = pn;
+                    if (m.x >= 0) a.adam.img[net_of_seg][0][m.x & 0x0fffffff] = pn;   // (bits 28..29: the net, for pime_adam_step_images)
+                    if (m.y >= 0) a.adam.img[net_of_seg][1][m.y & 0x0fffffff] = pn;
                 }
             }
         }

@@ -450,9 +450,13 @@ int launch_critic_scale(int D, int md, float* const* grads, const double* moment
 // (a device-side arrival counter) stores t.  No workgroup can read step[] after that store: the store waits for all of
 // them to have arrived, and they arrive after their reads.  (A separate 1-thread "tick" launch cost ~3 us per step.)
 // The arrival counter is step[1] (caller-owned, one per optimizer), so optimizers on different streams do not share it.
+struct AdamImages {   // optional: keep the packed images current (pime_adam_step_images)
+    const int32_t* map;   // [2 n], see pime_ppo_image_map; NULL: parameters only
+    float* img[2][2];     // [0 critic, 1 actor][0 forward, 1 transposed]
+};
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                            float* __restrict__ step) {
+                            float* __restrict__ step, AdamImages im) {
     const float t_new = step[0] + 1.0f;
     const double t = (double)t_new;
     const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
@@ -463,7 +467,13 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         const float vi = v[i] * b2 + gi * gi * (1.0f - b2);      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
         m[i] = mi;
         v[i] = vi;
-        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        const float pn = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        p[i] = pn;
+        if (im.map) {
+            const int2 e = reinterpret_cast<const int2*>(im.map)[i];
+            if (e.x >= 0) im.img[(e.x >> 28) & 1][0][e.x & 0x0fffffff] = pn;
+            if (e.y >= 0) im.img[(e.y >> 28) & 1][1][e.y & 0x0fffffff] = pn;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -477,11 +487,17 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
-                float* step, hipStream_t s) {
+                float* step, const int32_t* map, float* const (*img)[2], hipStream_t s) {
+    AdamImages im{};
+    if (map) {
+        im.map = map;
+        for (int k = 0; k < 2; ++k)
+            for (int w = 0; w < 2; ++w) im.img[k][w] = img[k][w];
+    }
     const int block = 256;
     long long grid = (n + block - 1) / block;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(block), 0, s, p, g, m, v, n, lr, b1, b2, eps, step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(block), 0, s, p, g, m, v, n, lr, b1, b2, eps, step, im);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }

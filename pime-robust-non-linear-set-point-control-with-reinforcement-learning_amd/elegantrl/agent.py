@@ -419,12 +419,16 @@ class AgentPPO(AgentBase):
                   self.lambda_entropy, st.scale, overwrite=True, index_row=st.row if use_table else None,
                   adam=self.optimizer if fuse_adam else None)
 
-        # With the image map the fused step writes every new parameter value into the packed images as well: no re-pack launch.
-        images_follow = fuse_adam and fused.images_follow_step
+        # With the image map the launch that applies Adam writes every new parameter value into the packed images as well (the
+        # fused step on one GPU, pime_adam_step_images behind the all-reduce under data parallelism): no re-pack launch.
+        images_follow = isinstance(self.optimizer, FlatAdam) and fused.images_follow_step
 
         def apply():
             if not fuse_adam:
-                self.optimizer.step()
+                if images_follow:
+                    self.optimizer.step(images=fused)
+                else:
+                    self.optimizer.step()
             if not images_follow:
                 fused.repack()
 
@@ -436,12 +440,12 @@ class AgentPPO(AgentBase):
             try:
                 grads()
             except PimeError:
-                fused.adam_fusable, fuse_adam, images_follow = False, False, False
+                fused.adam_fusable, fuse_adam = False, False
             for dst, src in zip((fused.flat_param, self.optimizer.exp_avg, self.optimizer.exp_avg_sq,
                                  self.optimizer.step_count, fused.loss_sums, st.row), snap):
                 dst.copy_(src)   # the probe must leave no trace
             if images_follow:
-                fused.repack()   # ... nor in the packed images it updated
+                fused.repack()   # ... nor in the packed images it may have updated
 
         def capture(*thunks):
             torch.cuda.synchronize(dev)
@@ -481,7 +485,7 @@ class AgentPPO(AgentBase):
                         st.graph_full = capture(grads, apply)
                     else:
                         st.graph_a = capture(grads)
-                        st.graph_b = None if images_follow else capture(apply)   # nothing left to launch after a fused step
+                        st.graph_b = None if (images_follow and fuse_adam) else capture(apply)   # nothing left to launch after a fused step
                 except RuntimeError as exc:  # keep training on the eager launch sequence
                     print(f"| HIP graph capture failed ({exc}); continuing with eager launches")
                     self.use_hip_graphs = False

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "pime_ppo_minibatch_grad": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     "pime_ppo_minibatch_step": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "pime_ppo_image_map": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
+    "pime_adam_step_images": (C.c_int, [_vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

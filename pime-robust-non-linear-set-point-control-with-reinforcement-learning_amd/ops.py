@@ -162,8 +162,8 @@ class FusedPPOGrad:
             if n_fwd <= 0 or n_bwd <= 0 or n_ws <= 0:
                 raise native.PimeError(f"fused PPO gradients unsupported for {kind} width {md}: {native.last_error()}")
             net = dict(kind=k, D=D, Di=Di, md=md, plist=plist,
-                       img_fwd=torch.empty(n_fwd, dtype=torch.float32, device=self.device),
-                       img_bwd=torch.empty(n_bwd, dtype=torch.float32, device=self.device),
+                       img_fwd=torch.zeros(n_fwd, dtype=torch.float32, device=self.device),   # zeros: the padding the pack
+                       img_bwd=torch.zeros(n_bwd, dtype=torch.float32, device=self.device),   # kernels never write is defined
                        ws=torch.empty(n_ws, dtype=torch.float32, device=self.device))
             self.nets.append(net)
         self._structs = None
@@ -301,7 +301,22 @@ class FlatAdam:
         self.step_count = torch.zeros(2, dtype=torch.float32, device=param.device)   # [0] step, [1] arrival counter (scratch)
         self.param_groups = [{"params": [param], "lr": self.lr}]
 
-    def step(self):
+    def step(self, images=None):
+        """images: the FusedPPOGrad whose packed images should follow the step (its image map): the launch then also writes
+        every new parameter value into them (pime_adam_step_images) and the caller skips repack()."""
+        imap = images.image_map() if images is not None else None
+        if imap is not None:
+            assert images.flat_param is self.param
+            if images._structs is None:
+                images._build_structs()
+            actor, critic, _ = images._structs
+            opt = native.Adam(param=self.param.data_ptr(), grad=self.grad.data_ptr(), exp_avg=self.exp_avg.data_ptr(),
+                              exp_avg_sq=self.exp_avg_sq.data_ptr(), step=self.step_count.data_ptr(), n=self.param.numel(),
+                              lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, image_map=imap.data_ptr())
+            with torch.cuda.device(self.param.device):
+                native.check(native.lib().pime_adam_step_images(C.byref(opt), C.byref(actor), C.byref(critic), _stream(self.param)),
+                             "pime_adam_step_images")
+            return
         with torch.cuda.device(self.param.device):
             native.check(native.lib().pime_adam_step(native.ptr(self.param), native.ptr(self.grad), native.ptr(self.exp_avg),
                                                      native.ptr(self.exp_avg_sq), self.param.numel(), C.c_float(self.lr),

@@ -339,3 +339,30 @@ def test_fused_step_keeps_the_packed_images_current(kind, md, D):
     for (gf, gb), n in zip(got, fused.nets):
         assert torch.equal(gf, n["img_fwd"]), "forward image drifted from the parameters"
         assert torch.equal(gb, n["img_bwd"]), "transposed image drifted from the parameters"
+
+
+@pytest.mark.parametrize("kind,md,D", [("modular", 128, 3), ("resid", 256, 3)])
+def test_separate_adam_launch_keeps_the_packed_images_current(kind, md, D):
+    """The data-parallel form (gradients, all-reduce, THEN Adam): pime_adam_step_images updates parameters and packed images in
+    the one Adam launch; the parameters must equal pime_adam_step's bit for bit and the images a re-pack's."""
+    from pime_amd import ops
+    act, cri = _make(kind, md, D, seed=6)
+    act2, cri2 = _make(kind, md, D, seed=6)
+    B = 1024
+    L = 3 * B
+    state, action, logprob, adv, r_sum = _data(L, D, act, seed=4)
+    fa, fb = ops.FusedPPOGrad(act, cri, B), ops.FusedPPOGrad(act2, cri2, B)
+    oa, ob = fa.make_optimizer(3e-4), fb.make_optimizer(3e-4)
+    scale = torch.zeros(1, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(12)
+    for _ in range(3):
+        idx = torch.randint(L, (B,), device=DEV, generator=g)
+        for f, o, images in ((fa, oa, fa), (fb, ob, None)):
+            f(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, 0.2, 0.02, scale, overwrite=True)
+            o.step(images=images)
+            if images is None:
+                f.repack()
+    torch.cuda.synchronize()
+    assert torch.equal(fa.flat_param, fb.flat_param)
+    for na, nb in zip(fa.nets, fb.nets):
+        assert torch.equal(na["img_fwd"], nb["img_fwd"]) and torch.equal(na["img_bwd"], nb["img_bwd"])
