@@ -243,6 +243,56 @@ def bench_water_tank(args, device, json_fd):
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
+def bench_water_tank_256(args, device, json_fd):
+    """The reference's live water-tank script (/root/reference/run_watertank_changing.sh:20-27): ResidualPPO, net_dim 256, the
+    30-float Stacking10 observation, reward 'distance'; 4096 lanes x 200-step episodes, batch 65536, repeat 8 as the other
+    workloads.  The update runs on the streamed 16-tile kernels (csrc/mlp16.hip), the rollout step-wise (policy forward +
+    fused residual env step per lock-step: the one-launch rollout serves widths 64 / 128).  `torch_update` is the same step with
+    update_net on PyTorch-ROCm autograd + rocBLAS (use_fused_update = False): what width 256 fell back to in round 1."""
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.agent_residual import AgentResidualPPO
+    from pime_amd.elegantrl.run import make_buffer
+    lanes, T = 4096, 200
+
+    def run(fused_update, steps, warmup):
+        env = gym_control.make_vec(gym_control.WT_STACKING.format(10), lanes, device=device, state_mode="mixed", seed=0,
+                                   reward_type="distance")
+        torch.manual_seed(0)
+        agent = AgentResidualPPO(device=device)
+        agent.use_fused_update = fused_update
+        agent.init(256, env.state_dim, 1)
+        agent.init_residual({"init_K": env.K.reshape(-1, 1)})
+        agent.init_actor_zero()
+        agent.fix_K()
+        buf = make_buffer(agent, env, lanes * T)
+
+        def step():
+            n = agent.explore_env(env, buf, lanes * T, 1.0, GAMMA)
+            agent.update_net(buf, lanes * T, BATCH, REPEAT)
+            return n
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total = sum(step() for _ in range(steps))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        took_hip = bool(agent._packed.get("fused"))
+        env.close()
+        return total / dt, dt / steps * 1e3, took_hip
+    v, ms, hip = run(True, args.steps, args.warmup)
+    assert hip, "width 256 did not take the HIP gradient path"
+    v_t, ms_t, _ = run(False, max(1, args.steps // 2), 1)
+    out = {"metric": "env-steps/sec (rollout+update), water-tank Stacking10 env, 4096 parallel envs, net_dim 256", "value": v,
+           "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "water tank Stacking10-v2 (30-float observation, reward 'distance'), 4096 lanes x 200-step "
+                                  "episodes, ResidualPPO net_dim 256 (run_watertank_changing.sh), batch 65536, repeat 8"},
+           "torch_update": {"value": v_t, "unit": "env-steps/s", "ms_per_step": ms_t,
+                            "what": "same step, update_net on PyTorch-ROCm autograd + rocBLAS (round 1's width-256 path)"}}
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
     relay rank 0's stdout (the JSON line) and return non-zero if any rank fails.  The parent makes NO GPU call (importing
@@ -341,7 +391,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ph", choices=["ph", "wt", "wt_td3"],
+    ap.add_argument("--workload", default="ph", choices=["ph", "wt", "wt_td3", "wt256"],
                     help="ph: the headline config (BASELINE config 3); wt: config 2, water tank, 4096 lanes x 200 steps "
                          "(reported for DESIGN.md; the headline metric is the ph line)")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
@@ -372,6 +422,8 @@ def main():
 
     if args.workload == "wt":
         return bench_water_tank(args, device, json_fd)
+    if args.workload == "wt256":
+        return bench_water_tank_256(args, device, json_fd)
     if args.workload == "wt_td3":
         return bench_water_tank_td3(args, device, json_fd)
     env, agent, buf = build_stack(device, rank, world, dp)
