@@ -120,6 +120,7 @@ class AgentPPO(AgentBase):
         self.use_hip_graphs = True
         self.use_single_graph = True     # one graph per optimizer step when nothing has to happen between its launches
         self.use_graph_collective = True  # data parallel: capture the RCCL all-reduce INSIDE that one graph
+        self.use_update_graph = True      # ... and, once that graph exists, all n_steps optimizer steps of an update as ONE graph
         self.use_fused_rollout = True
         self.launch_timer = None  # optional callable(name, thunk) that brackets the thunk with HIP events
 
@@ -392,6 +393,7 @@ class AgentPPO(AgentBase):
                id(self.optimizer), float(getattr(self.optimizer, "lr", self.learning_rate)))
         if st.key != key:
             st.key, st.graph_a, st.graph_b, st.graph_full = key, None, None, None
+            st.graph_update, st.graph_update_steps = None, None
 
         # Minibatch indices: with torch's own draw, all n_steps minibatches are drawn at once (agent.py:630 draws them one
         # torch.randint per step) into a table the kernels walk with a device-side row cursor, so a captured graph needs
@@ -401,6 +403,7 @@ class AgentPPO(AgentBase):
             if st.table is None or st.table.shape[0] < n_steps:
                 st.table = torch.empty((n_steps, batch_size), dtype=torch.int64, device=dev)
                 st.graph_a = st.graph_b = st.graph_full = None
+                st.graph_update, st.graph_update_steps = None, None
             if self.index_table_hook is not None:
                 st.table[:n_steps].copy_(self.index_table_hook(n_steps, buf_len, batch_size).to(dev))
             else:
@@ -464,8 +467,36 @@ class AgentPPO(AgentBase):
         one_graph = self.use_single_graph and (self.dp is None or in_graph_dp) and use_table and self.launch_timer is None
         if st.mode != (use_table, one_graph, fuse_adam):   # the captured graphs bake in the index source and the step form
             st.mode, st.graph_a, st.graph_b, st.graph_full = (use_table, one_graph, fuse_adam), None, None, None
+            st.graph_update, st.graph_update_steps = None, None
         last = None
-        for step in range(n_steps):
+        # With the index table every optimizer step is the same launch sequence (the row cursor lives on the device), so once
+        # the per-step graph exists the WHOLE update -- n_steps x (critic, actor, reduction [, all-reduce, Adam]) and the copy of
+        # the loss sums in front of the last step -- is captured as one graph: one replay per update_net instead of n_steps, and
+        # the ~5 us between two replays become a node boundary.
+        if (self.use_update_graph and one_graph and self.use_hip_graphs and st.graph_full is not None and n_steps > 1
+                and getattr(st, "graph_update_steps", None) != n_steps):
+            st.graph_update, st.graph_update_steps = None, n_steps
+            try:
+                def whole_update():
+                    for k in range(n_steps):
+                        if k == n_steps - 1:
+                            st.last.copy_(fused.loss_sums)
+                        grads()
+                        if self.dp is not None:
+                            self.dp.all_reduce_mean(fused.flat_grad)
+                        apply()
+                st.graph_update = capture(whole_update)
+            except RuntimeError as exc:
+                print(f"| capture of the whole update refused ({exc}); replaying one graph per optimizer step")
+                self.use_update_graph = False
+                torch.cuda.synchronize(dev)
+        if st.graph_update is not None and st.graph_update_steps == n_steps and one_graph and self.use_update_graph:
+            st.graph_update.replay()
+            last = st.last.clone()
+            n_loop = 0
+        else:
+            n_loop = n_steps
+        for step in range(n_loop):
             if not use_table:
                 st.idx.copy_(self.index_hook(step, buf_len, batch_size).to(dev))
             if step == n_steps - 1:
@@ -527,6 +558,7 @@ class AgentPPO(AgentBase):
             import types
             f32 = dict(dtype=torch.float32, device=dev)
             st = types.SimpleNamespace(buf_len=buf_len, batch=batch_size, key=None, graph_a=None, graph_b=None, graph_full=None, table=None, mode=None, warm=False,
+                                       graph_update=None, graph_update_steps=None, last=torch.zeros(6, **f32),
                                        row=torch.zeros(1, dtype=torch.int64, device=dev),
                                        r_sum=torch.empty(buf_len, **f32), logprob=torch.empty(buf_len, **f32),
                                        adv=torch.empty(buf_len, **f32), scale=torch.ones(1, **f32),

@@ -91,3 +91,43 @@ def test_hip_update_net_matches_reference_weights(tag, mode):
                 for k in _sd(g, f"{tag}:act0"))
     assert moved > 3e-4 and worst < 0.1 * moved
     np.testing.assert_allclose([obj_a, obj_c], g[f"{tag}:obj"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["ph128", "wts10_256"])
+def test_whole_update_graph_equals_per_step_graphs(tag):
+    """From the second update_net on, all optimizer steps of an update are ONE captured graph (agent.use_update_graph): one
+    replay per update instead of one per step.  Three updates on the reference's buffer with the reference's indices, once
+    that way and once with one graph per step: the weights must agree bit for bit, the reported losses to rounding."""
+    from pime_amd.elegantrl import agent_residual
+    from pime_amd.elegantrl.replay import ReplayBuffer
+    g = load_golden("ppo_update_wide.npz")
+    hyper = g[f"{tag}:hyper"]
+    net_dim, target_step, batch, repeat = int(hyper[0]), int(hyper[1]), int(hyper[2]), int(hyper[3])
+    c = CASES[tag]
+    state, other = g[f"{tag}:buf_state"], g[f"{tag}:buf_other"]
+    D = state.shape[1]
+    idx = torch.from_numpy(g[f"{tag}:indices"])
+    results = []
+    for whole in (True, False):
+        ag = getattr(agent_residual, c["agent"])(device=DEV)
+        ag.use_update_graph = whole
+        if c["integrator"] is not None:
+            ag.init(net_dim, D, 1, c["integrator"])
+        else:
+            ag.init(net_dim, D, 1)
+        ag.init_residual({"init_K": np.array(c["K"]).reshape(-1, 1)})
+        ag.fix_K()
+        ag.act.load_state_dict({k: v.to(DEV) for k, v in _sd(g, f"{tag}:act0").items()})
+        ag.cri.load_state_dict({k: v.to(DEV) for k, v in _sd(g, f"{tag}:cri0").items()})
+        ag.weights_changed()
+        buf = ReplayBuffer(len(state) + 8, D, 1, if_on_policy=True, device=DEV)
+        buf.extend_buffer(state, other)
+        ag.index_table_hook = lambda n, L, B: idx[:n]
+        objs = [ag.update_net(buf, target_step, batch, repeat) for _ in range(3)]
+        torch.cuda.synchronize()
+        fused = ag._packed.get("fused")
+        assert fused and (fused.static.graph_update is not None) == whole
+        results.append((fused.flat_param.clone(), objs))
+    assert torch.equal(results[0][0], results[1][0]), "weights differ between the whole-update graph and per-step graphs"
+    # (the logged loss sums are float atomics over the workgroups: reproducible to rounding, not bitwise)
+    np.testing.assert_allclose(np.array(results[0][1]), np.array(results[1][1]), rtol=1e-4, atol=1e-6)
