@@ -414,9 +414,14 @@ def main():
         return launcher_selftest(json_fd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    device = f"cuda:{local}"
-    torch.cuda.set_device(local)
-    dp = pdist.init_from_env(backend="nccl", device=device) if (world > 1 or os.environ.get("PIME_FORCE_DP") == "1") else None
+    # PIME_BENCH_REHEARSE=1: every rank on cuda:0 with gloo collectives -- a rehearsal of the launcher and the data-parallel
+    # step sequence on a one-GPU box (RCCL refuses two ranks on one device); its numbers mean nothing
+    rehearse = os.environ.get("PIME_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local
+    device = f"cuda:{dev_index}"
+    torch.cuda.set_device(dev_index)
+    dp = (pdist.init_from_env(backend="gloo" if rehearse else "nccl", device=device)
+          if (world > 1 or os.environ.get("PIME_FORCE_DP") == "1") else None)
     if dp is not None:
         world = torch.distributed.get_world_size()   # the RCCL communicator's size is what the JSON line reports
 

@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -40,3 +42,21 @@ def test_world_size_mismatch_is_reported():
     env = dict(_clean_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-launcher"], env=env, capture_output=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr.decode()
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` exactly as the driver starts it, rehearsed on a one-GPU box: PIME_BENCH_REHEARSE=1 puts both
+    ranks on cuda:0 with gloo collectives (RCCL refuses two ranks on one device).  Exercises the launcher, the sharded lanes,
+    the weight broadcast, the per-step flat-gradient all-reduce between the gradient launches and Adam, the max-over-ranks
+    timing and rank 0's JSON line -- everything of the N > 1 path but RCCL itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PIME_BENCH_REHEARSE"] = "1"
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env,
+                       capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["value"] > 1e6 and abs(out["value"] - 2 * 819200 / (out["ms_per_step"] * 1e-3)) < 1e-3 * out["value"]
