@@ -90,6 +90,31 @@ __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
 // workgroups flush the same tensor.  The rounds only exchange data through LDS.
 #define PIME_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// A forward image goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write; a wave
+// instruction lands 1 KB at a wave-uniform LDS base + lane * 16): issued at the top of a group, waited for (counted vmcnt) only in
+// front of the layer that reads it, so the first layer(s) run while the images of the later ones are still in flight.
+// NI = 8 KB pieces of the image (one DMA instruction per wave and piece).  The source base is made provably wave-uniform
+// (readfirstlane): a per-piece 64-bit VGPR address would be spilled, and every reload's vmcnt(0) would drain the DMAs.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+template <int NI>
+__device__ __forceinline__ void dma_image(float* __restrict__ lds_dst, const float* __restrict__ src, int tid) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(src);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const char* sbase = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    const unsigned voff = (unsigned)tid * 16u;
+    float* ldst = lds_dst + (tid >> 6) * 256;   // this wave's 1 KB inside every 8 KB piece
+#pragma unroll
+    for (int p = 0; p < NI; ++p)
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)(sbase + p * (kFusedThreads * 16) + voff),
+                                         (lds_void_ptr)(ldst + p * kFusedThreads * 4), 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_dma_then_barrier() {   // all but the N youngest vector-memory operations of this wave are done
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 // Accumulator-layout tile (sample on the lane) -> feature-major rows [t*32 + feat][sample], pitch 33.
 template <int NTL>
 __device__ __forceinline__ void put_tile(float* __restrict__ dst, int lane, const f32x16 (&v)[NTL]) {
@@ -694,13 +719,16 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
         if (a.D > 2) x2 = xrow[2];
         if (a.D > 3) x3 = xrow[3];
         __syncthreads();  // the previous group's backward is done with W / X
+        // the forward images, in the order the layers read them; each layer waits for its own (see the forward below)
+        constexpr int NI_TT = T * T * 1024 / (kFusedThreads * 4), NI_TH = T * H * 1024 / (kFusedThreads * 4);   // 8 KB pieces
+        static_assert(T * H * 1024 % (kFusedThreads * 4) == 0, "image = whole 8 KB pieces");
         if constexpr (MODULAR) {
-            stage_image(wbuf, a.img_fwd + L.off[6], T * T * 256);
-            stage_image(X, a.img_fwd + L.off[1], T * H * 256);
-            stage_image(X + T * H * 1024, a.img_fwd + L.off[4], T * H * 256);
+            dma_image<NI_TH>(X, a.img_fwd + L.off[1], tid);
+            dma_image<NI_TH>(X + T * H * 1024, a.img_fwd + L.off[4], tid);
+            dma_image<NI_TT>(wbuf, a.img_fwd + L.off[6], tid);
         } else {
-            stage_image(wbuf, a.img_fwd + L.off[1], T * T * 256);
-            stage_image(X, a.img_fwd + L.off[3], T * T * 256);
+            dma_image<NI_TT>(wbuf, a.img_fwd + L.off[1], tid);
+            dma_image<NI_TT>(X, a.img_fwd + L.off[3], tid);
         }
         if (h == 0) {
             float* xw = xs + (wave * 32 + li) * a.D;
@@ -718,7 +746,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                                         col(6, a.D > 6 ? xrow[6] : 0.f), col(7, 0.f));
             }
         }
-        __syncthreads();
+        PIME_LDS_BARRIER();   // the states are in LDS (the images are still in flight)
         PIME_MARK(1);
         const float* xl = xs + (wave * 32 + li) * a.D;   // this lane's state row
 
@@ -730,17 +758,17 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             {
                 f32x16 a0[T];
                 layer_first<T, 2>(lds + F.first0, xl, Do, h, a0);   // activations are applied by the consuming layer
-                PIME_NO_HOIST();
+                wait_dma_then_barrier<NI_TH + NI_TT>();               // other_net.2's image has landed
                 layer_mfma_in<T, H, 2, 1>(X, lds + F.bias[0], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
             }
             {
                 f32x16 a0[T];
                 PIME_NO_HOIST();
                 layer_first<T, 2>(lds + F.first1, xl + Do, a.Di, h, a0);
-                PIME_NO_HOIST();
+                wait_dma_then_barrier<NI_TT>();                       // integrator_net.2's
                 layer_mfma_in<T, H, 2, 1>(X + T * H * 1024, lds + F.bias[1], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
             }
-            PIME_NO_HOIST();
+            wait_dma_then_barrier<0>();                               // net.0's
             layer_mfma_in<T, T, 1, 1>(wbuf, lds + F.bias[2], lane, cat, hl);   // cat: tanh applied in place
             stash_put<T>(st, lane, cat);
             PIME_NO_HOIST();
@@ -750,10 +778,10 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             {
                 f32x16 a0[T];
                 layer_first<T, 2>(lds + F.first0, xl, a.D, h, a0);   // activations are applied by the consuming layer
-                PIME_NO_HOIST();
+                wait_dma_then_barrier<NI_TT>();                       // net.2's image has landed
                 layer_mfma_in<T, T, 2, ACT>(wbuf, lds + F.bias[0], lane, a0, a1);
             }
-            PIME_NO_HOIST();
+            wait_dma_then_barrier<0>();                               // net.4's
             layer_mfma_in<T, T, ACT, ACT>(X, lds + F.bias[1], lane, a1, hl);     // a1 (H2): activated in place
             stash_put<T>(st, lane, a1);
             PIME_NO_HOIST();
