@@ -753,6 +753,13 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
         // ---------------------------------------------------------------------------------- forward + loss gradient
         float y;
         f32x16 hl[T];  // last hidden activation; afterwards dZ of the last hidden layer
+        // Critic: the first backward step (dH2 = W4^T dZ3) runs BEFORE the weight-gradient rounds of net.4, with H2 kept in
+        // registers: net.4's transposed image lands in wbuf behind the last forward layer's MFMAs (wbuf's forward image is dead by
+        // then), the stash is not read back for act'(H2), and the stash stores have that whole dX step to drain before the rounds
+        // fetch them -- no drain barrier (3.3 us) in front of the rounds: 144 -> 141 us.  The actor kernels keep the old order: with
+        // dZ3 and dZ2 both live across the rounds hipcc spills 58 - 63 registers there (+5 us; profiles/r02_q_kernel_variant_ab.txt).
+        constexpr bool DX_FIRST = CRITIC;
+        f32x16 hk[T];  // DX_FIRST: H2, kept for act'(H2)
         if constexpr (MODULAR) {
             f32x16 cat[T];
             {
@@ -774,14 +781,15 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             PIME_NO_HOIST();
             y = layer_head<T>(lds + F.headw, lds[F.headb], lane, hl);
         } else {
-            f32x16 a1[T];
+            f32x16(&a1)[T] = hk;
             {
                 f32x16 a0[T];
                 layer_first<T, 2>(lds + F.first0, xl, a.D, h, a0);   // activations are applied by the consuming layer
                 wait_dma_then_barrier<NI_TT>();                       // net.2's image has landed
                 layer_mfma_in<T, T, 2, ACT>(wbuf, lds + F.bias[0], lane, a0, a1);
             }
-            wait_dma_then_barrier<0>();                               // net.4's
+            wait_dma_then_barrier<0>();                               // net.4's; every wave is done with net.2's (wbuf)
+            if constexpr (DX_FIRST) dma_image<NI_TT>(wbuf, a.img_bwd + Lb.off[2], tid);
             layer_mfma_in<T, T, ACT, ACT>(X, lds + F.bias[1], lane, a1, hl);     // a1 (H2): activated in place
             stash_put<T>(st, lane, a1);
             PIME_NO_HOIST();
@@ -859,7 +867,8 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             }
         }
         // ---------------------------------------------------------------------------------- backward + weight gradients
-        __syncthreads();  // forward images dead, stash visible to the whole workgroup
+        if constexpr (DX_FIRST) wait_dma_then_barrier<63>();   // forward images dead; net.4's transposed image (issued before the 64 stash stores) is in
+        else __syncthreads();                                  // forward images dead, stash visible to the whole workgroup
         PIME_MARK(3);
         float* const sl = a.slab + (size_t)blockIdx.x * a.slab_stride;   // this workgroup's partial gradients
         const bool accum = group != (int)blockIdx.x;                      // a later sample group of the same workgroup
@@ -973,30 +982,40 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             f32x16(&d)[T] = hl;                                                                     // dZ3
             f32x16 d2[T];
             PIME_MARK(4);
+            if constexpr (DX_FIRST) {
+                PIME_NO_HOIST();
+                layer_mfma<T, T, 2, false>(wbuf, nullptr, lane, d, d2);                              // dH2
+                times_act_grad<T, ACT>(d2, hk);                                                     // dZ2 (H2 from registers)
+                __syncthreads();   // wbuf read; the stash stores (issued a whole dX step ago) are visible to the workgroup
+                PIME_MARK(5);
+            }
             {
                 f32x16 acc[DwPlan<T, T>::PER];
                 float bsum;
                 PIME_NO_HOIST();
-                dw_rounds<T, T>(X, lane, wave, d, StashB{st0, T * 1024}, acc, bsum, wbuf, a.img_bwd + Lb.off[2],
+                // behind the rounds: the transposed image of the NEXT dX step (DX_FIRST: net.2's, else net.4's)
+                dw_rounds<T, T>(X, lane, wave, d, StashB{st0, T * 1024}, acc, bsum, wbuf, a.img_bwd + Lb.off[DX_FIRST ? 3 : 2],
                                 T * T * 256);
                 dw_store_full<T, T>(lane, wave, acc, bsum, sl + a.poff[4], sl + a.poff[5], accum);      // net.4
             }
-            PIME_LDS_BARRIER();
-            PIME_MARK(5);
-            PIME_NO_HOIST();
-            layer_mfma<T, T, 2, false>(wbuf, nullptr, lane, d, d2);
-            {
-                f32x16 hh[T];
-                stash_get<T>(st, lane, hh);                                                        // H2
-                times_act_grad<T, ACT>(d2, hh);                                                     // dZ2
+            if constexpr (!DX_FIRST) {
+                PIME_LDS_BARRIER();
+                PIME_MARK(5);
+                PIME_NO_HOIST();
+                layer_mfma<T, T, 2, false>(wbuf, nullptr, lane, d, d2);
+                {
+                    f32x16 hh[T];
+                    stash_get<T>(st, lane, hh);                                                    // H2
+                    times_act_grad<T, ACT>(d2, hh);                                                 // dZ2
+                }
             }
             PIME_MARK(6);
             {
                 f32x16 acc[DwPlan<T, T>::PER];
                 float bsum;
                 PIME_NO_HOIST();
-                dw_rounds<T, T>(X, lane, wave, d2, FirstB<ACT>{lds + F.first0, xs, a.D, a.D, 0, md}, acc, bsum, wbuf,
-                                a.img_bwd + Lb.off[3], T * T * 256,
+                dw_rounds<T, T>(X, lane, wave, d2, FirstB<ACT>{lds + F.first0, xs, a.D, a.D, 0, md}, acc, bsum,
+                                DX_FIRST ? nullptr : wbuf, DX_FIRST ? nullptr : a.img_bwd + Lb.off[3], DX_FIRST ? 0 : T * T * 256,
                                 (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
                 dw_store_full<T, T>(lane, wave, acc, bsum, sl + a.poff[2], sl + a.poff[3], accum);      // net.2
             }
