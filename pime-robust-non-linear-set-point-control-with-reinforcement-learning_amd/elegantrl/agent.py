@@ -368,15 +368,17 @@ class AgentPPO(AgentBase):
 
     def _update_fused(self, fused, n_steps, buf_len, batch_size, repeat_times, buf_state, buf_action, buf_r_sum,
                       buf_logprob, buf_advantage):
-        """Per optimizer step: indices -> minibatch r_sum scale -> three HIP launches that leave d(obj_united)/d(theta)
-        in the flat gradient buffer -> optional ONE all-reduce -> Adam -> re-pack of the kernel weight images.
+        """Per optimizer step: indices -> minibatch r_sum scale -> three HIP launches (critic, actor, slab reduction) that leave
+        d(obj_united)/d(theta) in the flat gradient buffer.  On one GPU the reduction also applies Adam and writes the new
+        parameter values into the packed weight images (pime_ppo_minibatch_step + image map): nothing else is launched.  Under
+        data parallelism ONE all-reduce of the flat buffer follows, then the Adam launch (which keeps the images current as well).
 
-        The launch sequence of a step is identical every time, so after one eager step (which also creates Adam's
-        state) it is captured into HIP graphs and replayed (the update is otherwise bound by ~200 us/step of host work):
-        ONE graph per step -- [gradients, Adam, re-pack] -- on a single GPU with torch's own index draw (all minibatches
-        of the update drawn at once into a table the kernels walk with a device-side cursor), else
-        two graphs -- [gradients] and [Adam, re-pack] -- split where the data-parallel all-reduce / an injected index
-        tensor / the bench's launch timer goes.  Three launch gaps per step (~15 us of ~360) is the difference."""
+        The launch sequence of a step is identical every time, so after one eager step (which also creates Adam's state) it is
+        captured into HIP graphs and replayed (the update is otherwise bound by ~200 us/step of host work): ONE graph per step
+        with torch's own index draw (all minibatches of the update drawn at once into a table the kernels walk with a device-side
+        cursor; the RCCL all-reduce is captured inside it), and from the second update on ONE graph for all n_steps steps of the
+        update; two graphs per step -- [gradients] and [Adam] -- only where something host-side sits in between (an injected index
+        tensor, the bench's launch timer, a collective that refuses capture)."""
         dev = buf_state.device
         fused.loss_sums.zero_()
         st = self._fused_static(fused, buf_len, batch_size, buf_state.shape[1], dev)
