@@ -22,9 +22,13 @@
 //          layer's transposed weight image is copied into W one slice per round, behind the MFMAs.  The bias gradient
 //          is the sum of the A operands a wave reads anyway.
 //   dH_{l-1} = W_l^T dZ_l: the forward chain code with the transposed image (mlp_device.hpp).
-// First-layer gradients (fan-in of a few floats) run on the vector ALUs from the same transposed tiles.
+// First-layer gradients (fan-in of a few floats) run on the vector ALUs from a feature-major, XOR-swizzled image (first_grad_valu).
+// The forward images arrive by LDS-DMA, each layer waiting for its own; the critic runs its first dH step in front of the last
+// layer's rounds with H2 kept in registers (DX_FIRST).  f32 MFMAs share the SIMD's issue slots with every vector / LDS instruction
+// (tools/dw_round_bench.hip): what counts in the MFMA phases is the instruction count, not latency hiding.
 // Every workgroup stores its partial gradient into its own slab (no atomics: memory-side float atomics cost 0.5 TB/s
-// here); ppo_grad_reduce_kernel sums the slabs in slab order, so gradients are reproducible bit for bit.
+// here); ppo_grad_reduce_kernel sums the slabs in slab order, so gradients are reproducible bit for bit, applies Adam to the
+// element it has just reduced and writes the new value into the packed images (pime_ppo_minibatch_step, pime_ppo_image_map).
 // PIME_FUSED_TRACE=<workgroup> prints wall-clock phase marks of that workgroup (tuning aid, not a production path).
 #include "ppo_device.hpp"
 #include "ppo_train.hpp"
