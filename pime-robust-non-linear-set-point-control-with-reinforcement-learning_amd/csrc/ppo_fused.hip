@@ -871,7 +871,9 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             }
         }
         // ---------------------------------------------------------------------------------- backward + weight gradients
-        if constexpr (DX_FIRST) wait_dma_then_barrier<63>();   // forward images dead; net.4's transposed image (issued before the 64 stash stores) is in
+        // forward images dead; net.4's transposed image is in: the only vector-memory operations issued after its DMA are the T * 16
+        // stash stores (vmcnt is a 6-bit counter: at most 63 may stay outstanding)
+        if constexpr (DX_FIRST) wait_dma_then_barrier<(T * 16 < 63 ? T * 16 : 63)>();
         else __syncthreads();                                  // forward images dead, stash visible to the whole workgroup
         PIME_MARK(3);
         float* const sl = a.slab + (size_t)blockIdx.x * a.slab_stride;   // this workgroup's partial gradients
