@@ -1138,11 +1138,24 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
             }
         }
     };
-    if (wave == 0 && !a.has_critic) {
-        if (lane == 0) scale_sh = 1.0f;
-    } else if (wave == 0) {  // critic scale from the moments (every workgroup: same slabs, same order, same value)
+    if (wave == 0 && (!a.has_critic || (sg.net != 0 && blockIdx.x != 0))) {
+        if (lane == 0) scale_sh = 1.0f;   // an actor segment needs no scale (workgroup 0 publishes it: always computed there)
+    } else if (wave == 0) {  // critic scale from the moments (every workgroup that needs it: same slabs, same order, same value)
         double m1 = 0.0, m2 = 0.0;
-        for (int s = lane; s < a.nslabs[0]; s += 64) {
+        // wave 0 is the workgroup's critical path (it also sums its share of the slabs): the moment loads of up to 512 slabs are
+        // issued together -- one memory round trip, not one per 64 slabs -- and summed in the same order as before
+        constexpr int kMaxIt = 8;
+        double2 mv[kMaxIt];
+#pragma unroll
+        for (int k = 0; k < kMaxIt; ++k) {
+            const int s = lane + 64 * k;
+            mv[k] = make_double2(0.0, 0.0);
+            if (s < a.nslabs[0])
+                mv[k] = *reinterpret_cast<const double2*>(a.slab[0] + (size_t)s * a.stride[0] + a.moments_off);
+        }
+#pragma unroll
+        for (int k = 0; k < kMaxIt; ++k) { m1 += mv[k].x; m2 += mv[k].y; }
+        for (int s = lane + 64 * kMaxIt; s < a.nslabs[0]; s += 64) {   // (grids beyond 512 slabs: not used today)
             const double* mo = reinterpret_cast<const double*>(a.slab[0] + (size_t)s * a.stride[0] + a.moments_off);
             m1 += mo[0]; m2 += mo[1];
         }
