@@ -1117,27 +1117,6 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
         step_size = a.adam.lr / (float)(1.0 - pow((double)a.adam.b1, t));
         bc2_sqrt = (float)sqrt(1.0 - pow((double)a.adam.b2, t));
     }
-    const int net_of_seg = sg.net;
-    auto emit = [&](float* q, float g) {   // store the finished gradient element and, if asked, apply Adam to its parameter
-        const float gv = a.overwrite ? g : *q + g;
-        *q = gv;
-        if (a.adam.flat_grad) {
-            const long long off = q - a.adam.flat_grad;
-            if (off >= 0 && off < a.adam.n) {   // (gradients of frozen parameters land in a dump buffer outside the flat one)
-                const float mi = a.adam.exp_avg[off] + (gv - a.adam.exp_avg[off]) * (1.0f - a.adam.b1);
-                const float vi = a.adam.exp_avg_sq[off] * a.adam.b2 + gv * gv * (1.0f - a.adam.b2);
-                a.adam.exp_avg[off] = mi;
-                a.adam.exp_avg_sq[off] = vi;
-                const float pn = a.adam.flat_param[off] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + a.adam.eps));
-                a.adam.flat_param[off] = pn;
-                if (a.adam.image_map) {   // the packed images are permutations of the parameters: keep them current here
-                    const int2 m = reinterpret_cast<const int2*>(a.adam.image_map)[off];
-                    if (m.x >= 0) a.adam.img[net_of_seg][0][m.x & 0x0fffffff] = pn;   // (bits 28..29: the net, for pime_adam_step_images)
-                    if (m.y >= 0) a.adam.img[net_of_seg][1][m.y & 0x0fffffff] = pn;
-                }
-            }
-        }
-    };
     if (wave == 0 && (!a.has_critic || (sg.net != 0 && blockIdx.x != 0))) {
         if (lane == 0) scale_sh = 1.0f;   // an actor segment needs no scale (workgroup 0 publishes it: always computed there)
     } else if (wave == 0) {  // critic scale from the moments (every workgroup that needs it: same slabs, same order, same value)
@@ -1177,6 +1156,38 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
         }
     }
     const int unit = c * 64 + lane, n4 = (sg.n + 3) / 4;
+    // Where this lane's four sums go (wave 0 finishes them), and -- wave 0 is the workgroup's critical path -- the optimizer state
+    // of those four parameters, requested NOW so that it arrives behind the slab loads instead of in a chain of its own at the end.
+    float* q4[4];
+    bool ok4[4], adam4[4];
+    float pm[4], pv[4], pp[4];
+    int2 pmap[4];
+    {
+        const int blk = unit >> 6, ln = unit & 63;   // perm_tb > 0: one lane's four accumulator registers of block (blk / TB, blk % TB)
+        const int tb = sg.perm_tb > 0 ? sg.perm_tb : 1;
+        const int row = (blk / tb) * 16 + 4 * (ln >> 4), col = (blk % tb) * 16 + (ln & 15);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (sg.perm_tb > 0) {
+                q4[k] = &sg.dst[(row + k) * sg.ldw + col];
+                ok4[k] = unit < n4 && col < sg.ncols;
+            } else {
+                q4[k] = &sg.dst[unit * 4 + k];
+                ok4[k] = unit * 4 + k < sg.n;
+            }
+            adam4[k] = false;
+            pm[k] = pv[k] = pp[k] = 0.f;
+            pmap[k] = make_int2(-1, -1);
+            if (wave == 0 && a.adam.flat_grad && ok4[k]) {
+                const long long off = q4[k] - a.adam.flat_grad;
+                if (off >= 0 && off < a.adam.n) {   // (gradients of frozen parameters land in a dump buffer outside the flat one)
+                    adam4[k] = true;
+                    pm[k] = a.adam.exp_avg[off]; pv[k] = a.adam.exp_avg_sq[off]; pp[k] = a.adam.flat_param[off];
+                    if (a.adam.image_map) pmap[k] = reinterpret_cast<const int2*>(a.adam.image_map)[off];
+                }
+            }
+        }
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (unit < n4) {
         const float* base = a.slab[sg.net] + sg.off + unit * 4;
@@ -1205,14 +1216,30 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
         for (int w = 1; w < 8; ++w) { const float4 v = part[w][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
         const float sc = sg.net == 0 ? scale_sh : 1.0f;
         const float o[4] = {t.x * sc, t.y * sc, t.z * sc, t.w * sc};
-        if (sg.perm_tb > 0) {   // unit = one lane's four accumulator registers of block (blk / TB, blk % TB)
-            const int blk = unit >> 6, ln = unit & 63;
-            const int row = (blk / sg.perm_tb) * 16 + 4 * (ln >> 4), col = (blk % sg.perm_tb) * 16 + (ln & 15);
-            if (col < sg.ncols)
-                for (int k = 0; k < 4; ++k) emit(&sg.dst[(row + k) * sg.ldw + col], o[k]);
-        } else {
-            for (int k = 0; k < 4; ++k)
-                if (unit * 4 + k < sg.n) emit(&sg.dst[unit * 4 + k], o[k]);
+        // store the finished gradient elements and, if asked, apply Adam to their parameters (torch.optim.Adam, as adam_kernel)
+        float gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            gv[k] = o[k];
+            if (ok4[k] && !a.overwrite) gv[k] += *q4[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok4[k]) continue;
+            *q4[k] = gv[k];
+            if (adam4[k]) {
+                const long long off = q4[k] - a.adam.flat_grad;
+                const float mi = pm[k] + (gv[k] - pm[k]) * (1.0f - a.adam.b1);
+                const float vi = pv[k] * a.adam.b2 + gv[k] * gv[k] * (1.0f - a.adam.b2);
+                a.adam.exp_avg[off] = mi;
+                a.adam.exp_avg_sq[off] = vi;
+                const float pn = pp[k] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + a.adam.eps));
+                a.adam.flat_param[off] = pn;
+                // the packed images are permutations of the parameters: keep them current here (bits 28..29 of a map entry: the net,
+                // for pime_adam_step_images)
+                if (pmap[k].x >= 0) a.adam.img[sg.net][0][pmap[k].x & 0x0fffffff] = pn;
+                if (pmap[k].y >= 0) a.adam.img[sg.net][1][pmap[k].y & 0x0fffffff] = pn;
+            }
         }
     }
     if (a.adam.flat_grad) {
