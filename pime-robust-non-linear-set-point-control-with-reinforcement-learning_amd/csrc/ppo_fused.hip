@@ -1110,12 +1110,16 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
     }
     if (si >= a.nseg) return;
     const ReduceSeg sg = a.seg[si];
-    float t_new = 0.f, step_size = 0.f, bc2_sqrt = 1.f;
-    if (a.adam.flat_grad) {   // every thread reads the OLD step count; the last workgroup to finish stores the new one
-        t_new = a.adam.step[0] + 1.0f;
-        const double t = (double)t_new;
-        step_size = a.adam.lr / (float)(1.0 - pow((double)a.adam.b1, t));
-        bc2_sqrt = (float)sqrt(1.0 - pow((double)a.adam.b2, t));
+    // Adam's bias corrections (two float64 pow, a dependent load of the step count in front of them) are worked out by wave 1 and
+    // handed over through LDS: wave 0, which finishes the elements, is the workgroup's critical path.  Every workgroup reads the
+    // OLD step count; the last one to finish stores the new one.
+    __shared__ float adam_sh[3];   // t_new, step_size, bc2_sqrt
+    if (a.adam.flat_grad && wave == 1) {
+        const float tn = a.adam.step[0] + 1.0f;
+        const double t = (double)tn;
+        const float ss = a.adam.lr / (float)(1.0 - pow((double)a.adam.b1, t));
+        const float bs = (float)sqrt(1.0 - pow((double)a.adam.b2, t));
+        if (lane == 0) { adam_sh[0] = tn; adam_sh[1] = ss; adam_sh[2] = bs; }
     }
     if (wave == 0 && (!a.has_critic || (sg.net != 0 && blockIdx.x != 0))) {
         if (lane == 0) scale_sh = 1.0f;   // an actor segment needs no scale (workgroup 0 publishes it: always computed there)
@@ -1211,6 +1215,8 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
     }
     part[wave][lane] = acc;
     __syncthreads();
+    const float t_new = a.adam.flat_grad ? adam_sh[0] : 0.f, step_size = a.adam.flat_grad ? adam_sh[1] : 0.f,
+                bc2_sqrt = a.adam.flat_grad ? adam_sh[2] : 1.f;
     if (wave == 0 && unit < n4) {
         float4 t = part[0][lane];
         for (int w = 1; w < 8; ++w) { const float4 v = part[w][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
