@@ -457,10 +457,18 @@ struct AdamImages {   // optional: keep the packed images current (pime_adam_ste
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
                             float* __restrict__ step, AdamImages im) {
-    const float t_new = step[0] + 1.0f;
-    const double t = (double)t_new;
-    const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
-    const float step_size = lr / bc1;
+    // the bias corrections (two float64 pow behind a dependent load of the step count) once per workgroup, not once per thread:
+    // they are ~10x the work of an element's update
+    __shared__ float consts[3];
+    if (threadIdx.x == 0) {
+        const float tn = step[0] + 1.0f;
+        const double t = (double)tn;
+        consts[0] = tn;
+        consts[1] = lr / (float)(1.0 - pow((double)b1, t));
+        consts[2] = (float)sqrt(1.0 - pow((double)b2, t));
+    }
+    __syncthreads();
+    const float t_new = consts[0], step_size = consts[1], bc2_sqrt = consts[2];
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i];
         const float mi = m[i] + (gi - m[i]) * (1.0f - b1);       // exp_avg.lerp_(grad, 1 - beta1)
