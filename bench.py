@@ -296,38 +296,78 @@ def bench_water_tank_256(args, device, json_fd):
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
     relay rank 0's stdout (the JSON line) and return non-zero if any rank fails.  The parent makes NO GPU call (importing
-    torch does not initialise HIP) and never replaces itself: the ranks are ordinary child processes."""
+    torch does not initialise HIP) and never replaces itself: the ranks are ordinary child processes, each the leader of its own
+    session so that its whole process group can be signalled.  No rank outlives the parent's interest in it: a failed rank, a
+    SIGTERM / SIGINT to the parent, an exception in the poll loop or the overall deadline (PIME_BENCH_DEADLINE_S, default 1500 s;
+    a rank stuck in RCCL init or in a collective would otherwise block the parent forever) terminate every live rank, then kill
+    what is left after a grace period."""
+    import signal
     import socket
     import subprocess
+    import threading
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
+    deadline = time.monotonic() + float(os.environ.get("PIME_BENCH_DEADLINE_S", "1500"))
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    import threading
+
+    def stop_ranks(grace=5.0):
+        live = [p for p in procs if p.poll() is None]
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            for p in live:
+                try:
+                    os.killpg(p.pid, sig)   # the rank and anything it started (start_new_session: pgid == pid)
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t_end = time.monotonic() + grace
+            while live and time.monotonic() < t_end:
+                live = [p for p in live if p.poll() is None]
+                time.sleep(0.05)
+            if not live:
+                break
+
+    class _Stop(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Stop(signum)
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
     chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    reader.start()   # drains rank 0's pipe for the whole run, so the rank can never block on a full one
     rc = 0
-    alive = set(range(n))
-    while alive:
-        for r in sorted(alive):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            alive.discard(r)
-            if code != 0 and rc == 0:
-                rc = code
-                log(f"rank {r} exited with code {code}; stopping the other ranks")
-                for q in alive:   # the survivors would block in their next collective forever
-                    procs[q].terminate()
-        time.sleep(0.05)
-    reader.join(timeout=10)
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()   # drains rank 0's pipe for the whole run, so the rank can never block on a full one
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    log(f"rank {r} exited with code {code}; stopping the other ranks")
+                    stop_ranks()   # the survivors would block in their next collective forever
+            if alive and time.monotonic() > deadline:
+                log(f"deadline reached with ranks {sorted(alive)} still running; stopping them")
+                rc = rc or 124
+                stop_ranks()
+            time.sleep(0.05)
+        reader.join(timeout=10)
+    except _Stop as stop:
+        log(f"signal {stop.args[0]} received; stopping the ranks")
+        rc = 128 + int(stop.args[0])
+    finally:
+        stop_ranks()
+        for sig, handler in old.items():
+            signal.signal(sig, handler)
     out0 = b"".join(c for c in chunks if c)
     sys.stdout.buffer.write(out0)
     sys.stdout.flush()
@@ -339,6 +379,11 @@ def launcher_selftest(json_fd):
     backend, no GPU -- what tests/test_bench_launcher.py runs in the GPU-less container."""
     from pime_amd import dist as pdist
     rank, world, local = pdist.env_rank_world()
+    if os.environ.get("PIME_SELFTEST_HANG"):   # tests: a rank that never finishes (stuck collective), with a child of its own
+        import subprocess
+        subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])
+        open(os.environ["PIME_SELFTEST_HANG"] + f".{rank}", "w").write(str(os.getpid()))
+        time.sleep(600)
     dp = pdist.init_from_env(backend="gloo", device="cpu")
     got_world = torch.distributed.get_world_size() if dp is not None else 1
     t = dp.max_over_ranks(1.0 + rank) if dp is not None else 1.0

@@ -461,8 +461,9 @@ ORACLE_API void oracle_wt_step(oracle_wt* e, const double* action, const double*
 }
 
 /* ------------------------------------------------------------------------------------------------
- * Residual action composition (elegantrl/agent_residual.py:61): tanh(a_pre) in float32, the prior term
- * state_f32 @ priorK_f64 in float64, summed in float64.
+ * Residual action composition (elegantrl/agent_residual.py:61): np.tanh(a_pre) of a float32 = the float64 tanh
+ * rounded once to float32 (implementation-independent up to ~1e-9 probability, unlike tanhf whose last ulp
+ * differs between libm / ocml / numpy); the prior term state_f32 @ priorK_f64 in float64, summed in float64.
  * ---------------------------------------------------------------------------------------------- */
 ORACLE_API void oracle_residual_action(int n, int D, const float* a_pre, const float* obs, const double* priorK,
                                        double* action) {
@@ -470,7 +471,7 @@ ORACLE_API void oracle_residual_action(int n, int D, const float* a_pre, const f
     for (int i = 0; i < n; ++i) {
         double dot = 0.0;
         for (int j = 0; j < D; ++j) dot += (double)obs[(size_t)D * i + j] * priorK[j];
-        action[i] = (double)tanhf(a_pre[i]) + dot;
+        action[i] = (double)(float)tanh((double)a_pre[i]) + dot;
     }
 }
 

@@ -119,12 +119,18 @@ __device__ __forceinline__ bool ph_lane_step(const PhParams& p, const S* __restr
     return L.t >= p.max_steps;  // gym TimeLimit; the env itself returns False (:348)
 }
 
+// np.tanh(action_f32) of the residual composition (agent_residual.py:61): the float64 tanh rounded ONCE to float32.  A float32
+// tanh differs between implementations by an ulp (ocml tanhf vs glibc tanhf vs numpy's), which now and then moves C*x*1e5 across
+// a rounding boundary of the titration table; the float64 functions agree to ~1e-16 relative, so their float32 roundings differ
+// with probability ~1e-9 per call and the device, the oracle and numpy's correctly-rounded float32 tanh all read the same cell.
+__device__ __forceinline__ double residual_tanh(float a_pre) { return (double)(float)tanh((double)a_pre); }
+
 // env action of the residual policy: np.tanh(action_f32) + state_f32 @ priorK_f64 (agent_residual.py:61)
 __device__ __forceinline__ double ph_residual_action(float a_pre, const float (&obs_in)[3], const PriorK& K) {
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) dot += (double)obs_in[j] * K.k[j];
-    return (double)tanhf(a_pre) + dot;
+    return residual_tanh(a_pre) + dot;
 }
 
 // ============================================================================================ water tank

@@ -150,7 +150,7 @@ __global__ void wt_step_kernel(WtParams p, WtPtrs<S, SI> st, const ActT* __restr
         if constexpr (RESIDUAL) {  // agent_residual.py:61
             double dot = 0.0;
             for (int j = 0; j < p.obs_dim; ++j) dot += (double)(float)obs_in[(size_t)i * p.obs_dim + j] * K.k[j];
-            a = (double)tanhf((float)act[i]) + dot;
+            a = residual_tanh((float)act[i]) + dot;
         } else {
             a = (double)act[i];
         }

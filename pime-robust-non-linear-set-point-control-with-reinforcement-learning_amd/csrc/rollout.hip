@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
         double dot = 0.0;                                                          // agent_residual.py:61
 #pragma unroll
         for (int j = 0; j < D; ++j) dot += (double)obs[j] * a.K.k[j];
-        const double a_env = (double)tanhf(a_pre) + dot;
+        const double a_env = residual_tanh(a_pre) + dot;
         float nxt[D], rew;
         bool d;
         if constexpr (ENV == 0) {

@@ -44,6 +44,55 @@ def test_world_size_mismatch_is_reported():
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr.decode()
 
 
+def _session_alive(pgid):
+    """Any RUNNING process left in the process group a rank led?  (Orphans that were killed stay behind as zombies where the
+    container's pid 1 does not reap; a zombie holds nothing.)"""
+    for pid in os.listdir("/proc"):
+        if not pid.isdigit():
+            continue
+        try:
+            fields = open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()
+        except OSError:
+            continue
+        if int(fields[2]) == pgid and fields[0] != "Z":   # after "comm)": state, ppid, pgrp
+            return True
+    return False
+
+
+def _hung_ranks(tmp_path, extra_env):
+    import time
+    tag = str(tmp_path / "rank")
+    env = dict(_clean_env(), PIME_SELFTEST_HANG=tag, **extra_env)
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--selftest-launcher"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE)
+    t_end = time.time() + 120
+    while time.time() < t_end and not all(os.path.exists(f"{tag}.{r}") for r in (0, 1)):
+        time.sleep(0.1)
+    pids = [int(open(f"{tag}.{r}").read()) for r in (0, 1)]
+    assert all(_session_alive(pid) for pid in pids)
+    return p, pids
+
+
+def test_sigterm_to_the_parent_leaves_no_rank_behind(tmp_path):
+    """a SIGTERMed parent (driver time-limit kill) must take its ranks -- and their children -- with it."""
+    import signal
+    import time
+    p, pids = _hung_ranks(tmp_path, {})
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    time.sleep(0.2)
+    assert not any(_session_alive(pid) for pid in pids), "a rank (or a child of one) survived the parent"
+
+
+def test_deadline_stops_hung_ranks(tmp_path):
+    import time
+    p, pids = _hung_ranks(tmp_path, {"PIME_BENCH_DEADLINE_S": "3"})
+    assert p.wait(timeout=60) == 124
+    assert b"deadline reached" in p.stderr.read()
+    time.sleep(0.2)
+    assert not any(_session_alive(pid) for pid in pids)
+
+
 @pytest.mark.gpu
 def test_two_rank_rehearsal_on_one_gpu():
     """`python bench.py --gpus 2` exactly as the driver starts it, rehearsed on a one-GPU box: PIME_BENCH_REHEARSE=1 puts both

@@ -11,10 +11,11 @@ auto-reset) -> trajectory writes; here every piece of what it stored is re-deriv
     reference's composition agent_residual.py:61, over TWO episodes so the in-kernel auto-reset and ensemble
     resampling are covered.
 
-Tolerances (state_mode "mixed": f32 state words, f64 x/A/B/C): pH obs/reward 2e-5 rel with the one-LUT-cell rule
-(device tanhf vs host tanhf differ by an ulp on some inputs -> on rare lanes C*x*1e5 crosses a rounding boundary and
-the neighbouring titration cell is read, |dy| <= 0.0296; such a lane is dropped until its next episode; >= 97 % of
-the lanes must stay cell-exact); water tank 2e-4 (20 Euler sub-steps in f32)."""
+Tolerances (state_mode "mixed": f32 state words, f64 x/A/B/C): pH obs/reward 2e-5 rel and EVERY lane reads the oracle's
+titration cell at every step (round 3: the residual tanh is the float64 tanh rounded once to float32 on the device and in
+the oracle, so the env action is the same float64 number on both sides; a lane whose float64 tanh differs in the last bit
+AND sits on a float32 rounding boundary may read the neighbouring cell: allowed on <= 1e-4 of the lanes per episode, observed
+0); water tank 2e-4 (20 Euler sub-steps in f32)."""
 import numpy as np
 import pytest
 import torch
@@ -112,12 +113,9 @@ def test_fused_rollout_replays_through_oracle(env_name, algo, N, md):
         assert bool(d.all()) == (tt == T - 1) and bool(d.any()) == bool(d.all())
         np.testing.assert_array_equal(done[t].astype(bool), d)
         if tt == T - 1:   # the obs row is the first observation of the next episode (in-kernel auto-reset, new ensemble draw)
-            # y of the last step is not stored (the slot holds the next episode's first observation), so the one-LUT-cell
-            # rule is applied through the reward: -(y-r)^2 (pH) moves by at most 0.0297 * (2|y-r| + 0.0297) per cell
-            err = np.abs(reward[t] - rew)
-            ok = err <= rtol * (1.0 + np.abs(rew))
+            # y of the last step is not stored (the slot holds the next episode's first observation): checked through the reward
+            ok = np.abs(reward[t] - rew) <= rtol * (1.0 + np.abs(rew))
             if is_ph:
-                assert (err[alive] <= 0.0297 * (2.0 * np.sqrt(np.abs(rew[alive])) + 0.0297) + rtol).all()
                 alive &= ok
             else:
                 assert ok[alive].all()
@@ -126,9 +124,7 @@ def test_fused_rollout_replays_through_oracle(env_name, algo, N, md):
             alive[:] = True
             continue
         if is_ph:
-            dy = np.abs(state[t + 1][:, 0] - obs[:, 0])
-            assert dy[alive].max() <= 0.0297, "pH off by more than one titration cell"
-            alive &= dy <= 1e-5
+            alive &= np.abs(state[t + 1][:, 0] - obs[:, 0]) <= 1e-5
         np.testing.assert_allclose(reward[t][alive], rew[alive], rtol=rtol, atol=rtol)
         np.testing.assert_allclose(state[t + 1][alive], obs[alive], rtol=rtol, atol=rtol)
         if not is_ph:   # the oracle continues from ITS state: re-sync it to the kernel's f32 state so errors do not compound
@@ -136,7 +132,7 @@ def test_fused_rollout_replays_through_oracle(env_name, algo, N, md):
             cols = (("h1", D - 3), ("h2", D - 2)) if stack else (("h1", 0), ("h2", 1), ("I", 3))
             for name, col in cols:
                 ref.set(name, state[t + 1][:, col].astype(np.float64))
-    assert min(cell_exact) >= 0.97, f"only {min(cell_exact):.3f} of the lanes stayed cell-exact over an episode"
+    assert min(cell_exact) >= 1.0 - 1e-4, f"only {min(cell_exact):.5f} of the lanes stayed cell-exact over an episode"
     # ensemble params were resampled by the in-kernel reset of episode 2 exactly as the oracle's
     if is_ph:
         np.testing.assert_allclose(env.get_field("qww_V"), ref.get("qww_V"), rtol=0, atol=0)
