@@ -30,6 +30,8 @@ class OracleVecEnv:
     if_discrete = False
 
     def __init__(self, kind, num_envs, seed=0, env_offset=0, table=None, **kw):
+        self._ctor = dict(kind=kind, num_envs=num_envs, seed=seed, env_offset=env_offset, table=table, **kw)
+        self.reset_count = 0
         self.kind = kind
         if kind == "ph":
             self.table = B.ph_table() if table is None else table
@@ -56,9 +58,17 @@ class OracleVecEnv:
     def fresh(self):
         return self._was_reset and self._t == 0
 
+    def clone(self, **overrides):
+        env = OracleVecEnv(**{**self._ctor, **overrides})
+        for k in ("env_name", "target_return"):
+            if hasattr(self, k):
+                setattr(env, k, getattr(self, k))
+        return env
+
     def reset(self, mask=None, out=None):
         obs = torch.from_numpy(self.core.reset(mask=mask))
         self._t, self._was_reset = 0, True
+        self.reset_count += 1
         self._last_obs = obs
         if out is not None:
             out.copy_(obs)

@@ -669,9 +669,18 @@ class AgentTD3(AgentBase):
         assert isinstance(buffer, VecReplayBuffer) and buffer.num_envs == env.num_envs
         N = env.num_envs
         steps = max(1, target_step // N)
+        if buffer.stored_slots + steps < 2:
+            steps = 2   # sampling needs one stored lock-step WITH a successor (replay.py: row i and row i + N)
+        if self._obs is not None and getattr(self, "_obs_epoch", None) != (id(env), env.reset_count):
+            # someone else reset this env since the last call (the evaluator, when it shares the training env): the cached
+            # observation is stale and the lanes sit in a post-evaluation state.  Start new episodes, and cut the newest
+            # stored lock-step off from what follows it (its successor slot will hold a reset observation).
+            buffer.cut_last_step()
+            self._obs = None
         if self._obs is None:
             self._obs = env.reset().clone()
             self._next_obs = torch.empty_like(self._obs)
+            self._obs_epoch = (id(env), env.reset_count)
         for _ in range(steps):
             obs = self._obs
             with torch.no_grad():
@@ -718,13 +727,13 @@ class AgentTD3(AgentBase):
         sums = torch.zeros(2, device=dev)
         obj_actor = obj_critic = torch.zeros((), device=dev)
         graphs = self._graphs if (vec and self.use_hip_graphs and dev.type == "cuda") else None
-        key = (id(buffer), batch_size, buffer.stored_slots if vec else 0, buffer.next_slot if vec else 0)
+        key = (id(buffer), batch_size)
         for i in range(n_steps):
             soft = i % self.update_freq == 0
-            if vec and self.use_hip_graphs and dev.type == "cuda" and i >= 2:
-                # the step's launch sequence is fixed once Adam's state exists: capture it twice (with / without the delayed
-                # soft update) and replay.  The sampler's index bounds are baked in, so the graphs live for this call only
-                # unless the ring is full and the cursor unchanged.
+            if vec and self.use_hip_graphs and dev.type == "cuda" and (i >= 2 or (graphs and graphs.get("key") == key)):
+                # the step's launch sequence is fixed once Adam's state exists (two eager steps): capture it twice (with /
+                # without the delayed soft update) and replay.  The sampler reads its index bounds from the device
+                # (VecReplayBuffer._bounds), so the two graphs serve every later call as well.
                 if graphs is None or graphs.get("key") != key:
                     graphs = self._capture_updates(buffer, batch_size, key)
                     self._graphs = graphs

@@ -142,6 +142,7 @@ class VecReplayBuffer:
         self.if_full = False
         self.now_len = 0
         self.if_on_policy = False
+        self._bounds = torch.zeros(2, dtype=torch.int64, device=self.device)   # see update_now_len_before_sample
 
     @property
     def stored_slots(self):
@@ -160,22 +161,32 @@ class VecReplayBuffer:
             self.next_slot, self.if_full = 0, True
 
     def update_now_len_before_sample(self):
+        """Also publishes the sampler's bounds to the device (rows that have a successor, the oldest slot): `sample_indices`
+        reads them there, so an update captured into a HIP graph keeps sampling the right rows as the ring fills and its
+        cursor moves -- the graph survives from one `update_net` call to the next."""
         self.now_len = self.stored_slots * self.num_envs
+        n_slots = self.stored_slots
+        host = torch.tensor([max(n_slots - 1, 0) * self.num_envs, self.next_slot if self.if_full else 0], dtype=torch.int64)
+        self._bounds.copy_(host)
 
     def sample_indices(self, batch_size, out=None):
-        """Flat row indices [batch] of transitions with a valid successor, and their successors' indices."""
-        n_slots = self.stored_slots
-        assert n_slots >= 2, "need two stored steps before sampling"
+        """Flat row indices [batch] of transitions with a valid successor, and their successors' indices.  Uniform over the
+        (stored_slots - 1) * N rows whose successor slot is stored: a 62-bit draw reduced modulo the row count that lives on
+        the device (bias < 2^-40; torch.randint(high) would bake `high` into a captured graph)."""
+        assert self.stored_slots >= 2, "need two stored steps before sampling"
         N = self.num_envs
-        u = torch.randint((n_slots - 1) * N, size=(batch_size,), device=self.device) if out is None else \
-            torch.randint((n_slots - 1) * N, size=(batch_size,), device=self.device, out=out)
-        if self.if_full:   # slots in age order start at the write cursor (the oldest); the newest (cursor - 1) is excluded
-            slot = (u // N + self.next_slot) % self.slots
-            idx = slot * N + u % N
-            nxt = ((slot + 1) % self.slots) * N + u % N
-        else:
-            idx, nxt = u, u + N
-        return idx, nxt
+        u = torch.randint(2 ** 62, size=(batch_size,), device=self.device) if out is None else \
+            torch.randint(2 ** 62, size=(batch_size,), device=self.device, out=out)
+        u = u % self._bounds[0]
+        lane = u % N
+        slot = (u // N + self._bounds[1]) % self.slots   # slots in age order start at the oldest (the write cursor once full)
+        return slot * N + lane, ((slot + 1) % self.slots) * N + lane
+
+    def cut_last_step(self):
+        """The newest stored lock-step gets mask 0: called when its successor slot will NOT hold the lanes' next observation
+        (the env was reset by someone else in between), so no target bootstraps across the cut."""
+        if self.stored_slots:
+            self.other[(self.next_slot - 1) % self.slots, :, 1] = 0.0
 
     def sample_batch(self, batch_size):
         """(reward, mask, action, state, next_state), shapes as ReplayBuffer.sample_batch."""

@@ -115,6 +115,11 @@ def train_and_evaluate(args):
     args.init_before_training(if_main=is_main)
     cwd, env, agent = args.cwd, args.env, args.agent
     env_eval = args.env_eval if args.env_eval is not None else (env if hasattr(env, "num_envs") else deepcopy(env))
+    if hasattr(env, "num_envs") and env_eval is env and not getattr(args.agent, "if_on_policy", False):
+        # An off-policy agent CONTINUES the running episodes of its env from one explore call to the next, and the evaluator
+        # resets the env it is given: on a shared vectorised env every evaluation would cut the episodes (the reference shares
+        # the env too, train.py:227-228, and stores that broken transition once per evaluation).  Evaluate on a clone.
+        env_eval = env.clone()
 
     if "integrator_dim" in args.Modular_kwargs:
         agent.init(args.net_dim, env.state_dim, env.action_dim, args.Modular_kwargs["integrator_dim"], args.if_per)

@@ -138,6 +138,18 @@ class VecControlEnv:
         self._t_all = 0
         self._t_lanes = None
         self._was_reset = False
+        self.reset_count = 0   # host-initiated resets so far: lets a caller that caches observations across calls (the
+        #                        off-policy agents) notice that someone else -- the evaluator -- reset the env in between
+
+    def clone(self, **overrides):
+        """A second, independent env of the same configuration (own handle, own state slab): `copy.deepcopy` for an env whose
+        state lives in HBM.  Used to give an off-policy run its own evaluation env (run.py: the evaluator resets the env it is
+        given, which must not be the one whose running episodes the agent continues)."""
+        env = type(self)(**{**self._ctor, **overrides})
+        for k in ("env_name", "target_return"):
+            if hasattr(self, k):
+                setattr(env, k, getattr(self, k))
+        return env
 
     # -- lifetime ------------------------------------------------------------------------------------------
     def close(self):
@@ -180,6 +192,7 @@ class VecControlEnv:
         native.check(self._lib.pime_env_reset(self._h, native.ptr(mask_dev), native.ptr(draws), native.ptr(obs),
                                               self._stream()), "pime_env_reset")
         self._was_reset = True
+        self.reset_count += 1
         return obs
 
     def _lane_steps(self):
@@ -268,6 +281,7 @@ class VecControlEnv:
         native.check(self._lib.pime_env_reset_h(self._h, native.ptr(mask_dev), native.ptr(draws), native.ptr(obs),
                                                 self._stream()), "pime_env_reset_h")
         self._was_reset = True
+        self.reset_count += 1
         return obs
 
     def step_h(self, action, auto_reset=True, out_obs=None, out_reward=None, out_done=None):
@@ -395,6 +409,7 @@ class VecPH(VecControlEnv):
                  qww_V=(0.005, 0.015), qc_V=(0.0015, 0.0025), P_control_K=(-0.02, 0.02, 0.035),
                  MHCl_step=1e-5, MHCl_len=100000, chem=None, action_punishment=0., action_change_punishment=0.,
                  integral_punish=0., sample_t=20.0, distance_threshold=0.05):
+        self._ctor = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
         cfg = native.EnvCfg()
         native.check(native.lib().pime_env_cfg_default(native.ENV_PH, C.byref(cfg)))
         self.table = ph_table(MHCl_len, MHCl_step, chem)
@@ -460,6 +475,7 @@ class VecWaterTank(VecControlEnv):
                  a1=(0.0015, 0.0024), a2=(0.0015, 0.0024), Kp=(0.07, 0.17), A1=1, A2=1, G=980, sample_t=2, n_discrete=20,
                  noise_scale=0.01, z1=1, P_max_action=10.0, P_control_K=None, integral_punish=0.,
                  distance_threshold=0.05):
+        self._ctor = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
         cfg = native.EnvCfg()
         native.check(native.lib().pime_env_cfg_default(native.ENV_WT, C.byref(cfg)))
         cfg.n_envs = num_envs

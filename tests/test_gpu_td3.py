@@ -75,7 +75,6 @@ def test_residual_td3_on_the_hip_env_with_graph_replay():
     buf = make_buffer(ag, env, 2 ** 17)
     assert isinstance(buf, VecReplayBuffer)
     r0 = get_episode_return_vec(env, ag.eval_policy).mean()       # the prior P controller alone
-    ag._obs = None
     steps = ag.explore_env(env, buf, 60 * N, 1.0, 0.99)
     assert steps == 60 * N and buf.stored_slots == 60
     done_rows = (buf.other[:60, :, 1] == 0).sum().item()
@@ -88,10 +87,11 @@ def test_residual_td3_on_the_hip_env_with_graph_replay():
     w1 = torch.cat([p.detach().reshape(-1) for p in ag.act.parameters()])
     assert torch.isfinite(w1).all() and not torch.equal(w0, w1)
     # a few more rounds: the residual must not destroy the prior controller's return (sanity of the composed agent)
+    graphs = ag._graphs
     for _ in range(6):
         ag.explore_env(env, buf, 50 * N, 1.0, 0.99)
         ag.update_net(buf, 50 * N, 512, 1)
-    ag._obs = None
+    assert ag._graphs is graphs, "the two update graphs must survive from one update_net call to the next (device-side sampler bounds)"
     r1 = get_episode_return_vec(env, ag.eval_policy).mean()
     assert np.isfinite(r1) and r1 > 2.0 * r0, f"return collapsed: prior {r0:.1f} -> {r1:.1f}"   # returns are negative
     env.close()

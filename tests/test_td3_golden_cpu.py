@@ -91,3 +91,80 @@ def test_residual_td3_composition_and_vector_loop():
     assert any(not torch.equal(v, before[k]) for k, v in ag.act.state_dict().items() if k != "priorK")
     assert torch.equal(ag.act.priorK, before["priorK"])
     assert any(not torch.equal(v, tgt_before[k]) for k, v in ag.cri_target.state_dict().items())
+
+
+def _td3_train_args(env, tmp_path, env_eval=None):
+    from pime_amd.elegantrl.agent_residual import AgentResidualTD3
+    from pime_amd.elegantrl.run import Arguments
+    N = env.num_envs
+    env.env_name, env.target_return = "wt-oracle", 1e9
+    args = Arguments(if_on_policy=False)
+    args.agent = AgentResidualTD3(backend=OracleBackend(), device="cpu")
+    args.env, args.env_eval = env, env_eval
+    args.cwd, args.if_remove = str(tmp_path / "run"), False
+    args.net_dim, args.batch_size, args.repeat_times = 32, 64, 1
+    args.target_step, args.max_memo = 7 * N, 64 * N       # 7 lock-steps per explore call: the evaluations fall mid-episode
+    args.break_step = 6 * 7 * N
+    args.eval_gap, args.eval_times1, args.eval_times2 = 2, N, N
+    args.num_threads, args.random_seed = 1, 3
+    args.residual_kwargs = {"init_K": env.K.reshape(-1, 1)}
+    args.if_residual, args.fix_K = True, True
+    return args
+
+
+def _assert_successor_rows(buf, stored, integral_max=25.0):
+    """Every stored transition with mask != 0 must be followed, one slot later in the same lane, by ITS env successor: same
+    episode (same set-point r) and the integrator advanced by that step's error, clip(I + (r - h2'), +-25)
+    (nonlinear_watertank.py:822-825).  A row whose successor slot holds a reset observation must carry mask 0."""
+    s, m = buf.state[:stored].double(), buf.other[:stored, :, 1]
+    cont = m[:-1] != 0
+    assert cont.any()
+    same_r = s[1:, :, 2] == s[:-1, :, 2]
+    want_I = (s[:-1, :, 3] + (s[:-1, :, 2] - s[1:, :, 1])).clamp(-integral_max, integral_max)
+    ok_I = (s[1:, :, 3] - want_I).abs() <= 1e-5
+    assert bool((same_r & ok_I)[cont].all()), "a stored transition continues into a row that is not its successor"
+
+
+def test_td3_train_loop_keeps_successor_rows_across_evaluations(tmp_path):
+    """the evaluator resets the env it is given.  (a) train_and_evaluate gives an off-policy agent on a
+    vectorised env its own evaluation env (a clone), so the running episodes are never cut; (b) if a caller shares the env
+    anyway, explore_vec_env notices the foreign reset, starts new episodes and cuts the newest stored step off (mask 0)."""
+    from pime_amd.elegantrl.run import get_episode_return_vec, make_buffer, train_and_evaluate
+    N = 16
+    env = OracleVecEnv("wt", N, seed=3, reward_type="distance", max_steps=30)
+    ag, buf = train_and_evaluate(_td3_train_args(env, tmp_path))
+    stored = buf.stored_slots
+    assert stored == 6 * 7 and not buf.if_full
+    _assert_successor_rows(buf, stored)
+    ends = (buf.other[:stored, :, 1] == 0).sum().item()
+    assert ends == N * (stored // 30), "with its own evaluation env no episode of the training env is cut short"
+    # (b) a shared env: evaluate on the training env between two explore calls
+    env2 = OracleVecEnv("wt", N, seed=4, reward_type="distance", max_steps=30)
+    args = _td3_train_args(env2, tmp_path)
+    ag2 = args.agent
+    ag2.init(32, env2.state_dim, 1)
+    ag2.init_residual(args.residual_kwargs)
+    buf2 = make_buffer(ag2, env2, 64 * N)
+    ag2.explore_env(env2, buf2, 7 * N, 1.0, 0.99)
+    get_episode_return_vec(env2, ag2.eval_policy)          # resets env2 and runs it a full episode
+    ag2.explore_env(env2, buf2, 7 * N, 1.0, 0.99)
+    assert buf2.stored_slots == 14
+    assert bool((buf2.other[6, :, 1] == 0).all()), "the step in front of the foreign reset must be cut (mask 0)"
+    assert bool((buf2.other[:6, :, 1] != 0).all())
+    _assert_successor_rows(buf2, 14)
+
+
+def test_td3_first_update_with_one_lock_step(tmp_path):
+    """target_step < 2 * num_envs used to store ONE lock-step and then assert in the sampler."""
+    from pime_amd.elegantrl.agent_residual import AgentResidualTD3
+    from pime_amd.elegantrl.run import make_buffer
+    N = 16
+    env = OracleVecEnv("wt", N, seed=3, reward_type="distance", max_steps=30)
+    ag = AgentResidualTD3(backend=OracleBackend(), device="cpu")
+    ag.init(32, env.state_dim, 1)
+    ag.init_residual({"init_K": env.K.reshape(-1, 1)})
+    buf = make_buffer(ag, env, 8 * N)
+    assert ag.explore_env(env, buf, N, 1.0, 0.99) == 2 * N and buf.stored_slots == 2
+    oa, oc = ag.update_net(buf, N, 32, 1)
+    assert np.isfinite(oa) and np.isfinite(oc)
+    assert ag.explore_env(env, buf, N, 1.0, 0.99) == N and buf.stored_slots == 3
