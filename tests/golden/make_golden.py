@@ -451,6 +451,88 @@ def golden_ppo_update_wide():
     save("ppo_update_wide.npz", **out)
 
 
+def golden_ppo_update_multi():
+    """update_net at MULTI-WORKGROUP batch sizes, with the reference's own gradients (VERDICT r02 task 3).
+
+    `ppo_update_wide.npz` has batch 128 / 256 = one workgroup of the fused HIP gradient kernel, so its slab reduction over many
+    workgroups, the second-group accumulation (batch > 65 536) and the one-graph path at large B were pinned only to torch
+    autograd on the same device.  Here: the reference pH ResidualIntegratorModularPPO, net_dim 128 (run_ph_changing.sh), ONE
+    explore_env chunk of >= 8 192 transitions, then from the same initial weights and buffer
+      mw  : update_net(batch 4 096, repeat 2)   -> 4 optimizer steps, 16 workgroups of 256 samples per net
+      big : update_net(batch 70 000, repeat 20) -> 2 optimizer steps; 70 000 > 65 536 = 256 workgroups x 256 samples, so 18 of the
+            workgroups take a second 256-sample group and accumulate (the reference's torch.randint draws with replacement, so a
+            batch larger than the buffer is its ordinary code path, agent.py:630)
+    recording per case: the minibatch indices, EVERY parameter's .grad after the first backward() (agent.py:655), the weights
+    after the first optimizer.step() and after the last, and the returned losses."""
+    from elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from elegantrl.env import PreprocessEnv
+    from elegantrl.replay import ReplayBuffer
+    out = {}
+    tag, net_dim, target_step, lam = "ph128", 128, 8192, 0.99
+    env = PreprocessEnv(make_ph(), if_print=False)
+    seed = 5
+    env.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    agent = AgentResidualIntegratorModularPPO()
+    agent.lambda_gae_adv = lam
+    agent.init(net_dim, env.state_dim, env.action_dim, env.n_integrator)
+    agent.device = torch.device("cpu")
+    agent.init_residual({"init_K": env.K.reshape(-1, 1)})
+    agent.init_actor_zero()
+    agent.fix_K()
+    with torch.no_grad():
+        agent.act.net[-1].weight.normal_(0, 0.05)
+    buffer = ReplayBuffer(max_len=target_step + env.max_step, state_dim=env.state_dim, action_dim=1, if_on_policy=True,
+                          if_per=False, if_gpu=True)
+    sd_act0 = {k: v.clone() for k, v in agent.act.state_dict().items()}
+    sd_cri0 = {k: v.clone() for k, v in agent.cri.state_dict().items()}
+    out.update(_sd_to_np(f"{tag}:act0", sd_act0))
+    out.update(_sd_to_np(f"{tag}:cri0", sd_cri0))
+    steps = agent.explore_env(env, buffer, target_step, 1.0, 0.99)
+    buffer.update_now_len_before_sample()
+    out[f"{tag}:steps"] = np.array(steps)
+    out[f"{tag}:buf_state"] = buffer.buf_state[:buffer.now_len].copy()
+    out[f"{tag}:buf_other"] = buffer.buf_other[:buffer.now_len].copy()
+    for case, batch, repeat, draw_seed in (("mw", 4096, 2, 99), ("big", 70000, 20, 98)):
+        # same start for every case: the reference's own optimizer rebuild (init_actor_zero, agent.py:569-574), then the weights
+        agent.init_actor_zero()
+        agent.act.load_state_dict(sd_act0)
+        agent.cri.load_state_dict(sd_cri0)
+        idx_log, snaps = [], []
+        orig_randint, orig_step = torch.randint, agent.optimizer.step
+
+        def rec_randint(*a, **k):
+            v = orig_randint(*a, **k)
+            idx_log.append(v.numpy().astype(np.int32))
+            return v
+
+        def rec_step(*a, **k):
+            if not snaps:   # the first backward() of the update: the reference's gradients of obj_united
+                for net_tag, net in (("act", agent.act), ("cri", agent.cri)):
+                    for name, p in net.named_parameters():
+                        if p.grad is not None:
+                            out[f"{tag}:{case}:grad1:{net_tag}.{name}"] = p.grad.detach().numpy().copy()
+            r = orig_step(*a, **k)
+            if not snaps:
+                out.update(_sd_to_np(f"{tag}:{case}:act_step1", agent.act.state_dict()))
+                out.update(_sd_to_np(f"{tag}:{case}:cri_step1", agent.cri.state_dict()))
+            snaps.append(1)
+            return r
+        torch.randint, agent.optimizer.step = rec_randint, rec_step
+        torch.manual_seed(draw_seed)
+        obj_a, obj_c = agent.update_net(buffer, target_step, batch, repeat)
+        torch.randint = orig_randint
+        assert len(snaps) == int(repeat * buffer.now_len / batch) == len(idx_log)
+        out[f"{tag}:{case}:indices"] = np.array(idx_log)
+        out[f"{tag}:{case}:obj"] = np.array([obj_a, obj_c])
+        out[f"{tag}:{case}:hyper"] = np.array([net_dim, target_step, batch, repeat, lam, 0.99, agent.learning_rate,
+                                               agent.ratio_clip, agent.lambda_entropy])
+        out.update(_sd_to_np(f"{tag}:{case}:act1", agent.act.state_dict()))
+        out.update(_sd_to_np(f"{tag}:{case}:cri1", agent.cri.state_dict()))
+    save("ppo_update_multi.npz", **out)
+
+
 def _ppo_cases(out, cases, with_eval):
     from elegantrl.agent_residual import AgentResidualIntegratorModularPPO
     from elegantrl.env import PreprocessEnv
@@ -571,7 +653,8 @@ def main():
                 ph_stepresponse=golden_ph_stepresponse, wt_rollouts=golden_wt_rollouts,
                 wt_stepresponse=golden_wt_stepresponse, wt_stacking=golden_wt_stacking,
                 gae=golden_gae, nets=golden_nets, ppo_update=golden_ppo_update_and_explore,
-                ppo_update_wide=golden_ppo_update_wide, td3_update=golden_td3_update)
+                ppo_update_wide=golden_ppo_update_wide, ppo_update_multi=golden_ppo_update_multi,
+                td3_update=golden_td3_update)
     for name, fn in jobs.items():
         if only and name not in only:
             continue

@@ -237,3 +237,51 @@ def test_save_load_model_round_trip(tmp_path):
     assert set(want) == {"a_std_log", "priorK", "other_net.0.weight", "other_net.0.bias", "other_net.2.weight",
                          "other_net.2.bias", "integrator_net.0.weight", "integrator_net.0.bias", "integrator_net.2.weight",
                          "integrator_net.2.bias", "net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias"}
+
+
+@pytest.mark.parametrize("case", ["mw", "big"])
+def test_update_net_multi_workgroup_golden_host_logic(case):
+    """tests/golden/ppo_update_multi.npz (batch 4 096 / 70 000, the reference's first-step .grad tensors) through this package's
+    update_net host logic on CPU tensors (torch autograd; oracle GAE): what the GPU test compares the HIP kernels with is first
+    shown to be reproduced by the same host code path -- gradients 2e-5 of each tensor's largest entry (70 000-row
+    sums in a different thread order than the single-threaded reference run), weights 2e-6 abs."""
+    from pime_amd.elegantrl import agent_residual
+    from pime_amd.elegantrl.replay import ReplayBuffer
+    g = load_golden("ppo_update_multi.npz")
+    tag = "ph128"
+    hyper = g[f"{tag}:{case}:hyper"]
+    net_dim, target_step, batch, repeat, lam = int(hyper[0]), int(hyper[1]), int(hyper[2]), int(hyper[3]), float(hyper[4])
+    state, other = g[f"{tag}:buf_state"], g[f"{tag}:buf_other"]
+    ag = agent_residual.AgentResidualIntegratorModularPPO(backend=OracleBackend(), device="cpu")
+    ag.lambda_gae_adv = lam
+    ag.init(net_dim, 3, 1, 1)
+    ag.init_residual({"init_K": np.array([-0.02, 0.02, 0.035]).reshape(-1, 1)})
+    ag.fix_K()
+    ag.act.load_state_dict(_sd(g, f"{tag}:act0"))
+    ag.cri.load_state_dict(_sd(g, f"{tag}:cri0"))
+    buf = ReplayBuffer(len(state) + 8, 3, 1, if_on_policy=True, device="cpu")
+    buf.extend_buffer(state, other)
+    idx = torch.from_numpy(g[f"{tag}:{case}:indices"].astype(np.int64))
+    ag.index_hook = lambda step, L, B: idx[step]
+    grads = {}
+    orig_step = ag.optimizer.step
+
+    def rec_step(*a, **k):
+        if not grads:
+            for net_tag, net in (("act", ag.act), ("cri", ag.cri)):
+                for name, p in net.named_parameters():
+                    if p.grad is not None and p.requires_grad:
+                        grads[f"{net_tag}.{name}"] = p.grad.detach().numpy().copy()
+        return orig_step(*a, **k)
+    ag.optimizer.step = rec_step
+    obj_a, obj_c = ag.update_net(buf, target_step, batch, repeat)
+    want_keys = {k[len(f"{tag}:{case}:grad1:"):] for k in g.files if k.startswith(f"{tag}:{case}:grad1:")}
+    assert set(grads) == want_keys
+    for k in want_keys:
+        want = g[f"{tag}:{case}:grad1:{k}"]
+        np.testing.assert_allclose(grads[k], want, rtol=0, atol=2e-5 * float(np.abs(want).max()) + 1e-12, err_msg=k)
+    for name, net in (("act1", ag.act), ("cri1", ag.cri)):
+        want = _sd(g, f"{tag}:{case}:{name}")
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), want[k].numpy(), rtol=0, atol=2e-6, err_msg=f"{name}.{k}")
+    np.testing.assert_allclose([obj_a, obj_c], g[f"{tag}:{case}:obj"], rtol=1e-4, atol=1e-6)

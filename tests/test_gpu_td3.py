@@ -95,3 +95,52 @@ def test_residual_td3_on_the_hip_env_with_graph_replay():
     r1 = get_episode_return_vec(env, ag.eval_policy).mean()
     assert np.isfinite(r1) and r1 > 2.0 * r0, f"return collapsed: prior {r0:.1f} -> {r1:.1f}"   # returns are negative
     env.close()
+
+
+def test_config2_residual_td3_4096_lanes_replays_through_oracle():
+    """BASELINE.json config 2 as worded: "Water-tank env, 4 096 vectorised instances, residual TD3, 1 MI355X".  The env side of
+    AgentResidualTD3.explore_env at 4 096 lanes x 210 lock-steps (one in-kernel auto-reset with ensemble resampling at step
+    200) is replayed through OracleWT (fp64, nonlinear_watertank.py:800-826,890-939): the ring buffer's recorded residual
+    actions + the prior term give the env action; observations / rewards 2e-4 (mixed mode: 20 Euler sub-steps in f32), done
+    masks exact, reset observations bit-equal.  Then 210 optimizer steps at batch 4 096 from the two persistent HIP graphs.
+    (The update arithmetic itself is pinned to the reference's weights by test_td3_update_matches_reference_on_gpu.)"""
+    import oracle
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.agent_residual import AgentResidualTD3
+    from pime_amd.elegantrl.run import make_buffer
+    N, seed, offset, T, steps = 4096, 11, 8192, 200, 210
+    env = gym_control.make_vec(gym_control.WT_INTEGRATOR, N, device=DEV, state_mode="mixed", seed=seed, env_offset=offset,
+                               reward_type="distance")
+    assert env.max_step == T
+    torch.manual_seed(0)
+    ag = AgentResidualTD3(device=DEV)
+    ag.init(128, env.state_dim, 1)
+    ag.init_residual({"init_K": env.K.reshape(-1, 1)})
+    with torch.no_grad():
+        ag.act.net[-1].weight.normal_(0, 0.05)   # a non-trivial residual
+    buf = make_buffer(ag, env, 2 ** 21)
+    assert ag.explore_env(env, buf, steps * N, 1.0, 0.99) == steps * N and buf.stored_slots == steps
+    torch.cuda.synchronize()
+    state, other = buf.state[:steps + 1], buf.other[:steps]
+    with torch.no_grad():   # the env action exactly as explore_vec_env composed it (float32, same device, same ops)
+        a_env = torch.stack([other[t, :, 2:3] + state[t] @ ag.act.priorK for t in range(steps)])[:, :, 0].double().cpu().numpy()
+    assert float(other[:, :, 2].abs().max()) <= 1.0
+    state, other = state.cpu().numpy(), other.cpu().numpy()
+    ref = oracle.OracleWT(N, max_steps=T, reward_type="distance", seed=seed, env_offset=offset)
+    np.testing.assert_array_equal(state[0], ref.reset())
+    for t in range(steps - 1):   # slot t + 1 is stored for t < steps - 1 (the newest step's successor is still in the agent)
+        obs, _, rew, d = ref.step(a_env[t], auto_reset=True)
+        assert bool(d.all()) == (t == T - 1) and bool(d.any()) == bool(d.all())
+        np.testing.assert_array_equal(other[t, :, 1] == 0, d)
+        np.testing.assert_allclose(other[t, :, 0], rew, rtol=2e-4, atol=2e-4, err_msg=f"reward, step {t}")
+        if t == T - 1:
+            np.testing.assert_array_equal(state[t + 1], obs)    # first observation of the next episode: Philox draws bit-equal
+            continue
+        np.testing.assert_allclose(state[t + 1], obs, rtol=2e-4, atol=2e-4, err_msg=f"observation, step {t}")
+        for name, col in (("h1", 0), ("h2", 1), ("I", 3)):      # re-sync the fp64 oracle to the kernel's f32 state
+            ref.set(name, state[t + 1][:, col].astype(np.float64))
+    np.testing.assert_allclose(env.get_field("a1"), ref.get("a1"), rtol=1e-7)
+    oa, oc = ag.update_net(buf, steps * N, 4096, 1)
+    torch.cuda.synchronize()
+    assert np.isfinite(oa) and np.isfinite(oc) and ag._graphs and True in ag._graphs
+    env.close()
