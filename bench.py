@@ -430,13 +430,90 @@ def bench_water_tank_td3(args, device, json_fd):
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
+def bench_mixed16(args, device, json_fd, rank, world, dp):
+    """BASELINE config 5 (SURVEY.md section 8d cfg 5), one rank's slice: 8 192 pH lanes + 8 192 Integrator water-tank lanes in
+    state_mode "mixed16" (binary16 storage of the integrated error and of the observation / reward rows; float32 / float64
+    arithmetic), ensemble ranges 1.5x the registered widths (domain-randomised sweep), one ResidualIntegratorModularPPO
+    net_dim 128 per env family.  One step = the two fused rollouts side by side on two HIP streams (50-step and 200-step
+    episodes: 409 600 + 1 638 400 env-steps written as binary16 rows) + both PPO updates (batch 65 536, repeat 8: 50 + 200
+    optimizer steps on the fused gradient kernels, each trajectory widened to float32 once per update).  Weak scaling: every rank
+    owns 16 384 lanes; per optimizer step one flat-gradient all-reduce per agent."""
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from pime_amd.elegantrl.run import make_buffer
+    from pime_amd.vec_env import VecWaterTank
+    lanes = LANES // 2
+    ph = gym_control.make_vec(gym_control.PH_V35, lanes, device=device, state_mode="mixed16", seed=0, env_offset=rank * lanes,
+                              qww_V=(0.0045, 0.0165), qc_V=(0.00125, 0.00275))
+    wt = VecWaterTank(lanes, device=device, state_mode="mixed16", seed=0, env_offset=rank * lanes, reward_type="distance",
+                      a1=(0.0012, 0.0027), a2=(0.0012, 0.0027), Kp=(0.045, 0.195))
+    stacks = []
+    for env in (ph, wt):
+        torch.manual_seed(0)
+        agent = AgentResidualIntegratorModularPPO(device=device)
+        agent.lambda_gae_adv = LAMBDA
+        agent.init(NET_DIM, env.state_dim, 1, env.n_integrator)
+        agent.init_residual({"init_K": env.K.reshape(-1, 1)})
+        agent.init_actor_zero()
+        agent.fix_K()
+        agent.dp = dp
+        if dp is not None:
+            dp.broadcast_module(agent.act, agent.cri)
+        buf = make_buffer(agent, env, lanes * env.max_step)
+        assert buf.state.dtype == torch.float16 and agent._fused_rollout_ok(env)
+        stacks.append((env, agent, buf, torch.cuda.Stream(device=device)))
+    torch.manual_seed(1000 + rank)
+
+    def step():
+        cur = torch.cuda.current_stream()
+        total = 0
+        for env, agent, buf, stream in stacks:     # the two halves of the batch roll out side by side
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                total += agent.explore_env(env, buf, lanes * env.max_step, 1.0, GAMMA)
+        for env, agent, buf, stream in stacks:
+            cur.wait_stream(stream)
+        for env, agent, buf, stream in stacks:
+            agent.update_net(buf, lanes * env.max_step, BATCH, REPEAT)
+        return total
+
+    def sync():
+        torch.cuda.synchronize()
+        if dp is not None:
+            dp.barrier()
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    total = sum(step() for _ in range(args.steps))
+    sync()
+    dt = time.perf_counter() - t0
+    if dp is not None:
+        dt = dp.max_over_ranks(dt)
+        total = dp.sum_over_ranks(total)
+    if rank == 0:
+        out = {"metric": "env-steps/sec (rollout+update), mixed pH + water-tank batch, fp16 state, 16384 lanes/GPU",
+               "value": total / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE config 5 rank slice: 8192 pH v35 lanes x 50-step episodes + 8192 water-tank "
+                                      "Integrator-v2 lanes (reward 'distance') x 200-step episodes, state_mode mixed16 (binary16 "
+                                      "I / observation / reward storage, f32 math, f64 x), ensemble ranges x1.5, "
+                                      "ResidualIntegratorModularPPO net_dim 128 per family, batch 65536, repeat 8",
+                          "lanes_per_gpu": LANES, "parallelism": f"dp{world}"}}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dp is not None:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ph", choices=["ph", "wt", "wt_td3", "wt256"],
+    ap.add_argument("--workload", default="ph", choices=["ph", "wt", "wt_td3", "wt256", "mixed16"],
                     help="ph: the headline config (BASELINE config 3); wt: config 2, water tank, 4096 lanes x 200 steps "
                          "(reported for DESIGN.md; the headline metric is the ph line)")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
@@ -470,6 +547,8 @@ def main():
     if dp is not None:
         world = torch.distributed.get_world_size()   # the RCCL communicator's size is what the JSON line reports
 
+    if args.workload == "mixed16":
+        return bench_mixed16(args, device, json_fd, rank, world, dp)
     if args.workload == "wt":
         return bench_water_tank(args, device, json_fd)
     if args.workload == "wt256":

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 9
+#define PIME_ABI_VERSION 10
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -314,6 +314,14 @@ int pime_rollout_supported(const pime_env* env, int32_t kind, int32_t md);
 int pime_rollout(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
                  const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, float* state,
                  float* action, float* noise, float* reward, uint8_t* done, pime_stream stream);
+/* The same launch for a handle in PIME_STATE_MIXED16 mode (BASELINE.json config 5, "fp16 state"; pH or Integrator water tank):
+ * state [dev] binary16[n_steps+1, N, obs_dim] and reward [dev] binary16[n_steps, N] (torch.float16); action and noise stay
+ * float32 (they feed the log-probabilities of the update).  Semantics of a chain of pime_env_step_residual_h calls: the policy
+ * and the prior term see the binary16 observation, the integrated error is rounded to binary16 after every step (its storage
+ * format in this mode), x / h1 / h2 / the plant never are.  replaces agent_residual.py:52-69 as pime_rollout does. */
+int pime_rollout_h(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
+                   const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, uint16_t* state,
+                   float* action, float* noise, uint16_t* reward, uint8_t* done, pime_stream stream);
 
 /* replaces: self.optimizer.step() of the single Adam over both nets (elegantrl/agent.py:565-566,656-657; no weight
  * decay, no amsgrad) when every parameter lives in ONE flat tensor.  All [dev] float32[n]; step [dev] float32[2], zeroed

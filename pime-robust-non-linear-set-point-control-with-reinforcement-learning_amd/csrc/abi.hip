@@ -671,20 +671,22 @@ int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const flo
 
 int pime_rollout_supported(const pime_env* e, int32_t kind, int32_t md) {
     if (e == nullptr) return 0;
-    if (e->cfg.state_mode != PIME_STATE_MIXED) return 0;
+    if (e->cfg.state_mode != PIME_STATE_MIXED && e->cfg.state_mode != PIME_STATE_MIXED16) return 0;
     if (e->cfg.kind != PIME_ENV_PH && e->cfg.num_stack != 0) {   // Stacking1/4/10 under a plain actor (no integrator column)
         const int S = e->cfg.num_stack;
         if (kind != PIME_MLP_PLAIN_ACTOR || !(S == 1 || S == 4 || S == 10)) return 0;
+        if (e->cfg.state_mode == PIME_STATE_MIXED16) return 0;   // binary16 rows: pH and the Integrator tank (config 5)
     }
     if (kind != PIME_MLP_PLAIN_ACTOR && kind != PIME_MLP_MODULAR_ACTOR) return 0;
     return (md == 64 || md == 128) && !family16(kind, md) ? 1 : 0;
 }
 
-int pime_rollout(pime_env* e, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
-                 const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, float* state,
-                 float* action, float* noise, float* reward, uint8_t* done, pime_stream stream) {
+static int rollout_common(pime_env* e, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
+                          const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, void* state,
+                          float* action, float* noise, void* reward, uint8_t* done, bool half, pime_stream stream) {
     PIME_REQUIRE(e != nullptr, "NULL env handle");
-    PIME_REQUIRE(e->cfg.state_mode == PIME_STATE_MIXED, "pime_rollout: needs an env handle in PIME_STATE_MIXED mode");
+    PIME_REQUIRE(e->cfg.state_mode == (half ? PIME_STATE_MIXED16 : PIME_STATE_MIXED),
+                 "pime_rollout needs an env handle in PIME_STATE_MIXED mode, pime_rollout_h one in PIME_STATE_MIXED16 mode");
     PIME_REQUIRE(packed_actor && a_std_log && priorK && state && action && noise && reward && done && n_steps >= 1,
                  "pime_rollout: bad arguments");
     PIME_REQUIRE(pime_rollout_supported(e, kind, md), "pime_rollout: no fused rollout for actor kind %d width %d "
@@ -700,8 +702,28 @@ int pime_rollout(pime_env* e, int32_t kind, int32_t md, const float* packed_acto
     a.img = packed_actor; a.a_std_log = a_std_log;
     for (int j = 0; j < e->obs_dim; ++j) a.K.k[j] = priorK[j];
     a.n_steps = n_steps; a.noise_seed = noise_seed; a.noise_epoch = noise_epoch;
-    a.state = state; a.action = action; a.noise = noise; a.reward = reward; a.done = done;
+    a.action = action; a.noise = noise; a.done = done;
+    if (half) {
+        a.I16 = a.env == 0 ? e->ph16.I : e->wt16.I;
+        a.state_h = static_cast<half_t*>(state); a.reward_h = static_cast<half_t*>(reward);
+    } else {
+        a.state = static_cast<float*>(state); a.reward = static_cast<float*>(reward);
+    }
     return launch_rollout(kind, md, a, static_cast<hipStream_t>(stream));
+}
+
+int pime_rollout(pime_env* e, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
+                 const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, float* state,
+                 float* action, float* noise, float* reward, uint8_t* done, pime_stream stream) {
+    return rollout_common(e, kind, md, packed_actor, a_std_log, priorK, n_steps, noise_seed, noise_epoch, state, action, noise,
+                          reward, done, false, stream);
+}
+
+int pime_rollout_h(pime_env* e, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
+                   const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, uint16_t* state,
+                   float* action, float* noise, uint16_t* reward, uint8_t* done, pime_stream stream) {
+    return rollout_common(e, kind, md, packed_actor, a_std_log, priorK, n_steps, noise_seed, noise_epoch, state, action, noise,
+                          reward, done, true, stream);
 }
 
 int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

@@ -208,6 +208,16 @@ __device__ __forceinline__ void wt_lane_noise(const WtParams& p, uint32_t gid, c
     }
 }
 
+// sqrt of the Euler sub-steps (:805-809).  float64 state: IEEE sqrt (reference precision).  float32 state (PIME_STATE_MIXED*): the
+// hardware v_sqrt_f32 (<= 1 ulp) instead of the correctly rounded sqrtf, which hipcc expands into the same instruction plus a
+// ~10-instruction Newton / scale fix-up -- 40 of them per env step made the kernel VALU-bound at 0.32 of HBM (profiles/
+// r02_m_env_pmc.json).  One ulp of a root is a 6e-8 relative perturbation of a smooth map, inside the mode's stated 2e-4.
+template <typename S>
+__device__ __forceinline__ S tank_sqrt(S v) {
+    if constexpr (sizeof(S) == 4) return __builtin_amdgcn_sqrtf(v);
+    else return sqrt(v);
+}
+
 // One env step for env action `a` (NOT clipped, :258-260); returns done (:816-821)
 template <typename S>
 __device__ __forceinline__ bool wt_lane_step(const WtParams& p, double a, double z1n, double z2n, WtLane<S>& L,
@@ -218,7 +228,7 @@ __device__ __forceinline__ bool wt_lane_step(const WtParams& p, double a, double
     const S A1 = (S)p.A1, A2 = (S)p.A2, G = (S)p.G, dt = (S)p.dt;
     const S lo = S(-0.0), hi = (S)INFINITY;                            // Box(low=-0, high=inf) :252-257
     for (int s = 0; s < p.n_discrete; ++s) {                            // :805-809, both roots from the OLD h1,h2
-        const S s1 = sqrt(2 * G * h1), s2 = sqrt(2 * G * h2);
+        const S s1 = tank_sqrt<S>(2 * G * h1), s2 = tank_sqrt<S>(2 * G * h2);
         const S n1 = h1 + (-L.a1 / A1 * s1 + L.kp / A1 * u) * dt;
         const S n2 = h2 + (L.a1 / A2 * s1 - L.a2 / A2 * s2) * dt;
         h1 = clip(n1, lo, hi);

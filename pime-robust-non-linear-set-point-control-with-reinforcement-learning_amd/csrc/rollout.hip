@@ -42,6 +42,20 @@ __device__ __forceinline__ void layer_first_regs(const float* __restrict__ w0, c
 
 constexpr int kRolloutThreads = 128;
 
+__device__ __forceinline__ PhPtrs<float, half_t> with_half_I(const PhPtrs<float>& s, half_t* I16) {
+    PhPtrs<float, half_t> h{};
+    h.x = s.x; h.A = s.A; h.B = s.B; h.C = s.C; h.qww = s.qww; h.qc = s.qc; h.r = s.r; h.last_a = s.last_a; h.I = I16;
+    h.t = s.t; h.episode = s.episode; h.table = s.table;
+    return h;
+}
+__device__ __forceinline__ WtPtrs<float, half_t> with_half_I(const WtPtrs<float>& s, half_t* I16) {
+    WtPtrs<float, half_t> h{};
+    h.h1 = s.h1; h.h2 = s.h2; h.r = s.r; h.a1 = s.a1; h.a2 = s.a2; h.kp = s.kp; h.I = I16; h.frames = s.frames; h.head = s.head;
+    h.t = s.t; h.episode = s.episode;
+    return h;
+}
+__device__ __forceinline__ float through_half(float v) { return (float)(half_t)v; }
+
 // ENV 0: pH, obs [y, r, I];  1: water tank, Integrator obs [h1, h2, r, I];  2: water tank, Stacking obs = the last STACK frames
 // [h1, h2, r], oldest first (nonlinear_watertank.py:1056-1208).  For ENV 2 the observation registers ARE the frame deque: a step
 // shifts them by one frame and appends the new one, a reset fills every frame with the first (:1181-1183); the SoA ring in HBM
@@ -66,11 +80,19 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
 
     PhLane<float> E;   // exactly one of the two lanes is live, selected at compile time
     WtLane<float> W;
-    if constexpr (ENV == 0) ph_lane_load<float>(a.p, a.st, i, E);
-    else wt_lane_load<float>(a.wp, a.wst, i, W);
+    // binary16 storage (PIME_STATE_MIXED16, wave-uniform): I lives as binary16 in the handle, observation / reward rows are
+    // binary16, and everything a step-per-launch *_h kernel would have stored and re-read is rounded through binary16 here
+    const bool h16 = ENV != 2 && a.I16 != nullptr;
+    if constexpr (ENV == 0) {
+        if (h16) ph_lane_load<float>(a.p, with_half_I(a.st, a.I16), i, E);
+        else ph_lane_load<float>(a.p, a.st, i, E);
+    } else {
+        if (h16) wt_lane_load<float>(a.wp, with_half_I(a.wst, a.I16), i, W);
+        else wt_lane_load<float>(a.wp, a.wst, i, W);
+    }
     float obs[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) obs[j] = a.state[(size_t)D * i + j];
+    for (int j = 0; j < D; ++j) obs[j] = h16 ? (float)a.state_h[(size_t)D * i + j] : a.state[(size_t)D * i + j];
     for (int t = 0; t < a.n_steps; ++t) {
         PIME_NO_HOIST();
         float a_avg;
@@ -134,21 +156,39 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
             }
         }
         const size_t k = (size_t)t * N + i;
+        if (h16) {   // what the next step reads back is what binary16 storage kept
+            if constexpr (ENV == 0) E.I = through_half(E.I);
+            else W.I = through_half(W.I);
+#pragma unroll
+            for (int j = 0; j < D; ++j) nxt[j] = through_half(nxt[j]);
+        }
         if (writer) {
             a.action[k] = a_pre;
             a.noise[k] = eps;
-            a.reward[k] = rew;
             a.done[k] = (uint8_t)d;
-            float* s = a.state + ((size_t)(t + 1) * N + i) * D;
+            if (h16) {
+                a.reward_h[k] = (half_t)rew;
+                half_t* s = a.state_h + ((size_t)(t + 1) * N + i) * D;
 #pragma unroll
-            for (int j = 0; j < D; ++j) s[j] = nxt[j];
+                for (int j = 0; j < D; ++j) s[j] = (half_t)nxt[j];
+            } else {
+                a.reward[k] = rew;
+                float* s = a.state + ((size_t)(t + 1) * N + i) * D;
+#pragma unroll
+                for (int j = 0; j < D; ++j) s[j] = nxt[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < D; ++j) obs[j] = nxt[j];
     }
     if (writer) {
-        if constexpr (ENV == 0) ph_lane_store<float>(a.p, a.st, i, E);
-        else wt_lane_store<float>(a.wp, a.wst, i, W);
+        if constexpr (ENV == 0) {
+            if (h16) ph_lane_store<float>(a.p, with_half_I(a.st, a.I16), i, E);
+            else ph_lane_store<float>(a.p, a.st, i, E);
+        } else {
+            if (h16) wt_lane_store<float>(a.wp, with_half_I(a.wst, a.I16), i, W);
+            else wt_lane_store<float>(a.wp, a.wst, i, W);
+        }
         if constexpr (ENV == 2) {   // the frame ring of the step-per-launch kernels: slot j = frame j, oldest at slot 0
 #pragma unroll
             for (int j = 0; j < D; ++j) a.wst.frames[(size_t)j * N + i] = obs[j];

@@ -19,5 +19,8 @@ struct RolloutArgs {
     uint32_t noise_epoch;
     float *state, *action, *noise, *reward;  // [n_steps+1, N, D], [n_steps, N] x3
     uint8_t* done;                           // [n_steps, N]
+    // PIME_STATE_MIXED16 (pime_rollout_h): the handle's binary16 integrated-error array (st.I / wst.I are NULL then) and binary16
+    // observation / reward rows instead of `state` / `reward`; the policy sees the binary16 observation, as with the *_h steps
+    half_t *I16, *state_h, *reward_h;
 };
 }  // namespace pime

@@ -233,7 +233,8 @@ class AgentPPO(AgentBase):
 
     def _vec_env_step(self, env, a_pre, obs, out_obs, out_reward, out_done):
         """Plain PPO: the env sees tanh(a_pre) (agent.py:599)."""
-        return env.step(torch.tanh(a_pre), auto_reset=True, out_obs=out_obs, out_reward=out_reward, out_done=out_done)
+        step = env.step_h if out_obs.dtype == torch.float16 else env.step
+        return step(torch.tanh(a_pre), auto_reset=True, out_obs=out_obs, out_reward=out_reward, out_done=out_done)
 
     def explore_vec_env(self, env, buffer, target_step, reward_scale, gamma):
         """Lock-step rollout of all lanes for whole episodes until >= target_step transitions are stored.
@@ -249,7 +250,14 @@ class AgentPPO(AgentBase):
         fused = self._fused_rollout_ok(env)
         # Every lane sits at the start of an episode either because nothing ran yet (-> reset) or because the last
         # step of the previous rollout auto-reset it inside the kernel (-> just read the observation back).
-        if env.fresh:
+        half = buffer.state.dtype == torch.float16   # env in state_mode "mixed16": binary16 observation / reward rows
+        assert buffer.state.dtype == getattr(env, "trajectory_dtype", torch.float32), "buffer / env row dtype mismatch"
+        if half:
+            if env.fresh:
+                buffer.state[0].copy_(env.observe())   # float32 -> binary16: the rounding the *_h kernels apply
+            else:
+                env.reset_h(out=buffer.state[0])
+        elif env.fresh:
             env.observe(out=buffer.state[0])
         else:
             env.reset(out=buffer.state[0])
@@ -267,7 +275,7 @@ class AgentPPO(AgentBase):
                 with torch.no_grad():
                     if std is None:
                         std = self.act.a_std_log.detach().exp()
-                    a_avg = self.policy_mean(obs)
+                    a_avg = self.policy_mean(obs.float() if half else obs)
                     noise = torch.randn_like(a_avg) if self.noise_hook is None else self.noise_hook(t, a_avg.shape)
                     a_pre = a_avg + noise * std
                     buffer.action[t] = a_pre

@@ -34,9 +34,10 @@ class AgentResidualPPO(AgentPPO, Residual):
         return np.tanh(action) + state @ self.priorK
 
     def _vec_env_step(self, env, a_pre, obs, out_obs, out_reward, out_done):
-        # the composition above is fused into the env kernel's prologue
-        return env.step_residual(a_pre, obs, self.priorK.reshape(-1), auto_reset=True, out_obs=out_obs,
-                                 out_reward=out_reward, out_done=out_done)
+        # the composition above is fused into the env kernel's prologue (binary16 rows: the *_h form of the same kernel)
+        step = env.step_residual_h if obs.dtype == torch.float16 else env.step_residual
+        return step(a_pre, obs, self.priorK.reshape(-1), auto_reset=True, out_obs=out_obs, out_reward=out_reward,
+                    out_done=out_done)
 
     def _rollout_priorK(self):
         return self.priorK.reshape(-1)

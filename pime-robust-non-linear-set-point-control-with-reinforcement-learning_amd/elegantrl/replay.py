@@ -85,13 +85,17 @@ class ReplayBuffer:
 class TrajectoryBuffer:
     """Time-major on-policy store for N lock-stepped env lanes: state [T,N,D], reward/mask [T,N], action/noise [T,N,A]."""
 
-    def __init__(self, horizon, num_envs, state_dim, action_dim, device):
+    def __init__(self, horizon, num_envs, state_dim, action_dim, device, dtype=torch.float32):
+        """dtype: storage type of the observation and reward rows -- float32, or float16 for an env in state_mode "mixed16"
+        (BASELINE.json config 5: the env kernels write binary16 rows; `sample_all` widens them once per update, the PPO
+        kernels compute in float32).  Actions, noise and masks stay float32."""
         self.device = torch.device(device)
         self.horizon, self.num_envs, self.state_dim, self.action_dim = horizon, num_envs, state_dim, action_dim
         f = dict(dtype=torch.float32, device=self.device)
+        self.dtype = dtype
         # one extra state slot: the step kernel writes the successor observation of slot t straight into slot t+1
-        self.state = torch.zeros((horizon + 1, num_envs, state_dim), **f)
-        self.reward = torch.zeros((horizon, num_envs), **f)
+        self.state = torch.zeros((horizon + 1, num_envs, state_dim), dtype=dtype, device=self.device)
+        self.reward = torch.zeros((horizon, num_envs), dtype=dtype, device=self.device)
         self.mask = torch.zeros((horizon, num_envs), **f)
         self.action = torch.zeros((horizon, num_envs, action_dim), **f)
         self.noise = torch.zeros((horizon, num_envs, action_dim), **f)
@@ -112,7 +116,8 @@ class TrajectoryBuffer:
     def sample_all(self):
         T = self.length
         flat = lambda x: x[:T].reshape(T * self.num_envs, *x.shape[2:])  # noqa: E731
-        return flat(self.reward), flat(self.mask), flat(self.action), flat(self.noise), flat(self.state)
+        wide = (lambda x: x.float()) if self.dtype != torch.float32 else (lambda x: x)   # binary16 rows: widened once per update
+        return wide(flat(self.reward)), flat(self.mask), flat(self.action), flat(self.noise), wide(flat(self.state))
 
 
 class VecReplayBuffer:

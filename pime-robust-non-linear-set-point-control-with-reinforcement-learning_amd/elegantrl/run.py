@@ -93,7 +93,8 @@ def make_buffer(agent, env, max_memo, if_per=False):
     if hasattr(env, "num_envs") and on_policy:
         per_episode = env.num_envs * env.max_step
         episodes = max(1, -(-max_memo // per_episode))
-        return TrajectoryBuffer(episodes * env.max_step, env.num_envs, env.state_dim, env.action_dim, agent.device)
+        return TrajectoryBuffer(episodes * env.max_step, env.num_envs, env.state_dim, env.action_dim, agent.device,
+                                dtype=getattr(env, "trajectory_dtype", torch.float32))
     if hasattr(env, "num_envs"):   # off-policy agent on a vectorised env: the per-lane device ring
         return VecReplayBuffer(max_memo, env.num_envs, env.state_dim, env.action_dim, agent.device)
     return ReplayBuffer(max_len=max_memo + env.max_step, state_dim=env.state_dim,

@@ -327,9 +327,15 @@ class VecControlEnv:
 
     @property
     def supports_fused_rollout(self):
-        """The one-launch-per-episode rollout kernel needs mixed-precision state and in-kernel (Philox) draws; which
-        observation / actor shapes it serves is the library's answer (`rollout_supported`)."""
-        return self.cfg.state_mode == native.STATE_MIXED and not self.draws.injects
+        """The one-launch-per-episode rollout kernel needs mixed-precision state (float32 words, or binary16 storage: "mixed16")
+        and in-kernel (Philox) draws; which observation / actor shapes it serves is the library's answer (`rollout_supported`)."""
+        return self.cfg.state_mode in (native.STATE_MIXED, native.STATE_MIXED16) and not self.draws.injects
+
+    @property
+    def trajectory_dtype(self):
+        """dtype of the observation / reward rows this env hands to a trajectory buffer: float16 in state_mode "mixed16"
+        (BASELINE.json config 5 "fp16 state"), else float32."""
+        return torch.float16 if self.cfg.state_mode == native.STATE_MIXED16 else torch.float32
 
     def rollout_supported(self, packed_actor):
         """Does the fused rollout kernel serve this env with this packed actor (kind / width)?  (pime_rollout_supported)"""
@@ -345,7 +351,9 @@ class VecControlEnv:
             assert t_.is_contiguous() and t_.device == self.device
         k = np.ascontiguousarray(np.asarray(priorK, dtype=np.float64).reshape(-1))
         assert k.size == self.obs_dim and packed_actor.D == self.obs_dim
-        native.check(self._lib.pime_rollout(
+        assert state.dtype == reward.dtype == self.trajectory_dtype and action.dtype == noise.dtype == torch.float32
+        fn = self._lib.pime_rollout_h if state.dtype == torch.float16 else self._lib.pime_rollout
+        native.check(fn(
             self._h, native.MLP_MODULAR_ACTOR if packed_actor.kind == "modular_actor" else native.MLP_PLAIN_ACTOR,
             packed_actor.md, native.ptr(packed_actor.packed), native.ptr(a_std_log), native.ptr(k), int(n_steps),
             C.c_uint64(noise_seed), C.c_uint32(noise_epoch), native.ptr(state), native.ptr(action), native.ptr(noise),

@@ -24,7 +24,8 @@ def test_header_library_binding_agree():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in pime_hip.h but not exported by libpime_hip.so"
     assert sorted(nt.EXPORTS) == declared, "ctypes binding and header disagree"
-    assert nt.lib().pime_abi_version() == nt.ABI_VERSION == 9
+    header_version = int(re.search(r"#define PIME_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "pime_hip.h")).read()).group(1))
+    assert nt.lib().pime_abi_version() == nt.ABI_VERSION == header_version
 
 
 def test_cfg_struct_layout_matches_c():
