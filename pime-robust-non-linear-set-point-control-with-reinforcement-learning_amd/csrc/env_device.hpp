@@ -200,11 +200,22 @@ __device__ __forceinline__ void wt_lane_noise(const WtParams& p, uint32_t gid, c
     } else {
         double ua, ub;
         philox_pair(p.seed, gid, (uint32_t)L.episode, (uint32_t)(L.t + 1), STREAM_NOISE, ua, ub);
-        const double rad = sqrt(-2.0 * log(1.0 - ua)), ang = 6.283185307179586476925286766559 * ub;
-        double sn, cs;
-        sincos(ang, &sn, &cs);
-        z1n = p.noise_scale * (rad * cs);
-        z2n = p.noise_scale * (rad * sn);
+        if constexpr (sizeof(S) == 4) {
+            // float32 state: Box-Muller on the float32 pipes (v_log / v_sqrt / v_sin / v_cos; the last two take revolutions) --
+            // the float64 log + sqrt + sincos of the exact form are several hundred float64 instructions per lane-step, more than
+            // the 20 Euler sub-steps they perturb.  Same Philox uniforms; the normals differ from the float64 ones by ~1e-6
+            // relative, i.e. ~1e-8 of a level after the 0.01 noise scale: far inside the mode's 2e-4.
+            const float u1 = (float)(1.0 - ua);                      // in [2^-53, 1]: log finite
+            const float rad = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1)), rev = (float)ub;
+            z1n = (double)((float)p.noise_scale * (rad * __builtin_amdgcn_cosf(rev)));
+            z2n = (double)((float)p.noise_scale * (rad * __builtin_amdgcn_sinf(rev)));
+        } else {
+            const double rad = sqrt(-2.0 * log(1.0 - ua)), ang = 6.283185307179586476925286766559 * ub;
+            double sn, cs;
+            sincos(ang, &sn, &cs);
+            z1n = p.noise_scale * (rad * cs);
+            z2n = p.noise_scale * (rad * sn);
+        }
     }
 }
 

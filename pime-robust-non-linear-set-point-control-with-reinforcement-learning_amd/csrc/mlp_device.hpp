@@ -155,17 +155,17 @@ __device__ __forceinline__ void stage_image(float* __restrict__ lds, const float
     stage_batches<1>(dst, src, n4, nthr, i);
 }
 
-// tanh for the hidden layers in 7 VALU ops, two of them transcendental (ocml's tanhf inlined 64x per layer drove the
-// kernel to the 256-VGPR cap and is ~40 ops): 1 - 2/(e^{2|x|}+1) via v_exp_f32 / v_rcp_f32, sign restored.  Absolute
-// error < 1.5e-7 everywhere; the RELATIVE error grows below |x| ~ 1e-3 (cancellation against 1), which is immaterial
-// for a hidden unit that feeds a dot product (an earlier version avoided it with a 9th-order polynomial branch for
-// |x| < 0.25: +6 VALU ops per activation, ~10 us per actor gradient kernel, no measurable change in any parity test).
-// The ENV action tanh (agent_residual.py:61) does not use this: it is ocml tanhf, as numpy's within 1 ulp.
+// tanh for the hidden layers in 5 VALU ops, two of them transcendental (ocml's tanhf inlined 64x per layer drove the
+// kernel to the 256-VGPR cap and is ~40 ops): 1 - 2/(e^{2x}+1) via v_exp_f32 / v_rcp_f32.  The formula holds for either sign
+// (x -> -inf: e -> 0, t -> -1; x > 44: e = inf, rcp -> 0, t -> 1), so no |x| / copysign pair around it (rounds 1-2 had them: 7
+// ops; with f32 MFMAs every vector instruction is time on the SIMD -- the modular actor's gradient kernel evaluates 514 of
+// these per lane).  Absolute error < 2e-7 everywhere; the RELATIVE error grows below |x| ~ 1e-3 (cancellation against 1),
+// which is immaterial for a hidden unit that feeds a dot product (an earlier version avoided it with a 9th-order polynomial
+// branch for |x| < 0.25: +6 VALU ops per activation, ~10 us per actor gradient kernel, no measurable change in any parity test).
+// The ENV action tanh (agent_residual.py:61) does not use this: it is the float64 tanh rounded once (env_device.hpp).
 __device__ __forceinline__ float fast_tanh(float x) {
-    const float ax = fabsf(x);
-    const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);  // e^{2|x|}  (inf for |x| > 44: rcp -> 0, t -> 1)
-    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    return copysignf(t, x);
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);  // e^{2x}
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);   // (explicit fma: the library is built with -ffp-contract=off)
 }
 
 template <int ACT>
@@ -304,7 +304,7 @@ __device__ __forceinline__ void layer_mfma_gate(const float* __restrict__ wp, in
                 const int idx = (kt * 16 + s) * PERK + q;
                 if (idx < NV) {
                     const float hq = activate<ACT>(v[idx >> 4][idx & 15]);
-                    v[idx >> 4][idx & 15] = ACT == 0 ? (hq > 0.f ? 1.f : 0.f) : 1.f - hq * hq;
+                    v[idx >> 4][idx & 15] = ACT == 0 ? (hq > 0.f ? 1.f : 0.f) : fmaf(-hq, hq, 1.f);
                 }
             }
         }

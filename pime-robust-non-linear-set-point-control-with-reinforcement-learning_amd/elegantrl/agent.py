@@ -12,6 +12,8 @@ What differs from the reference, by design:
   * under torch.distributed every optimizer step all-reduces ONE flat gradient buffer, and the buffer-global
     advantage normalisation (agent.py:707) all-reduces three moments.
 """
+import contextlib
+import gc
 import os
 
 import numpy as np
@@ -22,6 +24,21 @@ from .. import dist as pdist
 from ..backend import HipBackend
 from .net import Actor, ActorPPO, CriticAdv, CriticTwin
 from .replay import TrajectoryBuffer, VecReplayBuffer
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a HIP graph is being captured: a collection that happens to run inside the capture
+    can finalise an unrelated object that owns device resources (an env handle of an earlier run: pime_env_destroy -> hipFree),
+    and a hipFree under stream capture aborts the process (seen once in tests/test_gpu_td3.py, "Garbage-collecting" in the
+    fatal error's stack)."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class AgentBase:
@@ -464,7 +481,7 @@ class AgentPPO(AgentBase):
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread of a data-parallel run may touch the HIP API meanwhile
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with _no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 for thunk in thunks:
                     thunk()
             return g
@@ -768,7 +785,7 @@ class AgentTD3(AgentBase):
             for soft in (True, False):
                 res = torch.zeros(2, device=self.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with _no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                     oa, oc = self._one_update(buffer, batch_size, soft)
                     res.copy_(torch.stack([oa, oc]))
                 out[soft] = {"graph": g, "out": res}

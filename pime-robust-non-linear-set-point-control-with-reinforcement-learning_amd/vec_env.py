@@ -159,6 +159,8 @@ class VecControlEnv:
 
     def __del__(self):
         try:
+            if torch.cuda.is_current_stream_capturing():
+                return   # a hipFree under stream capture would abort the process: leak the slab until exit instead
             self.close()
         except Exception:  # interpreter shutdown
             pass
