@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 10
+#define PIME_ABI_VERSION 11
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -322,6 +322,26 @@ int pime_rollout(pime_env* env, int32_t kind, int32_t md, const float* packed_ac
 int pime_rollout_h(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
                    const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, uint16_t* state,
                    float* action, float* noise, uint16_t* reward, uint8_t* done, pime_stream stream);
+
+/* -- fused evaluation ---------------------------------------------------------------------------------------------
+ * replaces: get_episode_return (elegantrl/run.py:600-619: max_step x [act(s) -> env.step], summed rewards) on every lane, and the
+ * set-point step-response protocols (utils/test.py:1369-1407 pH, :209-349 water tank; utils/robust_test.py:4-46), as ONE launch:
+ * n_steps steps of every lane under the DETERMINISTIC residual policy a_env = tanh(mean(s)) + s @ priorK -- no exploration noise,
+ * no auto-reset, no per-step host round trip -- with the env state in registers.  Handles in PIME_STATE_MIXED or PIME_STATE_F64
+ * mode (the latter reproduces the reference's float64 protocol records to 1e-11), pH or Integrator water tank, Philox draws.
+ *   kind         PIME_MLP_PLAIN_ACTOR | PIME_MLP_MODULAR_ACTOR with packed_actor = its pime_mlp_pack image (width 64 / 128), or -1:
+ *                the prior controller alone (get_linear_action, ph.py:227-231), packed_actor ignored
+ *   seg_len      0: plain episode.  > 0: every seg_len steps (from step 0) a protocol segment starts: set-point r =
+ *                setpoints[segment], integrated error 0, step counter 0, plant state kept -- what the protocols' `env.reset();
+ *                set_state(last); set_r(r)` leaves (:1377-1381); setpoints [host] float64[n_setpoints <= 16]
+ *   ret          [dev] float64[N] or NULL: += the launch's per-lane sum of (float32) rewards, as run.py:613 accumulates them
+ *   trace        [dev] float64[n_steps, 6, N] or NULL, per step and lane: pH (y, r, I BEFORE the step; action, reward, x after it: the
+ *                protocol's per-step records, utils/test.py:1388-1396), water tank (h1, h2, r, I after the step; reward; action)
+ * Leaves every lane n_steps further; the caller resets the env before it rolls out again. */
+int pime_rollout_eval_supported(const pime_env* env, int32_t kind, int32_t md);
+int pime_rollout_eval(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const double* priorK, int32_t n_steps,
+                      int32_t seg_len, const double* setpoints, int32_t n_setpoints, double* ret, double* trace,
+                      pime_stream stream);
 
 /* replaces: self.optimizer.step() of the single Adam over both nets (elegantrl/agent.py:565-566,656-657; no weight
  * decay, no amsgrad) when every parameter lives in ONE flat tensor.  All [dev] float32[n]; step [dev] float32[2], zeroed

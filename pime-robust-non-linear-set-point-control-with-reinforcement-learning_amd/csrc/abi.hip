@@ -9,6 +9,7 @@
 #include "env_state.hpp"
 #include "ppo_train.hpp"
 #include "rollout.hpp"
+#include "rollout_eval.hpp"
 
 namespace pime {
 
@@ -275,6 +276,25 @@ int h2d_from_double(const FieldRef& f, int n, const double* in, hipStream_t s) {
 }
 
 }  // namespace
+
+template <typename S>
+static int rollout_eval_t(pime_env* e, const PhPtrs<S>& ph, const WtPtrs<S>& wt, int32_t kind, int32_t md, const float* packed_actor,
+                          const double* priorK, int32_t n_steps, int32_t seg_len, const double* setpoints, int32_t n_setpoints,
+                          double* ret, double* trace, pime_stream stream) {
+    EvalArgs<S> a{};
+    a.env = e->cfg.kind == PIME_ENV_PH ? 0 : 1;
+    a.n = e->cfg.n_envs;
+    a.env_offset = e->cfg.env_offset;
+    if (a.env == 0) { a.p = e->ph; a.p.auto_reset = 0; a.st = ph; }
+    else { a.wp = e->wt; a.wp.auto_reset = 0; a.wst = wt; }
+    a.img = packed_actor;
+    for (int j = 0; j < e->obs_dim; ++j) a.K.k[j] = priorK[j];
+    a.n_steps = n_steps; a.seg_len = seg_len;
+    for (int j = 0; j < n_setpoints; ++j) a.setpoint[j] = setpoints[j];
+    a.ret = ret; a.trace = trace;
+    return launch_rollout_eval<S>(kind, md, a, static_cast<hipStream_t>(stream));
+}
+
 
 extern "C" {
 
@@ -724,6 +744,34 @@ int pime_rollout_h(pime_env* e, int32_t kind, int32_t md, const float* packed_ac
                    float* action, float* noise, uint16_t* reward, uint8_t* done, pime_stream stream) {
     return rollout_common(e, kind, md, packed_actor, a_std_log, priorK, n_steps, noise_seed, noise_epoch, state, action, noise,
                           reward, done, true, stream);
+}
+
+int pime_rollout_eval_supported(const pime_env* e, int32_t kind, int32_t md) {
+    if (e == nullptr) return 0;
+    if (e->cfg.state_mode != PIME_STATE_MIXED && e->cfg.state_mode != PIME_STATE_F64) return 0;
+    if (e->cfg.kind != PIME_ENV_PH && e->cfg.num_stack != 0) return 0;   // pH and the Integrator tank
+    if (kind == -1) return 1;                                            // the prior controller alone
+    if (kind != PIME_MLP_PLAIN_ACTOR && kind != PIME_MLP_MODULAR_ACTOR) return 0;
+    return (md == 64 || md == 128) && !family16(kind, md) ? 1 : 0;
+}
+
+int pime_rollout_eval(pime_env* e, int32_t kind, int32_t md, const float* packed_actor, const double* priorK, int32_t n_steps,
+                      int32_t seg_len, const double* setpoints, int32_t n_setpoints, double* ret, double* trace,
+                      pime_stream stream) {
+    PIME_REQUIRE(e != nullptr, "NULL env handle");
+    PIME_REQUIRE(pime_rollout_eval_supported(e, kind, md), "pime_rollout_eval: not served for this handle / actor kind %d width %d "
+                 "(pime_rollout_eval_supported)", kind, md);
+    PIME_REQUIRE(priorK && n_steps >= 1 && (kind == -1 || packed_actor) && (ret || trace), "pime_rollout_eval: bad arguments");
+    PIME_REQUIRE(seg_len >= 0 && (seg_len == 0 || (setpoints && n_setpoints >= 1 && n_setpoints <= kMaxSetpoints &&
+                                                   (n_steps + seg_len - 1) / seg_len <= n_setpoints)),
+                 "pime_rollout_eval: the set-point schedule does not cover n_steps (at most %d segments)", kMaxSetpoints);
+    if (!e->was_reset) { set_error("pime_rollout_eval before pime_env_reset"); return PIME_ERR_STATE; }
+    if (int rc = use_device(e)) return rc;
+    if (e->cfg.state_mode == PIME_STATE_F64)
+        return rollout_eval_t<double>(e, e->ph64, e->wt64, kind, md, packed_actor, priorK, n_steps, seg_len, setpoints, n_setpoints,
+                                      ret, trace, stream);
+    return rollout_eval_t<float>(e, e->ph32, e->wt32, kind, md, packed_actor, priorK, n_steps, seg_len, setpoints, n_setpoints, ret,
+                                 trace, stream);
 }
 
 int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

@@ -11,34 +11,12 @@
 // (512 MFMAs x 64 cycles), so sharing a SIMD would only stretch the episode.
 // The env arithmetic is env_device.hpp -- literally the code of ph_step_kernel / ph_reset_kernel.
 #include "env_device.hpp"
-#include "mlp_device.hpp"
 #include "rollout.hpp"
+#include "rollout_policy.hpp"
 
 namespace pime {
 
 constexpr uint32_t STREAM_EXPLORE = 2;
-
-// first layer from a register-resident input of compile-time width
-template <int OT, int ACT, int DIN>
-__device__ __forceinline__ void layer_first_regs(const float* __restrict__ w0, const float* x, int h, f32x16 (&out)[OT]) {
-    const float* wb = w0 + DIN * (OT * 32) + h;
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) out[ot][r] = wb[(ot * 16 + r) * 2];
-#pragma unroll
-    for (int j = 0; j < DIN; ++j) {
-        const float* wj = w0 + j * (OT * 32) + h;
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[ot][r] = fmaf(x[j], wj[(ot * 16 + r) * 2], out[ot][r]);
-    }
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) out[ot][r] = activate<ACT>(out[ot][r]);
-}
 
 constexpr int kRolloutThreads = 128;
 
@@ -63,9 +41,8 @@ __device__ __forceinline__ float through_half(float v) { return (float)(half_t)v
 template <int T, int KIND, int ENV, int STACK>
 __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int D = ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), Di = ENV == 2 ? 0 : 1, Do = D - Di;
+    constexpr int D = ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), Di = ENV == 2 ? 0 : 1;
     static_assert(ENV != 2 || KIND == MLP_PLAIN_ACTOR, "the Stacking observation has no integrator column: plain actors only");
-    constexpr int H = T / 2 > 0 ? T / 2 : 1;
     const MlpLayout L = mlp_layout(KIND, D, Di, T * 32);
     stage_image(lds, a.img, L.total / 4);
     __syncthreads();
@@ -95,37 +72,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
     for (int j = 0; j < D; ++j) obs[j] = h16 ? (float)a.state_h[(size_t)D * i + j] : a.state[(size_t)D * i + j];
     for (int t = 0; t < a.n_steps; ++t) {
         PIME_NO_HOIST();
-        float a_avg;
-        if constexpr (KIND == MLP_MODULAR_ACTOR) {
-            f32x16 cat[T];
-            {
-                f32x16 a0[T];
-                layer_first_regs<T, 2, Do>(lds + L.off[0], obs, h, a0);   // activations are applied by the consuming layer
-                PIME_NO_HOIST();
-                layer_mfma_in<T, H, 2, 1>(lds + L.off[1], lds + L.off[2], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
-            }
-            {
-                f32x16 a0[T];
-                PIME_NO_HOIST();
-                layer_first_regs<T, 2, Di>(lds + L.off[3], obs + Do, h, a0);
-                PIME_NO_HOIST();
-                layer_mfma_in<T, H, 2, 1>(lds + L.off[4], lds + L.off[5], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
-            }
-            f32x16 n0[T];
-            PIME_NO_HOIST();
-            layer_mfma_in<T, T, 1, 1>(lds + L.off[6], lds + L.off[7], lane, cat, n0);
-            PIME_NO_HOIST();
-            a_avg = layer_head<T>(lds + L.off[8], lds[L.off[9]], lane, n0);
-        } else {
-            f32x16 a0[T], a1[T];
-            layer_first_regs<T, 2, D>(lds + L.off[0], obs, h, a0);
-            PIME_NO_HOIST();
-            layer_mfma_in<T, T, 2, 1>(lds + L.off[1], lds + L.off[2], lane, a0, a1);
-            PIME_NO_HOIST();
-            layer_mfma_in<T, T, 1, 1>(lds + L.off[3], lds + L.off[4], lane, a1, a0);
-            PIME_NO_HOIST();
-            a_avg = layer_head<T>(lds + L.off[5], lds[L.off[6]], lane, a0);
-        }
+        const float a_avg = policy_forward<T, KIND, D, Di>(lds, L, obs, lane);
         // exploration noise eps ~ N(0,1): Box-Muller on a Philox pair keyed by the global lane (net_residual.py:178)
         double ua, ub;
         philox_pair(a.noise_seed, gid, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE, ua, ub);

@@ -248,6 +248,16 @@ class AgentPPO(AgentBase):
         pk = self._packed_for("act")
         return pk is not None and self.act.state_dim == env.obs_dim and env.rollout_supported(pk)
 
+    def fused_eval_policy(self, env):
+        """(packed actor, priorK) if the fused evaluation kernel can run this agent's deterministic policy on `env`
+        (run.py:600-619 as one launch, csrc/rollout_eval.hip), else None -> the evaluator steps the env launch by launch."""
+        if not self.use_fused_rollout or not hasattr(env, "eval_supported"):
+            return None
+        pk = self._packed_for("act")
+        if pk is None or not env.eval_supported(pk):
+            return None
+        return pk, self._rollout_priorK()
+
     def _vec_env_step(self, env, a_pre, obs, out_obs, out_reward, out_done):
         """Plain PPO: the env sees tanh(a_pre) (agent.py:599)."""
         step = env.step_h if out_obs.dtype == torch.float16 else env.step

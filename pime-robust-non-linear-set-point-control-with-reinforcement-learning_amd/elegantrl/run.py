@@ -212,18 +212,19 @@ class Evaluator:
         for the residual PPO actors), or the agent's `eval_policy` where the actor's forward is the residual action alone."""
         return getattr(agent, "eval_policy", None) or agent.act
 
-    def _returns(self, act, times):
-        if hasattr(self.env, "num_envs"):  # one launch sequence evaluates num_envs episodes at once
+    def _returns(self, act, times, agent=None):
+        if hasattr(self.env, "num_envs"):  # one launch evaluates num_envs episodes at once
+            fused = agent.fused_eval_policy(self.env) if hasattr(agent, "fused_eval_policy") else None
             r = []
             while len(r) < times:
-                r.extend(get_episode_return_vec(self.env, act).tolist())
+                r.extend(get_episode_return_vec(self.env, act, fused=fused).tolist())
             return np.asarray(r[:max(times, 1)])
         return np.asarray([get_episode_return(self.env, act, self.device)[0] for _ in range(times)])
 
     def evaluate_act(self, agent):
         if self.eval_times1 == 0:
             return False
-        r = self._returns(self._policy(agent), self.eval_times1)
+        r = self._returns(self._policy(agent), self.eval_times1, agent)
         r_avg, r_std = float(r.mean()), float(r.std())
         if r_avg > self.r_max:
             self.r_max = r_avg
@@ -245,9 +246,9 @@ class Evaluator:
         self.total_step += steps
         if_reach_goal = False
         if self.eval_func_time % self.eval_gap == 0:
-            r = self._returns(self._policy(agent), self.eval_times1)
+            r = self._returns(self._policy(agent), self.eval_times1, agent)
             if r.mean() > self.r_max:  # confirm a new best with more episodes before saving
-                r = np.concatenate([r, self._returns(self._policy(agent), max(self.eval_times2 - self.eval_times1, 0))]) \
+                r = np.concatenate([r, self._returns(self._policy(agent), max(self.eval_times2 - self.eval_times1, 0), agent)]) \
                     if self.eval_times2 > self.eval_times1 else r
             r_avg, r_std = float(r.mean()), float(r.std())
             if r_avg > self.r_max:
@@ -290,8 +291,14 @@ def get_episode_return(env, act, device):
     return getattr(env, "episode_return", episode_return), step + 1
 
 
-def get_episode_return_vec(env, act):
-    """One deterministic episode on every lane of a vectorised env; returns the per-lane undiscounted returns."""
+def get_episode_return_vec(env, act, fused=None):
+    """One deterministic episode on every lane of a vectorised env; returns the per-lane undiscounted returns.
+    fused = (packed actor, priorK) from agent.fused_eval_policy(env): reset + ONE launch for the whole episode
+    (csrc/rollout_eval.hip) and one device-to-host copy, instead of max_step x [policy forward, env step] launches."""
+    if fused is not None:
+        env.reset()
+        ret, _ = env.rollout_eval(fused[0], fused[1], env.max_step)
+        return ret.cpu().numpy()
     obs = env.reset()
     ret = torch.zeros(env.num_envs, dtype=torch.float64, device=obs.device)
     for _ in range(env.max_step):

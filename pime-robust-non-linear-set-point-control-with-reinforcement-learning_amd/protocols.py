@@ -9,6 +9,10 @@ replaces (protocols only, not the matplotlib plotting around them):
 
 `policy` maps a float32 observation batch [N, D] to env actions [N]; None selects the prior controller -obs @ K
 (the reference's `get_linear_action`).  All lanes share the set-point sequence; each lane keeps its own plant.
+
+With `policy=None` (prior controller) or `agent=<a residual PPO agent>` the whole protocol is ONE launch of the fused evaluation
+kernel (csrc/rollout_eval.hip, `pime_rollout_eval` with a set-point schedule: no per-step launches, no per-step device-to-host
+reads; round 2 read four state fields back per step); an arbitrary `policy` callable keeps the step-per-launch loop.
 """
 import numpy as np
 import torch
@@ -25,7 +29,16 @@ def _prior(env):
     return lambda obs: obs.double() @ k
 
 
-def ph_step_response(env, policy=None, setpoints=PH_SETPOINTS, steps=50, plants=None):
+def _fused_policy(env, policy, agent):
+    """(packed actor or None, priorK) when the fused evaluation kernel can run the protocol, else None."""
+    if policy is not None or not hasattr(env, "eval_supported") or len(PH_SETPOINTS) > 16:
+        return None
+    if agent is None:
+        return (None, -env.K) if env.eval_supported(None) else None
+    return agent.fused_eval_policy(env) if hasattr(agent, "fused_eval_policy") else None
+
+
+def ph_step_response(env, policy=None, setpoints=PH_SETPOINTS, steps=50, plants=None, agent=None):
     """env: VecPH.  plants: optional [N, 2] (qww_V, qc_V) written before the run (the plant IS rebuilt, unlike the
     reference's set_params -- SURVEY.md App. C.3).  Returns dict of [len(setpoints)*steps, N] float64 arrays
     y, r, I, action, reward (and x) exactly in the order the reference protocol appends them."""
@@ -35,6 +48,15 @@ def ph_step_response(env, policy=None, setpoints=PH_SETPOINTS, steps=50, plants=
     if plants is not None:
         plants = np.asarray(plants, dtype=np.float64)
         env.set_params(plants[:, 0], plants[:, 1])
+    fused = _fused_policy(env, policy, agent)
+    if fused is not None and len(setpoints) <= 16:
+        env.reset()
+        env.set_field("x", np.zeros(env.num_envs))          # the protocol starts from state 0 (utils/test.py:1375)
+        _, tr = env.rollout_eval(fused[0], fused[1], len(setpoints) * steps, setpoints=setpoints, seg_len=steps, want_trace=True)
+        tr = tr.cpu().numpy()
+        return {"y": tr[:, 0], "r": tr[:, 1], "I": tr[:, 2], "action": tr[:, 3], "reward": tr[:, 4], "x": tr[:, 5]}
+    if policy is None and agent is not None:
+        policy = agent.act
     out = {k: [] for k in ("y", "r", "I", "action", "reward", "x")}
     last_x = np.zeros(env.num_envs)
     for r in setpoints:
@@ -53,7 +75,7 @@ def ph_step_response(env, policy=None, setpoints=PH_SETPOINTS, steps=50, plants=
     return {k: np.stack(v) for k, v in out.items()}
 
 
-def wt_step_response(env, policy=None, setpoints=WT_SETPOINTS, steps=None, plants=None):
+def wt_step_response(env, policy=None, setpoints=WT_SETPOINTS, steps=None, plants=None, agent=None):
     """env: VecWaterTank (Integrator observation).  plants: optional [N, 3] (a1, a2, Kp).  Returns obs [S*steps, N, D],
     action and reward [S*steps, N]; tank levels are carried from one set-point segment to the next."""
     policy = policy or _prior(env)
@@ -63,6 +85,15 @@ def wt_step_response(env, policy=None, setpoints=WT_SETPOINTS, steps=None, plant
     if plants is not None:
         plants = np.asarray(plants, dtype=np.float64)
         env.reset_changable_parameters(plants[:, 0], plants[:, 1], plants[:, 2])
+    fused = _fused_policy(env, policy, agent)
+    if fused is not None and len(setpoints) <= 16 and env.num_stack == 0:
+        env.reset()
+        env.set_field("h1", np.zeros(env.num_envs)); env.set_field("h2", np.zeros(env.num_envs))   # utils/test.py:219-221
+        _, tr = env.rollout_eval(fused[0], fused[1], len(setpoints) * steps, setpoints=setpoints, seg_len=steps, want_trace=True)
+        tr = tr.cpu().numpy()
+        return {"obs": np.ascontiguousarray(np.transpose(tr[:, :4], (0, 2, 1))), "reward": tr[:, 4], "action": tr[:, 5]}
+    if policy is None and agent is not None:
+        policy = agent.act
     out = {k: [] for k in ("obs", "action", "reward")}
     h1 = h2 = np.zeros(env.num_envs)
     for r in setpoints:

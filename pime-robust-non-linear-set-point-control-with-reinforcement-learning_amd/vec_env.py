@@ -362,6 +362,42 @@ class VecControlEnv:
             native.ptr(reward), native.ptr(done), self._stream()), "pime_rollout")
         # whole episodes with in-kernel auto-reset: every lane is back at step 0 of a new episode
 
+    def eval_supported(self, packed_actor=None):
+        """Does the fused evaluation kernel serve this env (with this packed actor, or the prior controller alone)?
+        (pime_rollout_eval_supported: float64 or mixed state, pH / Integrator tank, in-kernel draws)"""
+        if self.draws.injects:
+            return False
+        if packed_actor is None:
+            return bool(self._lib.pime_rollout_eval_supported(self._h, -1, 0))
+        kind = native.MLP_MODULAR_ACTOR if packed_actor.kind == "modular_actor" else native.MLP_PLAIN_ACTOR
+        return packed_actor.D == self.obs_dim and bool(self._lib.pime_rollout_eval_supported(self._h, kind, int(packed_actor.md)))
+
+    def rollout_eval(self, packed_actor, priorK, n_steps, setpoints=None, seg_len=0, want_trace=False, ret=None):
+        """`n_steps` steps of every lane under the deterministic residual policy in ONE launch (csrc/rollout_eval.hip; no
+        exploration noise, no auto-reset): returns (ret float64 [N] = per-lane sum of rewards, accumulated into `ret` if given,
+        trace float64 [n_steps, 6, N] or None).  packed_actor None = the prior controller alone.  setpoints / seg_len: a
+        step-response schedule (see include/pime_hip.h).  The lanes are left mid-episode: reset before the next rollout."""
+        k = np.ascontiguousarray(np.asarray(priorK, dtype=np.float64).reshape(-1))
+        assert k.size == self.obs_dim
+        if ret is None:
+            ret = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)
+        trace = torch.empty((n_steps, 6, self.num_envs), dtype=torch.float64, device=self.device) if want_trace else None
+        sp = np.ascontiguousarray(np.asarray(setpoints if setpoints is not None else [], dtype=np.float64))
+        if packed_actor is None:
+            kind, md, img = -1, 0, None
+        else:
+            kind = native.MLP_MODULAR_ACTOR if packed_actor.kind == "modular_actor" else native.MLP_PLAIN_ACTOR
+            md, img = int(packed_actor.md), packed_actor.packed
+        native.check(self._lib.pime_rollout_eval(self._h, kind, md, native.ptr(img), native.ptr(k), int(n_steps), int(seg_len),
+                                                 native.ptr(sp) if sp.size else None, int(sp.size), native.ptr(ret),
+                                                 native.ptr(trace), self._stream()), "pime_rollout_eval")
+        self._was_reset = False   # the lanes sit somewhere inside an episode: the next rollout must reset first
+        if self._t_lanes is None:
+            self._t_all += n_steps
+        else:
+            self._t_lanes += n_steps
+        return ret, trace
+
     # -- state access (float64 numpy on the host; synchronous) -------------------------------------------------
     def get_field(self, name):
         out = np.empty(self.num_envs, dtype=np.float64)

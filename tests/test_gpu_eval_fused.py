@@ -1,0 +1,108 @@
+"""Evaluation on the fused kernel (csrc/rollout_eval.hip, `pime_rollout_eval`): the evaluator's deterministic
+episode (/root/reference/elegantrl/run.py:600-619) and the set-point step-response protocols (utils/test.py:1369-1407,209-349) as
+ONE launch each, against (a) the reference's golden protocol records (float64 state mode, the tolerances of
+tests/test_gpu_facade.py::test_batched_step_response_protocols), (b) the CPU oracle stepped with the oracle's own policy forward,
+and (c) the launch-by-launch path it replaces."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from rollout_replay import DEV, make_agent, oracle_mean
+
+pytestmark = pytest.mark.gpu
+
+
+def _no_stepwise(env):
+    """The fused path must not fall back: any step-per-launch call on this env fails the test."""
+    def boom(*a, **k):
+        raise AssertionError("the protocol / evaluation fell back to step-per-launch kernels")
+    env.step = env.step_residual = boom
+
+
+def test_protocols_run_as_one_launch_and_match_the_golden_records():
+    from pime_amd import gym_control, protocols
+    g = load_golden("ph_stepresponse.npz")
+    env = gym_control.make_vec(gym_control.PH_V35, 2, device=DEV, state_mode="f64", seed=0)
+    _no_stepwise(env)
+    res = protocols.ph_step_response(env, plants=[g["nominal_params"], g["corner_params"]])
+    for lane, tag in enumerate(("nominal", "corner")):
+        np.testing.assert_allclose(res["action"][:, lane], g[tag + "_act"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(res["y"][:, lane], g[tag + "_y"], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(res["I"][:, lane], g[tag + "_I"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(res["x"][:, lane], g[tag + "_x"], rtol=1e-12)
+        np.testing.assert_allclose(res["reward"][:, lane], g[tag + "_rew"], rtol=2e-7, atol=1e-6)
+    env.close()
+    gw = load_golden("wt_stepresponse.npz")
+    env = gym_control.make_vec(gym_control.WT_INTEGRATOR, 2, device=DEV, state_mode="f64", seed=0, reward_type="distance",
+                               noise_scale=0.0)
+    _no_stepwise(env)
+    res = protocols.wt_step_response(env, steps=500, plants=[gw["robust1_params"][:3], gw["robust3_params"][:3]])
+    for lane, tag in enumerate(("robust1", "robust3")):
+        np.testing.assert_allclose(res["obs"][:, lane], gw[tag + "_obs"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(res["action"][:, lane], gw[tag + "_act"], rtol=0, atol=1e-12)
+    env.close()
+
+
+@pytest.mark.parametrize("env_name,algo,md", [("PH_V35", "ResidualIntegratorModularPPO", 128), ("PH_V35", "ResidualPPO", 64),
+                                              ("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 128)])
+def test_fused_episode_returns_against_oracle_and_stepwise(env_name, algo, md):
+    """One deterministic episode per lane: the fused launch vs (1) the oracle env driven by the oracle's forward of the same
+    weights, step by step in float64 (per-lane returns 1e-4 relative: float32 policy mean + mixed-mode state), (2) the
+    launch-by-launch evaluator path on an identically seeded env."""
+    import oracle
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.run import get_episode_return_vec
+    is_ph = env_name == "PH_V35"
+    N, seed, off = 2048, 13, 512
+    kw = {} if is_ph else dict(reward_type="distance", max_step=80)
+    envs = [gym_control.make_vec(getattr(gym_control, env_name), N, device=DEV, state_mode="mixed", seed=seed, env_offset=off, **kw)
+            for _ in range(2)]
+    ag = make_agent(algo, envs[0], md)
+    fused = ag.fused_eval_policy(envs[0])
+    assert fused is not None, "the fused evaluation kernel must serve this configuration"
+    _no_stepwise(envs[0])
+    got = get_episode_return_vec(envs[0], ag.act, fused=fused)
+    slow = get_episode_return_vec(envs[1], ag.act)
+    T = envs[0].max_step
+    ref = oracle.OraclePH(N, oracle.ph_table(), seed=seed, env_offset=off) if is_ph else \
+        oracle.OracleWT(N, max_steps=T, reward_type="distance", seed=seed, env_offset=off)
+    sd = {k: v.detach().cpu().numpy() for k, v in ag.act.state_dict().items()}
+    priorK = ag._rollout_priorK()
+    obs = ref.reset()
+    want = np.zeros(N)
+    for _ in range(T):
+        act = oracle.residual_action(oracle_mean(algo, obs, sd).astype(np.float32), obs, priorK)
+        obs, _, rew, _ = ref.step(act)
+        want += rew.astype(np.float32).astype(np.float64)
+    # pH: a float32-rounding difference of the policy mean can move one lane across a titration cell for a step; the episode
+    # return absorbs it (|dy| <= 0.03 on one step of 50)
+    np.testing.assert_allclose(got, want, rtol=2e-3 if is_ph else 1e-4, atol=0.05 if is_ph else 1e-3)
+    assert np.median(np.abs(got - want) / np.abs(want)) < 2e-5
+    np.testing.assert_allclose(got, slow, rtol=2e-3 if is_ph else 1e-4, atol=0.05 if is_ph else 1e-3)
+    for e in envs:
+        e.close()
+
+
+def test_evaluator_uses_the_fused_path_and_explore_resets_afterwards():
+    """train_and_evaluate's evaluator on the shared vectorised env: evaluation = reset + one launch; the next explore_env must
+    start from a fresh reset (the evaluation leaves the lanes mid-episode)."""
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.run import Evaluator, make_buffer
+    N = 512
+    env = gym_control.make_vec(gym_control.PH_V35, N, device=DEV, state_mode="mixed", seed=2)
+    ag = make_agent("ResidualIntegratorModularPPO", env, 128)
+    buf = make_buffer(ag, env, N * 50)
+    ag.explore_env(env, buf, N * 50, 1.0, 0.99)
+    assert env.fresh
+    ev = Evaluator(cwd="/tmp", agent_id=0, eval_times1=N, eval_times2=N, eval_gap=1, env=env, device=DEV, is_main=False)
+    calls = []
+    orig = env.rollout_eval
+    env.rollout_eval = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    r = ev._returns(ev._policy(ag), N, ag)
+    assert calls == [1] and r.shape == (N,) and np.isfinite(r).all()
+    assert not env.fresh
+    ep0 = env.get_field("episode").copy()
+    ag.explore_env(env, buf, N * 50, 1.0, 0.99)      # resets (episode + 1), rolls out one episode, auto-resets (episode + 1)
+    assert (env.get_field("episode") == ep0 + 2).all() and env.fresh
+    env.close()
