@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 11
+#define PIME_ABI_VERSION 12
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -342,6 +342,24 @@ int pime_rollout_eval_supported(const pime_env* env, int32_t kind, int32_t md);
 int pime_rollout_eval(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const double* priorK, int32_t n_steps,
                       int32_t seg_len, const double* setpoints, int32_t n_setpoints, double* ret, double* trace,
                       pime_stream stream);
+
+/* -- fused off-policy exploration -----------------------------------------------------------------------------------
+ * replaces, per lock-step of the vectorised off-policy agents: AgentBase.explore_env's body (elegantrl/agent.py:54-70) with
+ * AgentTD3.select_action (:300-306: a = (act(s) + N(0, explore_noise)).clamp(-1, 1)), env.step, and ReplayBuffer.append_buffer
+ * (replay.py:290-300) -- as ONE launch for n_steps lock-steps of every lane: deterministic actor forward on the matrix cores,
+ * clipped exploration noise (Philox stream 2, counter (lane, noise_epoch, t)), env action a_env = a + s @ priorK (priorK zeros:
+ * plain TD3), env step with in-kernel auto-reset, transition written into the device ring.  The running episodes CONTINUE (no
+ * reset in front).  Handle in PIME_STATE_MIXED mode, pH or Integrator water tank, Philox draws.
+ *   packed_actor  pime_mlp_pack image of kind PIME_MLP_CRITIC built from the TD3 Actor's tensors (net.py:96-110 has CriticAdv's
+ *                 shape and ReLUs; the kernel applies the tanh), width md = 64 / 128
+ *   obs           [dev] float32[N, obs_dim]: in = the lanes' current observation, out = the observation after the last step
+ *   ring_state    [dev] float32[slots, N, obs_dim]; ring_other [dev] float32[slots, N, 3] = (reward * reward_scale, mask = 0 if done
+ *                 else gamma, action); slots slot0 .. slot0 + n_steps - 1 (mod slots) are written: the successor of (slot, lane) is
+ *                 (slot + 1, lane), where replay.py:344-351 uses row i + 1 */
+int pime_rollout_offpolicy_supported(const pime_env* env, int32_t md);
+int pime_rollout_offpolicy(pime_env* env, int32_t md, const float* packed_actor, const double* priorK, float explore_noise,
+                           float gamma, float reward_scale, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch,
+                           float* obs, float* ring_state, float* ring_other, int32_t slot0, int32_t slots, pime_stream stream);
 
 /* replaces: self.optimizer.step() of the single Adam over both nets (elegantrl/agent.py:565-566,656-657; no weight
  * decay, no amsgrad) when every parameter lives in ONE flat tensor.  All [dev] float32[n]; step [dev] float32[2], zeroed

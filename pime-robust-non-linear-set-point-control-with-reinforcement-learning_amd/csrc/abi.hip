@@ -10,6 +10,7 @@
 #include "ppo_train.hpp"
 #include "rollout.hpp"
 #include "rollout_eval.hpp"
+#include "rollout_offpolicy.hpp"
 
 namespace pime {
 
@@ -772,6 +773,35 @@ int pime_rollout_eval(pime_env* e, int32_t kind, int32_t md, const float* packed
                                       ret, trace, stream);
     return rollout_eval_t<float>(e, e->ph32, e->wt32, kind, md, packed_actor, priorK, n_steps, seg_len, setpoints, n_setpoints, ret,
                                  trace, stream);
+}
+
+int pime_rollout_offpolicy_supported(const pime_env* e, int32_t md) {
+    if (e == nullptr || e->cfg.state_mode != PIME_STATE_MIXED) return 0;
+    if (e->cfg.kind != PIME_ENV_PH && e->cfg.num_stack != 0) return 0;
+    return (md == 64 || md == 128) && !family16(PIME_MLP_CRITIC, md) ? 1 : 0;
+}
+
+int pime_rollout_offpolicy(pime_env* e, int32_t md, const float* packed_actor, const double* priorK, float explore_noise,
+                           float gamma, float reward_scale, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch,
+                           float* obs, float* ring_state, float* ring_other, int32_t slot0, int32_t slots, pime_stream stream) {
+    PIME_REQUIRE(e != nullptr, "NULL env handle");
+    PIME_REQUIRE(pime_rollout_offpolicy_supported(e, md), "pime_rollout_offpolicy: not served for this handle / width %d", md);
+    PIME_REQUIRE(packed_actor && priorK && obs && ring_state && ring_other && n_steps >= 1 && slots >= 2 && slot0 >= 0 &&
+                 slot0 < slots && n_steps <= slots, "pime_rollout_offpolicy: bad arguments");
+    if (!e->was_reset) { set_error("pime_rollout_offpolicy before pime_env_reset"); return PIME_ERR_STATE; }
+    if (int rc = use_device(e)) return rc;
+    OffPolicyArgs a{};
+    a.env = e->cfg.kind == PIME_ENV_PH ? 0 : 1;
+    a.n = e->cfg.n_envs;
+    a.env_offset = e->cfg.env_offset;
+    if (a.env == 0) { a.p = e->ph; a.p.auto_reset = 1; a.st = e->ph32; }
+    else { a.wp = e->wt; a.wp.auto_reset = 1; a.wst = e->wt32; }
+    a.img = packed_actor;
+    for (int j = 0; j < e->obs_dim; ++j) a.K.k[j] = priorK[j];
+    a.explore_noise = explore_noise; a.gamma = gamma; a.reward_scale = reward_scale;
+    a.n_steps = n_steps; a.noise_seed = noise_seed; a.noise_epoch = noise_epoch;
+    a.obs = obs; a.ring_state = ring_state; a.ring_other = ring_other; a.slot0 = slot0; a.slots = slots;
+    return launch_rollout_offpolicy(md, a, static_cast<hipStream_t>(stream));
 }
 
 int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

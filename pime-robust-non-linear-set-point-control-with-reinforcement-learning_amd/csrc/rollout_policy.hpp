@@ -55,13 +55,14 @@ __device__ __forceinline__ float policy_forward(const float* __restrict__ lds, c
         layer_mfma_in<T, T, 1, 1>(lds + L.off[6], lds + L.off[7], lane, cat, n0);
         PIME_NO_HOIST();
         return layer_head<T>(lds + L.off[8], lds[L.off[9]], lane, n0);
-    } else {
+    } else {   // plain actor (Tanh) or the TD3 Actor, whose shape and ReLUs are CriticAdv's (net.py:96-110 / :274-277): KIND MLP_CRITIC
+        constexpr int ACT = KIND == MLP_CRITIC ? 0 : 1;
         f32x16 a0[T], a1[T];
         layer_first_regs<T, 2, D>(lds + L.off[0], obs, h, a0);
         PIME_NO_HOIST();
-        layer_mfma_in<T, T, 2, 1>(lds + L.off[1], lds + L.off[2], lane, a0, a1);
+        layer_mfma_in<T, T, 2, ACT>(lds + L.off[1], lds + L.off[2], lane, a0, a1);
         PIME_NO_HOIST();
-        layer_mfma_in<T, T, 1, 1>(lds + L.off[3], lds + L.off[4], lane, a1, a0);
+        layer_mfma_in<T, T, ACT, ACT>(lds + L.off[3], lds + L.off[4], lane, a1, a0);
         PIME_NO_HOIST();
         return layer_head<T>(lds + L.off[5], lds[L.off[6]], lane, a0);
     }

@@ -113,9 +113,16 @@ class AgentBase:
 
     @staticmethod
     def soft_update(target_net, current_net, tau):
+        """target <- (1 - tau) target + tau current (agent.py:116-124), as two multi-tensor launches per net on the GPU (the
+        per-parameter loop is ~40 small launches per delayed update of a TD3 agent)."""
         with torch.no_grad():
-            for tar, cur in zip(target_net.parameters(), current_net.parameters()):
-                tar.mul_(1 - tau).add_(cur, alpha=tau)
+            tar, cur = list(target_net.parameters()), list(current_net.parameters())
+            if tar and tar[0].is_cuda:
+                torch._foreach_mul_(tar, 1 - tau)
+                torch._foreach_add_(tar, cur, alpha=tau)
+                return
+            for t, c in zip(tar, cur):
+                t.mul_(1 - tau).add_(c, alpha=tau)
 
 
 # ================================================================================================= PPO
@@ -651,8 +658,10 @@ class AgentTD3(AgentBase):
         self.policy_noise = 0.2
         self.update_freq = 2
         self.use_hip_graphs = True
+        self.use_fused_rollout = True   # vectorised env: the whole explore call as ONE launch (csrc/rollout_offpolicy.hip)
         self._graphs = None
         self._obs = None
+        self._packed_act = None
 
     def init(self, net_dim, state_dim, action_dim, if_per=False):
         assert not if_per, "prioritised replay is not on the residual-control path"
@@ -671,10 +680,37 @@ class AgentTD3(AgentBase):
         self.cri_optimizer = torch.optim.Adam(self.cri.parameters(), lr=self.learning_rate, **kw)
         self.act_optimizer = torch.optim.Adam(self.act.parameters(), lr=self.learning_rate, **kw)
         self._graphs = None
+        self._packed_act = None
 
     def _prior_term(self, states):
         """Prior-controller part of the env action (none for plain TD3)."""
         return None
+
+    def _rollout_priorK(self):
+        """float64 prior gain of the fused exploration kernel's composition a_env = a + s @ priorK (zeros: plain TD3)."""
+        return np.zeros(self.act.state_dim)
+
+    def _fused_explore(self, env):
+        """Packed deterministic actor for the fused exploration kernel, or None -> lock-step by lock-step launches.  The image is
+        re-packed on every call: the actor's weights change with every update_net."""
+        if not (self.use_fused_rollout and hasattr(env, "offpolicy_rollout_supported") and hasattr(self.backend, "packed")):
+            return None
+        if getattr(self.act, "action_dim", 1) != 1:
+            return None
+        if self._packed_act is None or self._packed_act is False:
+            if self._packed_act is False:
+                return None
+            self._packed_act = self.backend.packed(self.act) or False
+            if self._packed_act is False:
+                return None
+        pk = self._packed_act
+        if not env.offpolicy_rollout_supported(pk):
+            return None
+        if not hasattr(self, "_rollout_seed"):
+            self._rollout_seed = int(torch.initial_seed()) & (2 ** 63 - 1)   # exploration stream follows torch's seed
+            self._rollout_epoch = 0
+        pk.repack()
+        return pk
 
     def select_action(self, state, if_deterministic=False):
         states = torch.as_tensor(np.asarray(state)[None], dtype=torch.float32, device=self.device)
@@ -716,6 +752,17 @@ class AgentTD3(AgentBase):
             self._obs = env.reset().clone()
             self._next_obs = torch.empty_like(self._obs)
             self._obs_epoch = (id(env), env.reset_count)
+        pk = self._fused_explore(env)
+        if pk is not None:   # ONE launch for the whole call: actor forward, noise, composition, env step, ring writes
+            done_steps = 0
+            while done_steps < steps:
+                n = min(steps - done_steps, buffer.slots)
+                self._rollout_epoch += 1
+                env.rollout_offpolicy(pk, self._rollout_priorK(), self.explore_noise, gamma, reward_scale, n, self._rollout_seed,
+                                      self._rollout_epoch, self._obs, buffer.state, buffer.other, buffer.next_slot)
+                buffer.advance(n)
+                done_steps += n
+            return steps * N
         for _ in range(steps):
             obs = self._obs
             with torch.no_grad():

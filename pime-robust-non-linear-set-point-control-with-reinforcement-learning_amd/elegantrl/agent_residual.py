@@ -94,6 +94,9 @@ class AgentResidualTD3(AgentTD3):
     def _prior_term(self, states):
         return states @ self.act.priorK
 
+    def _rollout_priorK(self):
+        return self.priorK.reshape(-1)
+
     def _env_action(self, state, action):
         return action + state @ self.priorK
 

@@ -60,7 +60,7 @@ class GaussianHead:
 
 class Actor(nn.Module):
     """Deterministic policy of TD3/DDPG: D -> md ReLU -> md ReLU -> md ReLU -> A, tanh-squashed."""
-    packed_kind = None
+    packed_kind = "critic"   # image kind of its pre-tanh mean for the fused kernels: CriticAdv's shape and activations (A = 1)
 
     def __init__(self, mid_dim, state_dim, action_dim):
         super().__init__()

@@ -165,6 +165,13 @@ class VecReplayBuffer:
         if self.next_slot >= self.slots:
             self.next_slot, self.if_full = 0, True
 
+    def advance(self, n):
+        """`n` lock-steps were written into slots next_slot .. next_slot + n - 1 (mod slots) by the fused exploration kernel."""
+        assert 1 <= n <= self.slots
+        if self.next_slot + n >= self.slots:
+            self.if_full = True
+        self.next_slot = (self.next_slot + n) % self.slots
+
     def update_now_len_before_sample(self):
         """Also publishes the sampler's bounds to the device (rows that have a successor, the oldest slot): `sample_indices`
         reads them there, so an update captured into a HIP graph keeps sampling the right rows as the ring fills and its

@@ -31,7 +31,7 @@ def _prior(env):
 
 def _fused_policy(env, policy, agent):
     """(packed actor or None, priorK) when the fused evaluation kernel can run the protocol, else None."""
-    if policy is not None or not hasattr(env, "eval_supported") or len(PH_SETPOINTS) > 16:
+    if policy is not None or not hasattr(env, "eval_supported"):
         return None
     if agent is None:
         return (None, -env.K) if env.eval_supported(None) else None
@@ -42,21 +42,19 @@ def ph_step_response(env, policy=None, setpoints=PH_SETPOINTS, steps=50, plants=
     """env: VecPH.  plants: optional [N, 2] (qww_V, qc_V) written before the run (the plant IS rebuilt, unlike the
     reference's set_params -- SURVEY.md App. C.3).  Returns dict of [len(setpoints)*steps, N] float64 arrays
     y, r, I, action, reward (and x) exactly in the order the reference protocol appends them."""
-    policy = policy or _prior(env)
+    fused = _fused_policy(env, policy, agent)
     env.set_reset_all(False)
     env.set_max_step(2 ** 30)                      # the protocol ignores TimeLimit's done and runs `steps` per segment
     if plants is not None:
         plants = np.asarray(plants, dtype=np.float64)
         env.set_params(plants[:, 0], plants[:, 1])
-    fused = _fused_policy(env, policy, agent)
     if fused is not None and len(setpoints) <= 16:
         env.reset()
         env.set_field("x", np.zeros(env.num_envs))          # the protocol starts from state 0 (utils/test.py:1375)
         _, tr = env.rollout_eval(fused[0], fused[1], len(setpoints) * steps, setpoints=setpoints, seg_len=steps, want_trace=True)
         tr = tr.cpu().numpy()
         return {"y": tr[:, 0], "r": tr[:, 1], "I": tr[:, 2], "action": tr[:, 3], "reward": tr[:, 4], "x": tr[:, 5]}
-    if policy is None and agent is not None:
-        policy = agent.act
+    policy = policy or (agent.act if agent is not None else _prior(env))
     out = {k: [] for k in ("y", "r", "I", "action", "reward", "x")}
     last_x = np.zeros(env.num_envs)
     for r in setpoints:
@@ -78,22 +76,20 @@ def ph_step_response(env, policy=None, setpoints=PH_SETPOINTS, steps=50, plants=
 def wt_step_response(env, policy=None, setpoints=WT_SETPOINTS, steps=None, plants=None, agent=None):
     """env: VecWaterTank (Integrator observation).  plants: optional [N, 3] (a1, a2, Kp).  Returns obs [S*steps, N, D],
     action and reward [S*steps, N]; tank levels are carried from one set-point segment to the next."""
-    policy = policy or _prior(env)
+    fused = _fused_policy(env, policy, agent)
     steps = steps or env.max_step
     env.set_reset_all(False)
     env.set_max_step(max(steps, env.max_step))
     if plants is not None:
         plants = np.asarray(plants, dtype=np.float64)
         env.reset_changable_parameters(plants[:, 0], plants[:, 1], plants[:, 2])
-    fused = _fused_policy(env, policy, agent)
     if fused is not None and len(setpoints) <= 16 and env.num_stack == 0:
         env.reset()
         env.set_field("h1", np.zeros(env.num_envs)); env.set_field("h2", np.zeros(env.num_envs))   # utils/test.py:219-221
         _, tr = env.rollout_eval(fused[0], fused[1], len(setpoints) * steps, setpoints=setpoints, seg_len=steps, want_trace=True)
         tr = tr.cpu().numpy()
         return {"obs": np.ascontiguousarray(np.transpose(tr[:, :4], (0, 2, 1))), "reward": tr[:, 4], "action": tr[:, 5]}
-    if policy is None and agent is not None:
-        policy = agent.act
+    policy = policy or (agent.act if agent is not None else _prior(env))
     out = {k: [] for k in ("obs", "action", "reward")}
     h1 = h2 = np.zeros(env.num_envs)
     for r in setpoints:

@@ -362,6 +362,31 @@ class VecControlEnv:
             native.ptr(reward), native.ptr(done), self._stream()), "pime_rollout")
         # whole episodes with in-kernel auto-reset: every lane is back at step 0 of a new episode
 
+    def offpolicy_rollout_supported(self, packed_actor):
+        """Does the fused off-policy exploration kernel serve this env with this packed deterministic actor?"""
+        return (self.cfg.state_mode == native.STATE_MIXED and not self.draws.injects and packed_actor.kind == "critic"
+                and packed_actor.D == self.obs_dim and bool(self._lib.pime_rollout_offpolicy_supported(self._h, int(packed_actor.md))))
+
+    def rollout_offpolicy(self, packed_actor, priorK, explore_noise, gamma, reward_scale, n_steps, noise_seed, noise_epoch, obs,
+                          ring_state, ring_other, slot0):
+        """`n_steps` lock-steps of every lane under the deterministic actor + clipped exploration noise in ONE launch, the
+        transitions written into the device ring from slot `slot0` on (csrc/rollout_offpolicy.hip); `obs` [N, D] is read (the
+        lanes' current observation) and overwritten with the observation after the last step.  The running episodes continue."""
+        for t_ in (obs, ring_state, ring_other):
+            assert t_.is_contiguous() and t_.device == self.device and t_.dtype == torch.float32
+        slots = ring_state.shape[0]
+        assert ring_state.shape == (slots, self.num_envs, self.obs_dim) and ring_other.shape == (slots, self.num_envs, 3)
+        k = np.ascontiguousarray(np.asarray(priorK, dtype=np.float64).reshape(-1))
+        assert k.size == self.obs_dim and self._was_reset
+        native.check(self._lib.pime_rollout_offpolicy(
+            self._h, int(packed_actor.md), native.ptr(packed_actor.packed), native.ptr(k), C.c_float(explore_noise), C.c_float(gamma),
+            C.c_float(reward_scale), int(n_steps), C.c_uint64(noise_seed), C.c_uint32(noise_epoch), native.ptr(obs),
+            native.ptr(ring_state), native.ptr(ring_other), int(slot0), int(slots), self._stream()), "pime_rollout_offpolicy")
+        if self._t_lanes is None:     # host mirror of the step counters: auto-reset wraps them at max_step
+            self._t_all = (self._t_all + n_steps) % self.max_step
+        else:
+            self._t_lanes = (self._t_lanes + n_steps) % self.max_step
+
     def eval_supported(self, packed_actor=None):
         """Does the fused evaluation kernel serve this env (with this packed actor, or the prior controller alone)?
         (pime_rollout_eval_supported: float64 or mixed state, pH / Integrator tank, in-kernel draws)"""

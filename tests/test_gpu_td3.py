@@ -119,8 +119,16 @@ def test_config2_residual_td3_4096_lanes_replays_through_oracle():
     with torch.no_grad():
         ag.act.net[-1].weight.normal_(0, 0.05)   # a non-trivial residual
     buf = make_buffer(ag, env, 2 ** 21)
+    assert ag._fused_explore(env) is not None, "config 2 must explore through the fused kernel (pime_rollout_offpolicy)"
     assert ag.explore_env(env, buf, steps * N, 1.0, 0.99) == steps * N and buf.stored_slots == steps
     torch.cuda.synchronize()
+    # the stored action is clamp(tanh(actor(s)) + 0.1 * eps, -1, 1) with eps the oracle's Philox stream-2 draw (agent.py:303-305)
+    sd = {k: v.detach().cpu().numpy() for k, v in ag.act.state_dict().items()}
+    for t in (0, 1, 57, 199, 200, 209):
+        s_t, a_t = buf.state[t].cpu().numpy(), buf.other[t, :, 2].cpu().numpy()
+        mean = oracle.critic_forward(s_t, sd)[:, 0]
+        want = np.clip(np.tanh(mean) + np.float32(0.1) * oracle.explore_noise(ag._rollout_seed, offset, N, 1, t), -1.0, 1.0)
+        np.testing.assert_allclose(a_t, want, rtol=0, atol=5e-5, err_msg=f"stored action, step {t}")
     state, other = buf.state[:steps + 1], buf.other[:steps]
     with torch.no_grad():   # the env action exactly as explore_vec_env composed it (float32, same device, same ops)
         a_env = torch.stack([other[t, :, 2:3] + state[t] @ ag.act.priorK for t in range(steps)])[:, :, 0].double().cpu().numpy()
@@ -144,3 +152,58 @@ def test_config2_residual_td3_4096_lanes_replays_through_oracle():
     torch.cuda.synchronize()
     assert np.isfinite(oa) and np.isfinite(oc) and ag._graphs and True in ag._graphs
     env.close()
+
+
+def test_fused_offpolicy_explore_matches_lock_step_launches():
+    """The one-launch exploration against the lock-step-by-lock-step path it replaces (torch actor, pime_env_step, torch copies
+    into the ring; its torch.randn replaced by the noise the kernel drew), two calls so that the episodes continue across them,
+    48 slots for 70 lock-steps so that the ring wraps: same transitions to float32 rounding of the policy forward."""
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.agent_residual import AgentResidualTD3
+    from pime_amd.elegantrl.replay import VecReplayBuffer
+    N, steps = 512, 70
+
+    def run(fused, noise_from=None):
+        env = gym_control.make_vec(gym_control.WT_INTEGRATOR, N, device=DEV, state_mode="mixed", seed=6, reward_type="distance",
+                                   max_step=25)
+        torch.manual_seed(0)
+        ag = AgentResidualTD3(device=DEV)
+        ag.use_fused_rollout = fused
+        ag.init(64, env.state_dim, 1)
+        ag.init_residual({"init_K": env.K.reshape(-1, 1)})
+        with torch.no_grad():
+            ag.act.net[-1].weight.normal_(0, 0.05)
+        buf = VecReplayBuffer(48 * N, N, env.state_dim, 1, DEV)
+        orig, it = torch.randn_like, iter(range(steps))
+        if noise_from is not None:   # eps = (a - tanh(mean)) / 0.1 reproduces the stored action exactly, clipped or not
+            f_states, f_other = noise_from
+
+            def replay_noise(a, **k):
+                t = next(it)
+                return (f_other[t][:, 2].reshape(a.shape) - torch.tanh(ag.act.net(f_states[t]))) / ag.explore_noise
+            torch.randn_like = replay_noise
+        states, other = [], []
+        try:
+            for chunk in (30, 40):
+                base = buf.next_slot
+                assert ag.explore_env(env, buf, chunk * N, 0.5, 0.98) == chunk * N
+                for j in range(chunk):
+                    states.append(buf.state[(base + j) % buf.slots].clone())
+                    other.append(buf.other[(base + j) % buf.slots].clone())
+        finally:
+            torch.randn_like = orig
+        torch.cuda.synchronize()
+        assert buf.if_full and buf.next_slot == steps % 48
+        assert (ag._fused_explore(env) is not None) == fused
+        env.close()
+        return states, other
+
+    s_f, o_f = run(True)
+    s_s, o_s = run(False, noise_from=(s_f, o_f))
+    n_done = 0
+    for t in range(steps):
+        torch.testing.assert_close(s_s[t], s_f[t], rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(o_s[t], o_f[t], rtol=2e-4, atol=2e-4)
+        assert torch.equal(o_s[t][:, 1], o_f[t][:, 1]), "masks (episode ends) must agree exactly"
+        n_done += int((o_f[t][:, 1] == 0).sum())
+    assert n_done == 2 * N      # 70 lock-steps of 25-step episodes: every lane ended two
