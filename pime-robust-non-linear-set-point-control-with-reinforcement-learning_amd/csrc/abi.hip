@@ -52,6 +52,7 @@ inline int stash_tiles_of(int kind, int md) { return (kind == 2 ? 6 : 5) * (md /
 int launch_pack_bwd(int, int, int, int, const float* const*, float*, hipStream_t);
 int launch_ppo_net(int, int, const PpoArgs&, hipStream_t);
 int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
+int launch_ppo_fused_dual(int, int, const PpoArgs&, const PpoArgs&, hipStream_t);
 int64_t fused_stash_floats(int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
@@ -1014,6 +1015,10 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
         }
     }
     PpoArgs slab_args[2];
+    // both nets on the LDS-resident fused kernel and of one width: ONE launch serves them (ppo_fused_dual_kernel); PIME_PPO_DUAL=0
+    // keeps one launch per net (A/B, and the per-net phase trace)
+    static const bool dual_off = std::getenv("PIME_PPO_DUAL") != nullptr && std::atoi(std::getenv("PIME_PPO_DUAL")) == 0;
+    const bool dual = mode[0] == FUSED && mode[1] == FUSED && critic->md == actor->md && !dual_off && !tracing;
     for (int k = 0; k < 2; ++k) {
         const pime_ppo_net* n = nets[k];
         PpoArgs a{};
@@ -1043,7 +1048,10 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
             a.slab = n->workspace + fused_stash_floats(b->B, n->md);
             a.slab_stride = slab_layout(n->kind, n->D, n->Di, n->md, a.poff, psize);
             slab_args[k] = a;
-            if (int rc = launch_ppo_fused(n->kind, n->md, a, s)) return rc;
+            if (dual) {
+                if (k == 1)
+                    if (int rc = launch_ppo_fused_dual(actor->kind, actor->md, slab_args[1], slab_args[0], s)) return rc;
+            } else if (int rc = launch_ppo_fused(n->kind, n->md, a, s)) return rc;
         } else {
             slab_args[k] = a;
             if (int rc = launch_ppo_net(n->kind, n->md, a, s)) return rc;

@@ -625,12 +625,13 @@ __device__ __forceinline__ float half_sum_dpp(float v) {
 
 #define PIME_MARK(i)                                                             \
     do {                                                                         \
-        if (a.trace && blockIdx.x == a.trace_wg && threadIdx.x == 0) a.trace[i] = wall_clock64(); \
+        if (a.trace && bid == a.trace_wg && threadIdx.x == 0) a.trace[i] = wall_clock64(); \
     } while (0)
 
+// bid / nb: this workgroup's index among the nb workgroups that work on THIS net (ppo_fused_kernel: the grid; ppo_fused_dual_kernel:
+// the net's share of a grid that serves both nets)
 template <int T, int KIND>
-__global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restrict__ lds, const int bid, const int nb) {
     constexpr bool MODULAR = KIND == MLP_MODULAR_ACTOR;
     constexpr bool CRITIC = KIND == MLP_CRITIC;
     constexpr int ACT = CRITIC ? 0 : 1;
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     const int Do = a.D - a.Di;
 
     PIME_MARK(0);
-    if (a.trace_span && threadIdx.x == 0 && blockIdx.x < 512) a.trace_span[2 * blockIdx.x] = wall_clock64();
+    if (a.trace_span && threadIdx.x == 0 && bid < 512) a.trace_span[2 * bid] = wall_clock64();
     const float asl = CRITIC ? 0.f : a.a_std_log[0];
     for (int e = tid; e < kFusedWaves * md; e += kFusedThreads) hacc[e] = 0.f;
     // small segments live in LDS for the whole kernel.  All their loads are issued before the first LDS write: one
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     if (tid < kFusedWaves * 6) wsum[tid] = 0.0;
 
 #pragma unroll 1
-    for (int group = blockIdx.x; group < ngroups; group += gridDim.x) {
+    for (int group = bid; group < ngroups; group += nb) {
         // Lane-derived offsets are made loop-variant on purpose: hipcc otherwise hoists ~100 per-lane LDS / global
         // offsets of the whole body out of this (usually single-trip) loop and spills them.
         int lane = tid & 63;
@@ -876,8 +877,8 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
         if constexpr (DX_FIRST) wait_dma_then_barrier<(T * 16 < 63 ? T * 16 : 63)>();
         else __syncthreads();                                  // forward images dead, stash visible to the whole workgroup
         PIME_MARK(3);
-        float* const sl = a.slab + (size_t)blockIdx.x * a.slab_stride;   // this workgroup's partial gradients
-        const bool accum = group != (int)blockIdx.x;                      // a later sample group of the same workgroup
+        float* const sl = a.slab + (size_t)bid * a.slab_stride;   // this workgroup's partial gradients
+        const bool accum = group != bid;                      // a later sample group of the same workgroup
         if constexpr (MODULAR) {
             f32x16(&dn0)[T] = hl;                                                                   // dZn0
             f32x16 dcat[T];
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 dw_rounds<T, 2 * T, CatB<T>, CatPlan<T>>(
                     wbuf, lane, wave, dcat,
                     CatB<T>{FirstB<1, false>{lds + F.first0, xs, Do, a.D, 0, md}, FirstB<1, false>{lds + F.first1, xs, a.Di, a.D, Do, md}},
-                    acc, bsum, nullptr, nullptr, 0, (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
+                    acc, bsum, nullptr, nullptr, 0, (a.trace && bid == a.trace_wg) ? a.trace + 16 : nullptr);
                 const CatPlan<T> pl(wave);
                 if (pl.active) {
                     const int br = pl.ao >= H ? 1 : 0;
@@ -1022,7 +1023,7 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
                 PIME_NO_HOIST();
                 dw_rounds<T, T>(X, lane, wave, d2, FirstB<ACT>{lds + F.first0, xs, a.D, a.D, 0, md}, acc, bsum,
                                 DX_FIRST ? nullptr : wbuf, DX_FIRST ? nullptr : a.img_bwd + Lb.off[3], DX_FIRST ? 0 : T * T * 256,
-                                (a.trace && blockIdx.x == a.trace_wg) ? a.trace + 16 : nullptr);
+                                (a.trace && bid == a.trace_wg) ? a.trace + 16 : nullptr);
                 dw_store_full<T, T>(lane, wave, acc, bsum, sl + a.poff[2], sl + a.poff[3], accum);      // net.2
             }
             PIME_LDS_BARRIER();
@@ -1043,11 +1044,11 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     }
 
     PIME_MARK(12);
-    if (a.trace_span && threadIdx.x == 0 && blockIdx.x < 512) a.trace_span[2 * blockIdx.x + 1] = wall_clock64();
+    if (a.trace_span && threadIdx.x == 0 && bid < 512) a.trace_span[2 * bid + 1] = wall_clock64();
     // ---- workgroup totals of the scalar sums, combined in a fixed order (the slabs make the gradients reproducible
     // bit for bit; only the loss sums, which are for logging, use atomics)
     __syncthreads();
-    float* const sl = a.slab + (size_t)blockIdx.x * a.slab_stride;
+    float* const sl = a.slab + (size_t)bid * a.slab_stride;
     constexpr int NP = MODULAR ? 12 : 8;
     if (tid < md) {   // head weight
         float t = hacc[tid];
@@ -1069,6 +1070,26 @@ __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
             sl[a.poff[NP]] = (float)t[2];                 // d loss / d a_std_log
         }
     }
+}
+
+template <int T, int KIND>
+__global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    ppo_fused_body<T, KIND>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Both nets of an optimizer step in ONE launch: workgroups [0, na) run the actor's body, [na, na + nc) the critic's.  The two
+// gradients are independent, so nothing orders them; as separate launches the second could not start before the slowest
+// workgroup of the first had finished (launch ramp + tail + launch boundary, ~9 us of a 320 us step), here a compute unit that
+// finishes an actor workgroup picks up a critic one at once.  The longer body (the actor's) is dispatched first, so the tail is
+// made of the shorter ones.  (Round 1 tried a dual launch on the first version of these kernels and lost 1.5 %; the bodies have
+// since shed their spill scratch and ~30 us each.)
+template <int T, int AKIND>
+__global__ __launch_bounds__(kFusedThreads) void ppo_fused_dual_kernel(PpoArgs actor, PpoArgs critic, int na) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = (int)blockIdx.x;
+    if (b < na) ppo_fused_body<T, AKIND>(actor, lds, b, na);
+    else ppo_fused_body<T, MLP_CRITIC>(critic, lds, b - na, (int)gridDim.x - na);
 }
 
 // ==================================================================================================== slab reduction
@@ -1358,6 +1379,31 @@ static int launch_fused(const PpoArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((ppo_fused_kernel<T, KIND>), dim3(grid), dim3(kFusedThreads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
+}
+
+template <int T, int AKIND>
+static int launch_dual(const PpoArgs& actor, const PpoArgs& critic, hipStream_t s) {
+    const size_t la = sizeof(float) * (size_t)fused_lds(AKIND, actor.D, actor.Di, T).total;
+    const size_t lc = sizeof(float) * (size_t)fused_lds(MLP_CRITIC, critic.D, critic.Di, T).total;
+    const size_t lds_bytes = la > lc ? la : lc;
+    PIME_REQUIRE(lds_bytes <= 160 * 1024, "fused PPO kernels need %zu B of LDS (> 160 KB)", lds_bytes);
+    static LdsLimit lds_limit;  // per instantiation
+    PIME_RAISE_LDS(lds_limit, (ppo_fused_dual_kernel<T, AKIND>), 160 * 1024);
+    const int na = fused_grid(actor.B), nc = fused_grid(critic.B);
+    hipLaunchKernelGGL((ppo_fused_dual_kernel<T, AKIND>), dim3(na + nc), dim3(kFusedThreads), lds_bytes, s, actor, critic, na);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+// Actor and critic of the same width in one launch (see ppo_fused_dual_kernel); PIME_ERR_ARG if there is no instantiation.
+int launch_ppo_fused_dual(int actor_kind, int md, const PpoArgs& actor, const PpoArgs& critic, hipStream_t s) {
+    const int T = md / 32;
+#define PIME_DUAL(TT, KK) \
+    if (T == TT && actor_kind == KK) return launch_dual<TT, KK>(actor, critic, s);
+    PIME_DUAL(4, MLP_MODULAR_ACTOR) PIME_DUAL(4, MLP_PLAIN_ACTOR) PIME_DUAL(2, MLP_MODULAR_ACTOR) PIME_DUAL(2, MLP_PLAIN_ACTOR)
+#undef PIME_DUAL
+    set_error("no dual fused PPO instantiation for actor kind %d width %d", actor_kind, md);
+    return PIME_ERR_ARG;
 }
 
 // Does the kernel's LDS map fit?  (wide observations, e.g. the stacked water tank, do not: the caller then uses the

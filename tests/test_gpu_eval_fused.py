@@ -75,11 +75,16 @@ def test_fused_episode_returns_against_oracle_and_stepwise(env_name, algo, md):
         act = oracle.residual_action(oracle_mean(algo, obs, sd).astype(np.float32), obs, priorK)
         obs, _, rew, _ = ref.step(act)
         want += rew.astype(np.float32).astype(np.float64)
-    # pH: a float32-rounding difference of the policy mean can move one lane across a titration cell for a step; the episode
-    # return absorbs it (|dy| <= 0.03 on one step of 50)
-    np.testing.assert_allclose(got, want, rtol=2e-3 if is_ph else 1e-4, atol=0.05 if is_ph else 1e-3)
+    # pH: a float32-rounding difference of the policy mean (3e-5) can move a lane across a titration cell (|dy| <= 0.03), and on
+    # the steep part of the curve the closed loop amplifies that for the rest of the episode: a handful of lanes differ by up
+    # to a few percent of their return, the rest agree to rounding.  The tank is a smooth map: every lane to 1e-4.
+    for other in (want, slow):
+        rel = np.abs(got - other) / np.abs(other)
+        if is_ph:
+            assert (rel <= 1e-4).mean() >= 0.99 and rel.max() <= 0.05, (float((rel <= 1e-4).mean()), float(rel.max()))
+        else:
+            np.testing.assert_allclose(got, other, rtol=1e-4, atol=1e-3)
     assert np.median(np.abs(got - want) / np.abs(want)) < 2e-5
-    np.testing.assert_allclose(got, slow, rtol=2e-3 if is_ph else 1e-4, atol=0.05 if is_ph else 1e-3)
     for e in envs:
         e.close()
 
