@@ -97,11 +97,11 @@ def pmc_traffic_bytes(kernel_prefixes):
         return None, None
     data = json.load(open(path))
     total = 0.0
-    for pref in kernel_prefixes:
+    for pref in kernel_prefixes:   # every kernel of the profile whose name contains the prefix (one launch of each per minibatch)
         hit = [v for k, v in data.items() if pref in k]
         if not hit:
             return None, os.path.relpath(path, ROOT)
-        total += (hit[0]["fetch_mb_corrected"] + hit[0]["write_mb"]) * 1024 * 1024
+        total += sum((h["fetch_mb_corrected"] + h["write_mb"]) * 1024 * 1024 for h in hit)
     return total, os.path.relpath(path, ROOT)
 
 
@@ -422,11 +422,31 @@ def bench_water_tank_td3(args, device, json_fd):
     total = sum(step() for _ in range(args.steps))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # roofline of the update, which is 97 % of the step: one TD3 optimizer step on PyTorch-ROCm (autograd + rocBLAS + elementwise
+    # kernels, ~150 launches replayed from a HIP graph) against the f32 matrix peak.  Algorithmic flops per sample (net_dim 128,
+    # D = 4): actor 2 * 33 664, twin critic 2 * 17 408; target actor + target critic forwards, critic forward + backward (3x),
+    # actor objective: actor forward + backward (3x) and target-critic forward + input-gradient backward (2x)
+    agent.update_net(buf, lanes * T, batch, 1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    agent.update_net(buf, lanes * T, batch, 1)
+    torch.cuda.synchronize()
+    upd_ms = (time.perf_counter() - t1) * 1e3 / T
+    fa, fc = 2 * 33664, 2 * 17408
+    flops = (fa + fc + 3 * fc + 3 * fa + 2 * fc) * batch
+    td3_tf = flops / (upd_ms * 1e-3) / 1e12
+    roofline = {"kernel": "one TD3 optimizer step (AgentTD3.update_net on PyTorch-ROCm: ~150 autograd / rocBLAS / elementwise "
+                          "launches per step, HIP-graph replay)", "bound": "mfma", "achieved": td3_tf, "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": td3_tf / F32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": upd_ms,
+                "algorithmic_flops_per_launch": flops,
+                "note": "batch 4096 = 16 workgroup-sized sample groups: launch-latency bound by construction (profiles/"
+                        "r03_*_td3_kernel_stats.csv); the exploration is ONE launch per explore call (pime_rollout_offpolicy)"}
     out = {"metric": "env-steps/sec (rollout+update), water-tank env, 4096 parallel envs, residual TD3", "value": total / dt,
            "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "water tank Integrator-v2 (reward 'distance'), 4096 lanes x 200 lock-steps, AgentResidualTD3 "
-                                  "net_dim 128, 200 optimizer steps of batch 4096 per step (HIP-graph replay)"}}
+                                  "net_dim 128, 200 optimizer steps of batch 4096 per step (HIP-graph replay)"},
+           "roofline": roofline}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
@@ -627,11 +647,13 @@ def main():
     n_dom, ms_dom = ks[dominant]
     if dominant == "ppo_minibatch_grad":
         achieved = GRAD_FLOPS_PER_SAMPLE * BATCH / (ms_dom * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic_bytes(["ppo_fused_kernel<4, 0>", "ppo_fused_kernel<4, 2>",
-                                                  "ppo_grad_reduce_kernel"])
-        roofline = {"kernel": "ppo_minibatch_grad = ppo_fused_kernel<critic> + ppo_fused_kernel<modular_actor> + "
+        # the gradient kernels of the profile: ppo_fused_dual_kernel (round 3: actor and critic bodies in one grid) or the two
+        # ppo_fused_kernel launches of rounds 1-2, plus the slab reduction
+        traffic, traffic_src = pmc_traffic_bytes(["ppo_fused_", "ppo_grad_reduce_kernel"])
+        roofline = {"kernel": "ppo_minibatch_grad = ppo_fused_dual_kernel<4, modular_actor> (actor and critic bodies in one grid) + "
                               "ppo_grad_reduce_kernel (one minibatch of 65536: forward, loss, backward and weight "
-                              "gradients; per-kernel split in profiles/)", "bound": "mfma", "achieved": achieved,
+                              "gradients of both nets, slab reduction; per-kernel split in profiles/)", "bound": "mfma",
+                    "achieved": achieved,
                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                     "traffic": traffic,
                     "traffic_source": f"{traffic_src} (rocprofv3 --pmc of this bench, separate FETCH_SIZE / WRITE_SIZE passes, "
