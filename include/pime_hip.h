@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 12
+#define PIME_ABI_VERSION 13
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -372,6 +372,24 @@ int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * packed images, so no pime_ppo_repack follows.  For data-parallel callers, whose all-reduce sits between pime_ppo_minibatch_grad
  * and the optimizer step (single-GPU callers get the same from pime_ppo_minibatch_step in one launch less). */
 int pime_adam_step_images(const pime_adam* opt, const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream);
+
+/* -- one-shot all-reduce of the flat gradient buffer over peer-mapped memory ---------------------------------------------
+ * replaces: nothing in the reference (one process; elegantrl/run.py:232-247 is an unused mp.Pipe) -- it is the hand-written
+ * alternative to the RCCL all-reduce of SURVEY.md section 8(e) for the 270 KB gradient message: every rank writes its vector into
+ * every peer's inbox (hipIpc-mapped, one write per xGMI link, all links at once), raises a flag, waits for its peers' flags and
+ * sums the rows in rank order: one latency step, bit-identical results on every rank.  csrc/allreduce.hip has the protocol.
+ * Life cycle, per rank (one process per GPU): create -> export the 64-byte handle -> exchange the handles of all ranks (any
+ * transport: torch.distributed all_gather) -> connect -> allreduce_mean per optimizer step (one launch on the caller's stream,
+ * HIP-graph capturable) -> destroy.  world <= 8.  A peer that never arrives does not hang the device: the kernel gives up after
+ * ~2 s and pime_oneshot_status() returns non-zero. */
+typedef struct pime_oneshot pime_oneshot;
+pime_oneshot* pime_oneshot_create(int32_t rank, int32_t world, int64_t n_floats, int32_t device);
+int pime_oneshot_export(pime_oneshot* h, void* handle_out /* [host] 64 bytes */);
+int pime_oneshot_connect(pime_oneshot* h, const void* handles /* [host] world x 64 bytes, rank order */);
+/* data [dev] float32[n_floats]: replaced by the mean over the ranks */
+int pime_oneshot_allreduce_mean(pime_oneshot* h, float* data, pime_stream stream);
+int pime_oneshot_status(pime_oneshot* h);
+void pime_oneshot_destroy(pime_oneshot* h);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -44,13 +44,61 @@ def broadcast_scalar(value, src=0):
     return float(t.item())
 
 
+class OneShotAllReduce:
+    """The hand-written one-shot all-reduce (mean) of a flat float32 device buffer over peer-mapped memory
+    (csrc/allreduce.hip, `pime_oneshot_*`): every rank writes its vector into every peer's inbox, raises a flag, waits for its
+    peers' flags and sums the rows in rank order -- one launch on the current stream, HIP-graph capturable, bit-identical on
+    every rank.  The 64-byte IPC handles are exchanged once through the process group that is already up."""
+
+    def __init__(self, rank, world, n_floats, device):
+        import ctypes as C
+
+        from . import native
+        self._lib, self.n = native.lib(), int(n_floats)
+        self.device = torch.device(device)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC
+        self._h = C.c_void_p(self._lib.pime_oneshot_create(rank, world, self.n, self.device.index or 0))
+        if not self._h:
+            raise native.PimeError(f"pime_oneshot_create failed: {native.last_error()}")
+        mine = (C.c_ubyte * 64)()
+        native.check(self._lib.pime_oneshot_export(self._h, mine), "pime_oneshot_export")
+        dev = self.device if td.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        td.all_gather(gathered, t)
+        handles = (C.c_ubyte * (64 * world))(*[int(b) for g in gathered for b in g.cpu().tolist()])
+        native.check(self._lib.pime_oneshot_connect(self._h, handles), "pime_oneshot_connect")
+        td.barrier()   # every rank has mapped every region before the first push
+
+    def __call__(self, flat):
+        from . import native
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() == self.n
+        stream = torch.cuda.current_stream(flat.device).cuda_stream
+        native.check(self._lib.pime_oneshot_allreduce_mean(self._h, flat.data_ptr(), stream), "pime_oneshot_allreduce_mean")
+        return flat
+
+    def status(self):
+        """0: every call so far completed; non-zero: a peer did not arrive within the kernel's spin limit (synchronises)."""
+        return int(self._lib.pime_oneshot_status(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pime_oneshot_destroy(self._h)
+            self._h = None
+
+
 class DataParallel:
     def __init__(self, rank, world, local_rank=0, device=None):
         self.rank, self.world, self.local_rank = rank, world, local_rank
         self.device = device
         self._flat = None
+        # PIME_ONESHOT_ALLREDUCE=1: float32 device buffers are averaged by the hand-written one-shot kernel instead of RCCL.
+        # Opt-in: it is validated with two processes on ONE device (tests/test_gpu_oneshot_allreduce.py); visibility of
+        # fine-grained memory ACROSS devices over xGMI cannot be exercised on this pool's one-GPU boxes.
+        self.use_oneshot = os.environ.get("PIME_ONESHOT_ALLREDUCE") == "1"
+        self._oneshot = {}
         # RCCL collectives are kernels on the current stream and can be captured into a HIP graph; gloo's are host calls
-        self.graph_capturable = td.is_initialized() and td.get_backend() == "nccl"
+        self.graph_capturable = td.is_initialized() and (td.get_backend() == "nccl" or os.environ.get("PIME_ONESHOT_ALLREDUCE") == "1")
 
     def lane_offset(self, lanes_per_rank):
         """Global id of this rank's lane 0 (the env kernels' Philox counter word / Mt19937 seed offset)."""
@@ -69,6 +117,11 @@ class DataParallel:
     def all_reduce_mean(self, t):
         """Mean over the ranks in ONE collective: RCCL's AVG op on the GPU (no separate divide launch); gloo has no
         AVG, so the CPU tests sum and divide."""
+        if self.use_oneshot and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and self.world <= 8:
+            ar = self._oneshot.get(t.numel())
+            if ar is None:
+                ar = self._oneshot[t.numel()] = OneShotAllReduce(self.rank, self.world, t.numel(), t.device)
+            return ar(t)
         if td.get_backend() == "nccl":
             td.all_reduce(t, op=td.ReduceOp.AVG)
         else:

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PIME_LIB_PATH") or os.path.join(PACKAGE_DIR, "libpime
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
-ABI_VERSION = 12
+ABI_VERSION = 13
 ENV_PH, ENV_WT = 0, 1
 STATE_F64, STATE_MIXED, STATE_MIXED16 = 0, 1, 2
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
@@ -113,6 +113,12 @@ _SIGNATURES = {
     "pime_rollout_offpolicy_supported": (C.c_int, [_vp, _i32]),
     "pime_rollout_offpolicy": (C.c_int, [_vp, _i32, _vp, _vp, C.c_float, C.c_float, C.c_float, _i32, C.c_uint64, C.c_uint32, _vp, _vp,
                                          _vp, _i32, _i32, _vp]),
+    "pime_oneshot_create": (_vp, [_i32, _i32, C.c_int64, _i32]),
+    "pime_oneshot_export": (C.c_int, [_vp, _vp]),
+    "pime_oneshot_connect": (C.c_int, [_vp, _vp]),
+    "pime_oneshot_allreduce_mean": (C.c_int, [_vp, _vp, _vp]),
+    "pime_oneshot_status": (C.c_int, [_vp]),
+    "pime_oneshot_destroy": (None, [_vp]),
     "pime_rollout_h": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pime_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     "pime_ppo_minibatch_grad": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
