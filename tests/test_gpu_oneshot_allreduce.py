@@ -50,3 +50,41 @@ def test_two_processes_on_one_gpu_bit_equal_to_gloo(tmp_path, n):
             assert torch.equal(g, w), f"rank {r}, call {k}: one-shot all-reduce differs from gloo (max {float((g - w).abs().max())})"
     for k in range(11):
         assert torch.equal(res[0]["got"][k], res[1]["got"][k]), "the ranks must end with identical bits"
+
+
+def _run_dp(tmp_path, tag, oneshot):
+    world, port = 2, _free_port()
+    out = str(tmp_path / tag)
+    procs = []
+    for r in range(world):
+        env = {k: v for k, v in os.environ.items() if k != "PIME_ONESHOT_ALLREDUCE"}
+        env.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if oneshot:
+            env["PIME_ONESHOT_ALLREDUCE"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "oneshot_dp_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode()[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n---\n".join(logs)
+    return [torch.load(f"{out}.{r}.pt", weights_only=True) for r in range(world)]
+
+
+def test_data_parallel_update_with_the_oneshot_allreduce(tmp_path):
+    """Two data-parallel ranks (each its own lane slice, both on cuda:0) run three rollouts + updates of the bench's agent with
+    the per-optimizer-step flat-gradient all-reduce done by the one-shot kernel, captured INSIDE the step graphs: the replicas
+    end bit-identical, and bit-equal to the same run with gloo's all-reduce (two ranks: a + b is one rounding either way)."""
+    fast = _run_dp(tmp_path, "oneshot", True)
+    ref = _run_dp(tmp_path, "gloo", False)
+    assert all(r["oneshot"] and r["status"] == 0 and r["in_graph"] for r in fast), [(r["oneshot"], r["status"], r["in_graph"]) for r in fast]
+    assert not any(r["oneshot"] for r in ref)
+    assert torch.equal(fast[0]["flat"], fast[1]["flat"]), "replicas diverged under the one-shot all-reduce"
+    assert torch.equal(fast[0]["flat"], ref[0]["flat"]), "one-shot and gloo all-reduce give different weights"
+    assert torch.isfinite(fast[0]["flat"]).all()
