@@ -53,7 +53,7 @@ int launch_pack_bwd(int, int, int, int, const float* const*, float*, hipStream_t
 int launch_ppo_net(int, int, const PpoArgs&, hipStream_t);
 int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
 int launch_ppo_fused_dual(int, int, const PpoArgs&, const PpoArgs&, hipStream_t);
-int64_t fused_stash_floats(int, int);
+int64_t fused_stash_floats(int, int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
 int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, bool, bool, bool, bool, int, int, float* const*,
@@ -1045,7 +1045,7 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
             slab_args[k] = a;
             if (int rc = launch_ppo16(n->kind, n->md, a, s)) return rc;
         } else if (mode[k] == FUSED) {
-            a.slab = n->workspace + fused_stash_floats(b->B, n->md);
+            a.slab = n->workspace + fused_stash_floats(n->kind, b->B, n->md);
             a.slab_stride = slab_layout(n->kind, n->D, n->Di, n->md, a.poff, psize);
             slab_args[k] = a;
             if (dual) {

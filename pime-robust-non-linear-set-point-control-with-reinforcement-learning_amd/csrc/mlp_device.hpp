@@ -279,7 +279,8 @@ __device__ __forceinline__ void layer_mfma_in(const float* __restrict__ wp, cons
 // Backward chain step into a FIRST layer: out = (W * in) (.) act'(h1), where h1 = act(v) is the first-layer
 // activation whose pre-activations v the caller recomputed (layer_first<.., 2>).  The OT*16 activations (a tanh is ~50
 // VALU cycles) are evaluated inside the k-loop, in the shadow of the MFMAs, instead of after it.
-template <int KT, int OT, int ACT>
+// V_IS_ACT: v already holds the ACTIVATED h1 (read back from a stash) -- only act' = 1 - h1^2 / [h1 > 0] is formed here.
+template <int KT, int OT, int ACT, bool V_IS_ACT = false>
 __device__ __forceinline__ void layer_mfma_gate(const float* __restrict__ wp, int lane, const f32x16 (&in)[KT],
                                                 f32x16 (&out)[OT], f32x16 (&v)[OT]) {
     using Frag = typename WFrag<OT>::type;
@@ -303,7 +304,7 @@ __device__ __forceinline__ void layer_mfma_gate(const float* __restrict__ wp, in
             for (int q = 0; q < PERK; ++q) {
                 const int idx = (kt * 16 + s) * PERK + q;
                 if (idx < NV) {
-                    const float hq = activate<ACT>(v[idx >> 4][idx & 15]);
+                    const float hq = V_IS_ACT ? v[idx >> 4][idx & 15] : activate<ACT>(v[idx >> 4][idx & 15]);
                     v[idx >> 4][idx & 15] = ACT == 0 ? (hq > 0.f ? 1.f : 0.f) : fmaf(-hq, hq, 1.f);
                 }
             }

@@ -491,6 +491,22 @@ struct CatB {   // tiles [0,T): other branch, [T,2T): integrator branch
     }
 };
 
+template <int T>
+struct CatStashB {   // tiles [0,T): other_net's first-layer activation (stash region 1), [T,2T): integrator_net's (region 2)
+    static constexpr bool kLate = false;  // global loads: issue early, they land behind the MFMAs
+    template <int NP> using Pre = NoPre;
+    const float *o, *i;   // the group's first tile in either region
+    int tile_stride;
+    template <int NP>
+    __device__ __forceinline__ void prepare(int, int, int, NoPre&) const {}
+    template <int NP>
+    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, const NoPre&, float (&v)[NP]) const {
+        const float* p = (t < T ? o : i) + (size_t)ow * tile_stride + ((t < T ? t : t - T) * 16 + r0) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) v[k] = p[k * 64];
+    }
+};
+
 // One 32x32 accumulator block -> rows row0.. of a row-major [.. x ldw] slab tensor at column `col` (this lane's).  The
 // accumulate / overwrite decision is wave-uniform: taken once, not per element.
 __device__ __forceinline__ void block_store(const f32x16& acc, float* __restrict__ gW, int ldw, int row0, int col,
@@ -714,6 +730,15 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
         const float* xrow = a.state + (size_t)row * a.D;
         float* st = a.stash + (size_t)tile * T * 1024;
         const float* st0 = a.stash + (size_t)group * kFusedWaves * T * 1024;  // the group's first tile
+        // Stash regions 1 (and 2): the FIRST-layer activations (round 3).  Rounds 1-2 recomputed them from the states wherever the
+        // backward needed them -- as B operand of the second layer's weight-gradient rounds and for act'(H1) -- which is ~1 000
+        // vector instructions per wave for the critic and ~2 300 (640 of them transcendental pairs) for the modular actor; with
+        // f32 MFMAs every one of those is time on the SIMD, while 64 fire-and-forget stores and prefetched loads are not.
+        const size_t region = (size_t)ngroups * kFusedWaves * T * 1024;
+        float* st1 = st + region;
+        const float* st1_0 = st0 + region;
+        [[maybe_unused]] float* st2 = st + 2 * region;
+        [[maybe_unused]] const float* st2_0 = st0 + 2 * region;
         const float in_rsum = CRITIC ? a.r_sum[row] : 0.f;
         const float in_action = CRITIC ? 0.f : a.action[row];
         const float in_logprob = CRITIC ? 0.f : a.logprob[row];
@@ -772,15 +797,19 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
                 layer_first<T, 2>(lds + F.first0, xl, Do, h, a0);   // activations are applied by the consuming layer
                 wait_dma_then_barrier<NI_TH + NI_TT>();               // other_net.2's image has landed
                 layer_mfma_in<T, H, 2, 1>(X, lds + F.bias[0], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
+                stash_put<T>(st1, lane, a0);                         // h_o1 (activated in place by the layer above)
             }
+            // (vmcnt is a 6-bit in-order counter: with T * 16 stash stores younger than the image DMAs, "all but the 63 youngest
+            //  done" is the weakest encodable wait that covers the DMAs; it forces at most one store, issued a layer ago)
             {
                 f32x16 a0[T];
                 PIME_NO_HOIST();
                 layer_first<T, 2>(lds + F.first1, xl + Do, a.Di, h, a0);
-                wait_dma_then_barrier<NI_TT>();                       // integrator_net.2's
+                wait_dma_then_barrier<(NI_TT + T * 16 < 63 ? NI_TT + T * 16 : 63)>();   // integrator_net.2's
                 layer_mfma_in<T, H, 2, 1>(X + T * H * 1024, lds + F.bias[1], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
+                stash_put<T>(st2, lane, a0);                         // h_i1
             }
-            wait_dma_then_barrier<0>();                               // net.0's
+            wait_dma_then_barrier<(2 * T * 16 < 63 ? 2 * T * 16 : 63)>();   // net.0's (older than every stash store)
             layer_mfma_in<T, T, 1, 1>(wbuf, lds + F.bias[2], lane, cat, hl);   // cat: tanh applied in place
             stash_put<T>(st, lane, cat);
             PIME_NO_HOIST();
@@ -792,8 +821,11 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
                 layer_first<T, 2>(lds + F.first0, xl, a.D, h, a0);   // activations are applied by the consuming layer
                 wait_dma_then_barrier<NI_TT>();                       // net.2's image has landed
                 layer_mfma_in<T, T, 2, ACT>(wbuf, lds + F.bias[0], lane, a0, a1);
+                stash_put<T>(st1, lane, a0);                         // H1 (activated in place by the layer above)
             }
-            wait_dma_then_barrier<0>();                               // net.4's; every wave is done with net.2's (wbuf)
+            // net.4's image (older than the T * 16 stash stores just issued: see the note on vmcnt in the modular branch); every
+            // wave is done with net.2's (wbuf)
+            wait_dma_then_barrier<(T * 16 < 63 ? T * 16 : 63)>();
             if constexpr (DX_FIRST) dma_image<NI_TT>(wbuf, a.img_bwd + Lb.off[2], tid);
             layer_mfma_in<T, T, ACT, ACT>(X, lds + F.bias[1], lane, a1, hl);     // a1 (H2): activated in place
             stash_put<T>(st, lane, a1);
@@ -905,9 +937,8 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
                 f32x16 acc[CatPlan<T>::PER];
                 float bsum;
                 PIME_NO_HOIST();
-                dw_rounds<T, 2 * T, CatB<T>, CatPlan<T>>(
-                    wbuf, lane, wave, dcat,
-                    CatB<T>{FirstB<1, false>{lds + F.first0, xs, Do, a.D, 0, md}, FirstB<1, false>{lds + F.first1, xs, a.Di, a.D, Do, md}},
+                dw_rounds<T, 2 * T, CatStashB<T>, CatPlan<T>>(
+                    wbuf, lane, wave, dcat, CatStashB<T>{st1_0, st2_0, T * 1024},
                     acc, bsum, nullptr, nullptr, 0, (a.trace && bid == a.trace_wg) ? a.trace + 16 : nullptr);
                 const CatPlan<T> pl(wave);
                 if (pl.active) {
@@ -934,10 +965,10 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
                     float* const img = wbuf + br * H * T * 1024;
                     f32x16 d1[T];
                     {
-                        f32x16 v[T];   // pre-activations of h1; the layer turns them into act'(h1)
-                        layer_first<T, 2>(lds + (br ? F.first1 : F.first0), xl + col0, Din, h, v);
+                        f32x16 v[T];   // h1 (activated) from the stash; the layer turns it into act'(h1) behind its MFMAs
+                        stash_get<T>(br ? st2 : st1, lane, v);
                         PIME_NO_HOIST();
-                        layer_mfma_gate<H, T, 1>(img, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[br * H]), d1, v);   // dZ1
+                        layer_mfma_gate<H, T, 1, true>(img, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[br * H]), d1, v);   // dZ1
                     }
                     PIME_MARK(9 + br);
                     float* gW = sl + a.poff[br ? 4 : 0], *gb = sl + a.poff[br ? 5 : 1];
@@ -957,12 +988,20 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
                 PIME_NO_HOIST();
                 layer_mfma<H, T, 2, false>(wbuf, nullptr, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[0]),
                                            *reinterpret_cast<f32x16(*)[T]>(&d1[0]));
-                first_times_act_grad<T, 1>(lds + F.first0, xl, Do, h, *reinterpret_cast<f32x16(*)[T]>(&d1[0]));  // dZo1
+                {
+                    f32x16 hh[T];
+                    stash_get<T>(st1, lane, hh);
+                    times_act_grad<T, 1>(*reinterpret_cast<f32x16(*)[T]>(&d1[0]), hh);                  // dZo1
+                }
                 PIME_MARK(9);
                 PIME_NO_HOIST();
                 layer_mfma<H, T, 2, false>(wbuf + H * T * 1024, nullptr, lane, *reinterpret_cast<f32x16(*)[H]>(&dcat[H]),
                                            *reinterpret_cast<f32x16(*)[T]>(&d1[T]));
-                first_times_act_grad<T, 1>(lds + F.first1, xl + Do, a.Di, h, *reinterpret_cast<f32x16(*)[T]>(&d1[T]));  // dZi1
+                {
+                    f32x16 hh[T];
+                    stash_get<T>(st2, lane, hh);
+                    times_act_grad<T, 1>(*reinterpret_cast<f32x16(*)[T]>(&d1[T]), hh);                  // dZi1
+                }
                 PIME_MARK(10);
                 if (a.D <= kFirstValuMaxD) {   // other_net.0, integrator_net.0 on the vector ALUs
                     first_grad_valu<T>(X, lane, wave, *reinterpret_cast<f32x16(*)[T]>(&d1[0]), xsp, a.D, 0, Do,
@@ -1021,7 +1060,7 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
                 f32x16 acc[DwPlan<T, T>::PER];
                 float bsum;
                 PIME_NO_HOIST();
-                dw_rounds<T, T>(X, lane, wave, d2, FirstB<ACT>{lds + F.first0, xs, a.D, a.D, 0, md}, acc, bsum,
+                dw_rounds<T, T>(X, lane, wave, d2, StashB{st1_0, T * 1024}, acc, bsum,
                                 DX_FIRST ? nullptr : wbuf, DX_FIRST ? nullptr : a.img_bwd + Lb.off[3], DX_FIRST ? 0 : T * T * 256,
                                 (a.trace && bid == a.trace_wg) ? a.trace + 16 : nullptr);
                 dw_store_full<T, T>(lane, wave, acc, bsum, sl + a.poff[2], sl + a.poff[3], accum);      // net.2
@@ -1030,7 +1069,11 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
             PIME_MARK(7);
             PIME_NO_HOIST();
             layer_mfma<T, T, 2, false>(wbuf, nullptr, lane, d2, d);
-            first_times_act_grad<T, ACT>(lds + F.first0, xl, a.D, h, d);                            // dZ1 (H1 again)
+            {
+                f32x16 hh[T];
+                stash_get<T>(st1, lane, hh);                                                        // H1
+                times_act_grad<T, ACT>(d, hh);                                                      // dZ1
+            }
             PIME_MARK(8);
             if (a.D <= kFirstValuMaxD) {   // net.0 on the vector ALUs (W is dead: its LDS holds the partial sums)
                 first_grad_valu<T>(X, lane, wave, d, xsp, a.D, 0, a.D, sl + a.poff[0], sl + a.poff[1], accum);
@@ -1359,13 +1402,18 @@ int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, 
 }
 
 // Floats of workspace the fused kernel needs: activation stash (one hidden activation per sample) + gradient slabs.
-int64_t fused_stash_floats(int B, int md) {
+// One stash region holds one width-md activation of every sample: [tile][md / 32][16][64].  Regions: 0 = the hidden activation in
+// front of the last hidden layer (critic / plain actor H2, modular actor `cat`), 1 = the first-layer activation H1 (modular actor:
+// other_net's), 2 = the modular actor's integrator_net first-layer activation.
+int64_t fused_stash_region_floats(int B, int md) {
     const int64_t ngroups = ((B + 31) / 32 + kFusedWaves - 1) / kFusedWaves;
     return ngroups * kFusedWaves * (md / 32) * 1024;
 }
+int fused_stash_regions(int kind) { return kind == MLP_MODULAR_ACTOR ? 3 : 2; }
+int64_t fused_stash_floats(int kind, int B, int md) { return fused_stash_regions(kind) * fused_stash_region_floats(B, md); }
 int64_t fused_workspace_floats(int kind, int B, int D, int Di, int md) {
     int poff[13], psize[12];
-    return fused_stash_floats(B, md) + (int64_t)fused_grid(B) * slab_layout(kind, D, Di, md, poff, psize);
+    return fused_stash_floats(kind, B, md) + (int64_t)fused_grid(B) * slab_layout(kind, D, Di, md, poff, psize);
 }
 
 template <int T, int KIND>

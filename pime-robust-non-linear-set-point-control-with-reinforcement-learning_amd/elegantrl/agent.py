@@ -548,12 +548,20 @@ class AgentPPO(AgentBase):
             if self.use_hip_graphs and st.warm and st.graph_a is None and st.graph_full is None:
                 try:
                     if one_graph and self.dp is not None:
+                        refused = None
                         try:
                             st.graph_full = capture(grads, lambda: self.dp.all_reduce_mean(fused.flat_grad), apply)
                         except RuntimeError as exc:
-                            print(f"| all-reduce inside the HIP graph refused ({exc}); using the two-graph step sequence")
+                            refused = exc
+                        # the ranks must use the SAME launch form from here on (a rank replaying the collective from its graph
+                        # while another issues it eagerly between two graphs would still match up, but a rank-local failure
+                        # must not go unnoticed): one MAX over the ranks decides for all of them
+                        if self.dp.max_over_ranks(1.0 if refused is not None else 0.0) > 0.5:
+                            print(f"| all-reduce inside the HIP graph refused on a rank ({refused}); every rank uses the "
+                                  "two-graph step sequence")
                             self.use_graph_collective, one_graph = False, False
                             st.mode = (use_table, one_graph, fuse_adam)
+                            st.graph_full = None
                             torch.cuda.synchronize(dev)
                             st.graph_a, st.graph_b = capture(grads), capture(apply)
                     elif one_graph:

@@ -188,7 +188,34 @@ class FusedPPOGrad:
                                                      self.flat_param.numel(), m.data_ptr(), _stream(self.flat_param))
             self._image_map = m if rc == 0 else False
             self.image_map_error = None if rc == 0 else native.last_error()
+            if rc == 0 and not self._image_map_is_exact(m):
+                # the map assumes every pack kernel is a pure permutation of the parameters; a pack kernel that ever scales or
+                # folds a weight would make a map-scattered image differ from a re-packed one: then re-pack after every step
+                self._image_map, self.image_map_error = False, "map-scattered images differ from the re-packed ones"
         return self._image_map if self._image_map is not False else None
+
+    def _image_map_is_exact(self, m):
+        """Scatter the CURRENT parameter values through the map into zeroed images and compare them bit for bit with what
+        repack() laid down: every mapped position must hold its parameter, every unmapped one the packing's zero padding."""
+        self.repack()
+        pairs = m.view(-1, 2).to(torch.int64)
+        for col, key in ((0, "img_fwd"), (1, "img_bwd")):
+            code = pairs[:, col]
+            valid = code >= 0
+            pos, which = code & ((1 << 28) - 1), (code >> 28) & 3
+            for net_bit, net in ((1, self.nets[0]), (0, self.nets[1])):     # bits 28..29: 0 critic, 1 actor; self.nets = [actor, critic]
+                sel = valid & (which == net_bit)
+                have = net[key]
+                if bool((pos[sel] >= have.numel()).any()):
+                    return False
+                if all(p.requires_grad for p in net["plist"]):   # every image element is a mapped parameter or zero padding
+                    want = torch.zeros_like(have)
+                    want[pos[sel]] = self.flat_param.detach()[sel]
+                    if not torch.equal(want, have):
+                        return False
+                elif not torch.equal(have[pos[sel]], self.flat_param.detach()[sel]):   # frozen tensors are in the images, not the map
+                    return False
+        return True
 
     @property
     def images_follow_step(self):
