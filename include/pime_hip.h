@@ -192,10 +192,10 @@ int pime_gae_scan(const float* reward, const float* mask, const float* value, in
  *                                integrator_net.2 W,b ; net.0 W,b ; net.2 W,b ; Di = integrator_dim (trailing
  *                                columns of x)
  * All weights are [dev] float32 in nn.Linear layout ([out, in] row-major).  D <= 32.  Widths: 64 and 128 (every kind: the
- * whole net stays in the 160 KB LDS of a persistent workgroup, csrc/mlp_mfma.hip) and 256 (CRITIC and PLAIN_ACTOR -- the width
- * run_watertank_changing.sh:20-27 trains on the 30-float Stacking10 observation: 16-sample tiles on v_mfma_f32_16x16x4_f32 with
- * the 256 x 256 images streamed through LDS in k-slices, csrc/mlp16.hip).  A MODULAR_ACTOR of width 256 has no kernel: the
- * size queries return 0 with a message and the Python agents warn and use torch modules on the GPU.
+ * whole net stays in the 160 KB LDS of a persistent workgroup, csrc/mlp_mfma.hip) and 256 (every kind -- the width
+ * run_watertank_changing.sh trains: ResidualPPO on the 30-float Stacking10 observation :20-27, ResidualIntegratorModularPPO on the
+ * Integrator observation :11-18 -- on 16-sample tiles of v_mfma_f32_16x16x4_f32 with the weight images streamed through LDS in
+ * k-slices, csrc/mlp16.hip; the modular actor's md -> md/2 tower layers are rectangular chain layers there).
  * out [dev] float32[M] is the scalar head (value, or pre-tanh action mean without noise and prior term). */
 enum pime_mlp_kind { PIME_MLP_CRITIC = 0, PIME_MLP_PLAIN_ACTOR = 1, PIME_MLP_MODULAR_ACTOR = 2 };
 /* floats in the packed image (0 and an error message if the shape is unsupported) */

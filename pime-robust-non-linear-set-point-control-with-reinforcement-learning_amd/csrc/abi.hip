@@ -63,7 +63,7 @@ int fused_grid(int);
 bool family16(int, int);
 bool family16_grad(int, int, int, int);
 int64_t ppo_fwd_image_floats(int, int, int, int);
-int grid16(int, int, int);
+int grid16(int, int, int, int, int);
 int launch_pack16(const PackArgs&, float*, float*, hipStream_t);
 int launch_ppo16(int, int, const PpoArgs&, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
@@ -678,7 +678,7 @@ int64_t pime_ppo_fwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t m
 }
 
 int64_t pime_ppo_workspace_floats(int32_t kind, int32_t B, int32_t md) {
-    if (B < 1 || (md != 64 && md != 128 && md != 256) || (md == 256 && kind == PIME_MLP_MODULAR_ACTOR)) {
+    if (B < 1 || (md != 64 && md != 128 && md != 256)) {
         set_error("pime_ppo_workspace_floats: B=%d md=%d kind=%d", B, md, kind);
         return 0;
     }
@@ -1041,7 +1041,7 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
         int psize[12];
         if (mode[k] == F16) {
             a.slab = n->workspace;
-            a.slab_stride = slab_layout16(n->D, n->md, a.poff, psize);
+            a.slab_stride = n->kind == PIME_MLP_MODULAR_ACTOR ? slab_layout16m(n->md, a.poff, psize) : slab_layout16(n->D, n->md, a.poff, psize);
             slab_args[k] = a;
             if (int rc = launch_ppo16(n->kind, n->md, a, s)) return rc;
         } else if (mode[k] == FUSED) {
@@ -1095,8 +1095,8 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
         }
     }
     if (any_slab) {
-        const int nslabs[2] = {mode[0] == F16 ? grid16(b->B, critic->md, critic->D) : fused_grid(b->B),
-                               mode[1] == F16 ? grid16(b->B, actor->md, actor->D) : fused_grid(b->B)};
+        const int nslabs[2] = {mode[0] == F16 ? grid16(critic->kind, b->B, critic->md, critic->D, critic->Di) : fused_grid(b->B),
+                               mode[1] == F16 ? grid16(actor->kind, b->B, actor->md, actor->D, actor->Di) : fused_grid(b->B)};
         if (int rc = launch_grad_reduce(slab_args[0], slab_args[1], critic->kind, critic->md, actor->kind, actor->md,
                                         mode[0] == F16, mode[1] == F16, mode[0] != SPLIT, mode[1] != SPLIT, nslabs[0], nslabs[1],
                                         critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, loss_sums + 3,

@@ -135,19 +135,22 @@ __device__ __forceinline__ float act16(float v) {
 // hipcc sinks register-staged loads down to their ds_write (the L2 round trip then sits exposed in front of every barrier)
 // and lets one ds_read run ahead at most: the DMA has no register to sink, and sched_barrier pins the fragment reads.
 // wbuf must be free on entry (callers barrier before); it is free again on return.
-template <int T>
+// TK input tiles (k = 16 TK features), TO output tiles; the square layers of the plain nets are TK = TO = T, the modular actor's
+// tower layers md -> md/2 are (T, T/2) and their transposes (T/2, T).
+template <int TK, int TO = TK>
 struct Layer16Geom {
-    static constexpr int Q = T / 4;
-    static constexpr int KS = T * 4;                       // k-steps of the layer (width / 4)
-    static constexpr int SKS = T >= 8 ? 8 : KS;            // k-steps per slice
+    static constexpr int Q = TO / 4;
+    static constexpr int KS = TK * 4;                      // k-steps of the layer (input width / 4)
+    static constexpr int SKS = TK >= 8 ? 8 : KS;           // k-steps per slice
     static constexpr int NS = KS / SKS;
     static constexpr int SLICE = SKS * Q * 256;            // floats
     static constexpr int NBUFW = NS >= 3 ? 3 : NS;
     static constexpr int PER = SLICE / 4 / k16Threads;     // 1 KB DMA pieces per wave per slice
-    static constexpr int KSG = T >= 16 ? 1 : 16 / T;       // k-steps per fragment group: KSG * T = 16 MFMAs
+    static constexpr int KSG = TO >= 16 ? 1 : 16 / TO;     // k-steps per fragment group: KSG * TO = 16 MFMAs
     static constexpr int NG = SKS / KSG;
     static constexpr int NF = KSG * Q;                     // float4 fragments per group
     static_assert(SLICE / 4 % k16Threads == 0, "slice must split evenly over the workgroup");
+    static_assert(TO % 4 == 0 && SKS % KSG == 0, "whole quads of output tiles, whole fragment groups per slice");
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -161,10 +164,11 @@ __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "add the count");
 }
 
-template <int T, int ACT, bool HAS_BIAS>
-__device__ __forceinline__ void layer16(const float* __restrict__ gimg, const float* __restrict__ bias, float* __restrict__ wbuf,
-                                        int lane, int tid, const f32x4 (&in)[T], f32x4 (&out)[T]) {
-    using G = Layer16Geom<T>;
+template <int TK, int TO, int ACT, bool HAS_BIAS>
+__device__ __forceinline__ void layer16r(const float* __restrict__ gimg, const float* __restrict__ bias, float* __restrict__ wbuf,
+                                         int lane, int tid, const f32x4 (&in)[TK], f32x4 (&out)[TO]) {
+    using G = Layer16Geom<TK, TO>;
+    constexpr int T = TO;   // the output-side loops below run over the TO output tiles
     constexpr int Q = G::Q, SKS = G::SKS, NS = G::NS, SLICE = G::SLICE, PER = G::PER, KSG = G::KSG, NG = G::NG, NF = G::NF;
     const int g = lane >> 4;
     const int wave_base = (tid >> 6) * 256;   // floats: this wave's 1 KB piece inside every 4 KB of a slice
@@ -236,9 +240,15 @@ __device__ __forceinline__ void layer16(const float* __restrict__ gimg, const fl
         for (int r = 0; r < 4; ++r) out[t][r] = act16<ACT>(out[t][r]);
 }
 
-template <int T>
+template <int T, int ACT, bool HAS_BIAS>
+__device__ __forceinline__ void layer16(const float* __restrict__ gimg, const float* __restrict__ bias, float* __restrict__ wbuf,
+                                        int lane, int tid, const f32x4 (&in)[T], f32x4 (&out)[T]) {
+    layer16r<T, T, ACT, HAS_BIAS>(gimg, bias, wbuf, lane, tid, in, out);
+}
+
+template <int TK, int TO = TK>
 __host__ __device__ constexpr int layer16_lds_floats() {
-    return Layer16Geom<T>::NBUFW * Layer16Geom<T>::SLICE;
+    return Layer16Geom<TK, TO>::NBUFW * Layer16Geom<TK, TO>::SLICE;
 }
 
 // First layer from the LDS-resident natural-order image: h = act(W0 x + b0), x[s][4 ks + g] in xr[ks].
@@ -818,6 +828,312 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
     }
 }
 
+// ==================================================================================================== modular actor
+// ActorResidualIntegratorModularPPO (/root/reference/elegantrl/net_residual.py:138-205) in the 16-tile family, for the width the
+// LDS-resident kernels cannot hold (net_dim 256: run_watertank_changing.sh:11-18):
+//   o1 = tanh(Wo0 x[:, :Do] + bo0)  (md)     o2 = tanh(Wo2 o1 + bo2)  (md / 2)
+//   i1 = tanh(Wi0 x[:, Do:] + bi0)  (md)     i2 = tanh(Wi2 i1 + bi2)  (md / 2)
+//   n0 = tanh(Wn0 [o2 | i2] + bn0)  (md)     mean = wn2 . n0 + bn2
+// The towers' second layers are rectangular chain layers (layer16r<T, T/2>), their transposes layer16r<T/2, T>; `cat` is the two
+// half-width activations side by side in one T-tile register array, so net.0 and its weight gradient are the square-layer code.
+// Weight gradients of the tower layers: dw16<T/2, T> (rectangular patches), first layers dw16<T, 1> on the tower's own columns.
+struct Layout16M {
+    int T, KS0o, KS0i;
+    int w0o, b0o, w1o, b1o, w0i, b0i, w1i, b1i, wn, bn, w3, b3, total;   // forward image (float offsets)
+};
+struct LayoutB16M {
+    int wnt, w1ot, w1it, total;   // backward image: Wn0^T (md -> md), Wo2^T, Wi2^T (md/2 -> md) as chain-order layers
+};
+__host__ __device__ inline Layout16M layout16m(int D, int Di, int md) {
+    Layout16M L{};
+    const int Do = D - Di;
+    L.T = md / 16;
+    L.KS0o = (Do + 3) / 4;
+    L.KS0i = (Di + 3) / 4;
+    int o = 0;
+    auto seg = [&](int& f, int n) { f = o; o += (n + 3) & ~3; };
+    seg(L.w0o, L.KS0o * L.T * 64); seg(L.b0o, md);
+    seg(L.w1o, md * md / 2); seg(L.b1o, md / 2);
+    seg(L.w0i, L.KS0i * L.T * 64); seg(L.b0i, md);
+    seg(L.w1i, md * md / 2); seg(L.b1i, md / 2);
+    seg(L.wn, md * md); seg(L.bn, md);
+    seg(L.w3, md); seg(L.b3, 4);
+    L.total = o;
+    return L;
+}
+__host__ __device__ inline LayoutB16M layoutb16m(int md) {
+    LayoutB16M L{};
+    L.wnt = 0; L.w1ot = md * md; L.w1it = md * md + md * md / 2; L.total = 2 * md * md;
+    return L;
+}
+
+// params (nn.Linear W, b pairs): other_net.0, other_net.2, integrator_net.0, integrator_net.2, net.0, net.2
+__global__ void pack16m_kernel(PackArgs a, float* __restrict__ fwd, float* __restrict__ bwd) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+    const int md = a.md, hd = md / 2, Do = a.D - a.Di;
+    if (fwd) {
+        const Layout16M L = layout16m(a.D, a.Di, md);
+        pack16_layer(fwd + L.w0o, a.p[0], md, Do, md, Do, L.KS0o, true, false, tid, nthr);
+        pack16_layer(fwd + L.w1o, a.p[2], hd, md, hd, md, md / 4, false, false, tid, nthr);
+        pack16_layer(fwd + L.w0i, a.p[4], md, a.Di, md, a.Di, L.KS0i, true, false, tid, nthr);
+        pack16_layer(fwd + L.w1i, a.p[6], hd, md, hd, md, md / 4, false, false, tid, nthr);
+        pack16_layer(fwd + L.wn, a.p[8], md, md, md, md, md / 4, false, false, tid, nthr);
+        for (int i = tid; i < md; i += nthr) {
+            fwd[L.b0o + i] = a.p[1][i];
+            fwd[L.b0i + i] = a.p[5][i];
+            fwd[L.bn + i] = a.p[9][i];
+            fwd[L.w3 + i] = a.p[10][i];
+            if (i < hd) { fwd[L.b1o + i] = a.p[3][i]; fwd[L.b1i + i] = a.p[7][i]; }
+        }
+        if (tid < 4) fwd[L.b3 + tid] = tid == 0 ? a.p[11][0] : 0.f;
+    }
+    if (bwd) {
+        const LayoutB16M L = layoutb16m(md);
+        pack16_layer(bwd + L.wnt, a.p[8], md, md, md, md, md / 4, false, true, tid, nthr);
+        // V = W^T of a [hd x md] matrix: md outputs, hd inputs (k-steps hd / 4); W's row length is md
+        pack16_layer(bwd + L.w1ot, a.p[2], hd, md, md, hd, hd / 4, false, true, tid, nthr);
+        pack16_layer(bwd + L.w1it, a.p[6], hd, md, md, hd, hd / 4, false, true, tid, nthr);
+    }
+}
+
+struct Lds16M {
+    int w0o, b0o, b1o, w0i, b0i, b1i, bn, w3, b3, wsum, region, total;
+};
+template <int T>
+__host__ __device__ inline Lds16M lds16m(int D, int Di, bool grad) {
+    const int md = T * 16;
+    const Layout16M L = layout16m(D, Di, md);
+    Lds16M S{};
+    int o = 0;
+    auto seg = [&](int& f, int n) { f = o; o += (n + 3) & ~3; };
+    seg(S.w0o, L.KS0o * T * 64); seg(S.b0o, md); seg(S.b1o, md / 2);
+    seg(S.w0i, L.KS0i * T * 64); seg(S.b0i, md); seg(S.b1i, md / 2);
+    seg(S.bn, md); seg(S.w3, md); seg(S.b3, 4);
+    seg(S.wsum, k16Waves * 6 * 2);
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    int region = mx(layer16_lds_floats<T, T>(), mx(layer16_lds_floats<T, T / 2>(), layer16_lds_floats<T / 2, T>()));
+    if (grad) {
+        constexpr int RT = T <= 8 ? 4 : 2;
+        int dwf = mx(dw16_lds_floats<T, T, RT>(), mx(dw16_lds_floats<T / 2, T, RT>(), dw16_lds_floats<T, 1, RT>()));
+        if constexpr (T == 4 * k16Waves) dwf = mx(dwf, Dw16Sliced<T>::FLOATS);
+        region = mx(region, mx(dwf, k16Waves * md));
+    }
+    seg(S.region, region);
+    S.total = o;
+    return S;
+}
+
+template <int T>
+__device__ __forceinline__ void stage_small16m(float* lds, const Lds16M& S, const float* __restrict__ img, const Layout16M& L, int tid) {
+    const int md = T * 16;
+    for (int e = tid; e < L.KS0o * T * 16; e += k16Threads) reinterpret_cast<float4*>(lds + S.w0o)[e] = reinterpret_cast<const float4*>(img + L.w0o)[e];
+    for (int e = tid; e < L.KS0i * T * 16; e += k16Threads) reinterpret_cast<float4*>(lds + S.w0i)[e] = reinterpret_cast<const float4*>(img + L.w0i)[e];
+    for (int e = tid; e < md; e += k16Threads) {
+        lds[S.b0o + e] = img[L.b0o + e];
+        lds[S.b0i + e] = img[L.b0i + e];
+        lds[S.bn + e] = img[L.bn + e];
+        lds[S.w3 + e] = img[L.w3 + e];
+        if (e < md / 2) { lds[S.b1o + e] = img[L.b1o + e]; lds[S.b1i + e] = img[L.b1i + e]; }
+    }
+    if (tid < 4) lds[S.b3 + tid] = img[L.b3 + tid];
+}
+
+// the towers' inputs in the first layer's natural k order: lane (s, g) holds column 4 ks + g of its tower's slice of the state
+__device__ __forceinline__ void gather_x16m(const float* __restrict__ xrow, int D, int Di, int g, float (&xo)[8], float (&xi)[8]) {
+    const int Do = D - Di;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int c = 4 * ks + g;
+        xo[ks] = c < Do ? xrow[c] : 0.f;
+        xi[ks] = c < Di ? xrow[Do + c] : 0.f;
+    }
+}
+
+// policy mean of the modular actor (forward only): pime_mlp_forward at width 256
+template <int T>
+__global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void mlp16m_forward_kernel(const float* __restrict__ x, int M, int D, int Di,
+                                                                                     const float* __restrict__ img,
+                                                                                     float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int H = T / 2;
+    const Layout16M L = layout16m(D, Di, T * 16);
+    const Lds16M S = lds16m<T>(D, Di, false);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 15, g = lane >> 4;
+    stage_small16m<T>(lds, S, img, L, tid);
+    __syncthreads();
+    const int ngroups = (M + k16Group - 1) / k16Group;
+#pragma unroll 1
+    for (int group = blockIdx.x; group < ngroups; group += gridDim.x) {
+        const int m = group * k16Group + wave * 16 + s;
+        float xo[8], xi[8];
+        gather_x16m(x + (size_t)(m < M ? m : M - 1) * D, D, Di, g, xo, xi);
+        f32x4 cat[T], n0[T];
+        {
+            f32x4 t1[T];
+            first16<T, 1>(lds + S.w0o, lds + S.b0o, L.KS0o, lane, xo, t1);
+            PIME_NO_HOIST();
+            layer16r<T, H, 1, true>(img + L.w1o, lds + S.b1o, lds + S.region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[0]));
+            PIME_NO_HOIST();
+            first16<T, 1>(lds + S.w0i, lds + S.b0i, L.KS0i, lane, xi, t1);
+            PIME_NO_HOIST();
+            layer16r<T, H, 1, true>(img + L.w1i, lds + S.b1i, lds + S.region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[H]));
+        }
+        PIME_NO_HOIST();
+        layer16<T, 1, true>(img + L.wn, lds + S.bn, lds + S.region, lane, tid, cat, n0);
+        const float y = head16<T>(lds + S.w3, lds[S.b3], lane, n0);
+        if (g == 0 && m < M) out[m] = y;
+    }
+}
+
+// PPO minibatch gradients of the modular actor: ppo16_kernel's structure (no activation stash, slabs in accumulator order)
+template <int T>
+__global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16m_kernel(PpoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int ACT = 1, md = T * 16, H = T / 2;
+    constexpr int RT = T <= 8 ? 4 : 2;
+    const Layout16M L = layout16m(a.D, a.Di, md);
+    const LayoutB16M Lb = layoutb16m(md);
+    const Lds16M S = lds16m<T>(a.D, a.Di, true);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const region = lds + S.region;
+    double* const wsum = reinterpret_cast<double*>(lds + S.wsum);   // [wave][6]
+    const float asl = a.a_std_log[0];
+    stage_small16m<T>(lds, S, a.img_fwd, L, tid);
+    if (tid < k16Waves * 6) wsum[tid] = 0.0;
+    __syncthreads();
+    const int ngroups = (a.B + k16Group - 1) / k16Group;
+    const float invB = 1.0f / (float)a.B;
+    float* const sl = a.slab + (size_t)blockIdx.x * a.slab_stride;   // this workgroup's partial gradients
+    // slab positions (slab_layout16m): 0/1 other.0 W,b  2/3 other.2  4/5 integrator.0  6/7 integrator.2  8/9 net.0  10/11 net.2  12 scalars
+
+#pragma unroll 1
+    for (int group = blockIdx.x; group < ngroups; group += gridDim.x) {
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));   // keep per-lane offsets inside the loop
+        const int s = lane & 15, g = lane >> 4;
+        const bool accum = group != (int)blockIdx.x;
+        const int pos = group * k16Group + wave * 16 + s;
+        const bool valid = pos < a.B;
+        const int64_t* const idx = a.indices + (a.index_row ? (size_t)a.index_row[0] * a.B : 0);
+        const long long row = idx[valid ? pos : a.B - 1];
+        float xo[8], xi[8];
+        gather_x16m(a.state + (size_t)row * a.D, a.D, a.Di, g, xo, xi);
+        const float in_action = a.action[row], in_logprob = a.logprob[row], in_adv = a.adv[row];
+
+        // ------------------------------------------------------------------------------------------ forward
+        f32x4 cat[T], n0[T];
+        {
+            f32x4 t1[T];
+            first16<T, ACT>(lds + S.w0o, lds + S.b0o, L.KS0o, lane, xo, t1);
+            PIME_NO_HOIST();
+            layer16r<T, H, ACT, true>(a.img_fwd + L.w1o, lds + S.b1o, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[0]));
+            PIME_NO_HOIST();
+            first16<T, ACT>(lds + S.w0i, lds + S.b0i, L.KS0i, lane, xi, t1);
+            PIME_NO_HOIST();
+            layer16r<T, H, ACT, true>(a.img_fwd + L.w1i, lds + S.b1i, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[H]));
+        }
+        PIME_NO_HOIST();
+        layer16<T, ACT, true>(a.img_fwd + L.wn, lds + S.bn, region, lane, tid, cat, n0);
+        const float y = head16<T>(lds + S.w3, lds[S.b3], lane, n0);
+
+        // ------------------------------------------------------------------------------------------ loss gradient (agent.py:637-645)
+        float dout = 0.f, s0 = 0.f, s1 = 0.f, gstd = 0.f;
+        if (valid) {
+            const float inv_sigma = __expf(-asl);
+            const float z = (y - in_action) * inv_sigma;
+            const float logp = -(asl + kLogSqrt2Pi + 0.5f * z * z);           // compute_logprob
+            const float ratio = __expf(logp - in_logprob);
+            const float lo = 1.f - a.ratio_clip, hi = 1.f + a.ratio_clip;
+            const float clamped = fminf(fmaxf(ratio, lo), hi);
+            const float u = in_adv * ratio, c = in_adv * clamped;
+            const float w_u = u < c ? 1.f : (u == c ? 0.5f : 0.f);            // torch.min backward (ties split)
+            const float w_c = c < u ? 1.f : (u == c ? 0.5f : 0.f);
+            const bool in_range = ratio >= lo && ratio <= hi;
+            const float g_sur = w_u * u + (in_range ? w_c * u : 0.f);
+            const float p = __expf(logp);
+            const float g_logp = (-g_sur + a.lambda_entropy * p * (logp + 1.f)) * invB;
+            dout = g_logp * (-z * inv_sigma);
+            if (g == 0) { gstd = g_logp * (z * z - 1.f); s0 = -fminf(u, c); s1 = p * logp; }
+        }
+        {
+            float ghb = g == 0 ? dout : 0.f;   // head bias gradient
+            s0 = wave_total_dpp(s0); ghb = wave_total_dpp(ghb);   // totals valid in lane 63
+            s1 = wave_total_dpp(s1); gstd = wave_total_dpp(gstd);
+            if (lane == 63) {
+                double* w = wsum + wave * 6;
+                w[0] += s0; w[1] += s1; w[2] += gstd; w[3] += ghb;
+            }
+        }
+        // head weight gradient (DPP row sums, per wave into the free region, then over the waves); dZn0 replaces n0
+        {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(lds + S.w3 + t * 16 + 4 * g);
+                f32x4 hs;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    hs[r] = row_sum16(dout * n0[t][r]);
+                    n0[t][r] = w[r] * dout * act_grad_from_output<ACT>(n0[t][r]);
+                }
+                if (s == 15) *reinterpret_cast<f32x4*>(region + wave * md + t * 16 + 4 * g) = hs;
+            }
+            PIME16_BARRIER();
+            if (tid < md) {
+                float t8 = region[tid];
+                for (int w = 1; w < k16Waves; ++w) t8 += region[w * md + tid];
+                float* qd = &sl[a.poff[10] + tid];
+                *qd = accum ? *qd + t8 : t8;
+            }
+        }
+        // ------------------------------------------------------------------------------------------ backward
+        PIME_NO_HOIST();
+        if constexpr (T == 4 * k16Waves)
+            dw16_sliced<T>(region, lane, wave, n0, cat, sl + a.poff[8], sl + a.poff[9], accum);                                      // net.0
+        else
+            dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{n0, g}, PubAcc16<T>{cat, g}, sl + a.poff[8], sl + a.poff[9], accum);
+        f32x4 dcat[T];
+        PIME16_BARRIER();
+        layer16<T, 2, false>(a.img_bwd + Lb.wnt, nullptr, region, lane, tid, n0, dcat);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dcat[t][r] *= act_grad_from_output<ACT>(cat[t][r]);                                          // [dZo2 | dZi2]
+        // the two towers, one after the other: cat / n0 are dead, their registers take the recomputed first-layer activation and dZ1
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            f32x4(&t1)[T] = cat;     // tower's first-layer activation (recomputed)
+            f32x4(&d1)[T] = n0;      // dZ of the tower's first layer
+            const f32x4(&dz2)[H] = *reinterpret_cast<const f32x4(*)[H]>(&dcat[br * H]);
+            PIME_NO_HOIST();
+            if (br == 0) first16<T, ACT>(lds + S.w0o, lds + S.b0o, L.KS0o, lane, xo, t1);
+            else first16<T, ACT>(lds + S.w0i, lds + S.b0i, L.KS0i, lane, xi, t1);
+            dw16<H, T, RT>(region, lane, wave, PubAcc16<H>{dz2, g}, PubAcc16<T>{t1, g}, sl + a.poff[br ? 6 : 2], sl + a.poff[br ? 7 : 3], accum);
+            PIME16_BARRIER();
+            layer16r<H, T, 2, false>(a.img_bwd + (br ? Lb.w1it : Lb.w1ot), nullptr, region, lane, tid, dz2, d1);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d1[t][r] *= act_grad_from_output<ACT>(t1[t][r]);                                         // dZ1
+            PIME_NO_HOIST();
+            if (br == 0) dw16<T, 1, RT>(region, lane, wave, PubAcc16<T>{d1, g}, PubX16{xo, g, L.KS0o, 16}, sl + a.poff[0], sl + a.poff[1], accum);
+            else dw16<T, 1, RT>(region, lane, wave, PubAcc16<T>{d1, g}, PubX16{xi, g, L.KS0i, 16}, sl + a.poff[4], sl + a.poff[5], accum);
+            PIME16_BARRIER();   // the next chain layer / the next group writes the region
+        }
+    }
+
+    // ---- workgroup totals of the scalar sums, in a fixed order (only the logged loss sums use atomics)
+    __syncthreads();
+    if (tid == 0) {
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < k16Waves; ++w)
+            for (int k = 0; k < 6; ++k) t[k] += wsum[w * 6 + k];
+        sl[a.poff[11]] = (float)t[3];                 // head bias
+        atomicAdd(&a.loss_sums[0], (float)t[0]);
+        atomicAdd(&a.loss_sums[1], (float)t[1]);
+        sl[a.poff[12]] = (float)t[2];                 // d loss / d a_std_log
+    }
+}
+
 // ==================================================================================================== host side
 bool fused_fits(int kind, int D, int Di, int md);
 
@@ -830,7 +1146,7 @@ static bool forced16() {
     return forced;
 }
 bool family16(int kind, int md) {
-    if (kind == MLP_MODULAR_ACTOR) return false;
+    if (kind == MLP_MODULAR_ACTOR) return md == 256;   // the modular actor here only at the width the LDS-resident kernels cannot hold
     if (md == 256) return true;
     return forced16() && (md == 64 || md == 128);
 }
@@ -840,11 +1156,14 @@ bool family16_grad(int kind, int md, int D, int Di) {
     return !fused_fits(kind, D, Di, md);
 }
 
-int64_t packed16_floats(int D, int md) { return layout16(D, md).total; }
-int64_t bwd16_floats(int md) { return layoutb16(md).total; }
+int64_t packed16_floats(int kind, int D, int Di, int md) {
+    return kind == MLP_MODULAR_ACTOR ? layout16m(D, Di, md).total : layout16(D, md).total;
+}
+int64_t bwd16_floats(int kind, int md) { return kind == MLP_MODULAR_ACTOR ? layoutb16m(md).total : layoutb16(md).total; }
 
 int launch_pack16(const PackArgs& a, float* fwd, float* bwd, hipStream_t s) {
-    hipLaunchKernelGGL(pack16_kernel, dim3(128), dim3(256), 0, s, a, fwd, bwd);
+    if (a.kind == MLP_MODULAR_ACTOR) hipLaunchKernelGGL(pack16m_kernel, dim3(128), dim3(256), 0, s, a, fwd, bwd);
+    else hipLaunchKernelGGL(pack16_kernel, dim3(128), dim3(256), 0, s, a, fwd, bwd);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
@@ -856,11 +1175,12 @@ static int wgs_per_cu(size_t lds_bytes) {
     return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
 }
 
-int grid16(int B, int md, int D) {
+int grid16(int kind, int B, int md, int D, int Di) {
     const int ngroups = (B + k16Group - 1) / k16Group;
     size_t lds = 0;
     int per = 1;
-    if (md == 64) { lds = sizeof(float) * lds16<4>(D, true).total; per = wgs_per_cu<4>(lds); }
+    if (kind == MLP_MODULAR_ACTOR) { lds = sizeof(float) * lds16m<16>(D, Di, true).total; per = wgs_per_cu<16>(lds); }
+    else if (md == 64) { lds = sizeof(float) * lds16<4>(D, true).total; per = wgs_per_cu<4>(lds); }
     else if (md == 128) { lds = sizeof(float) * lds16<8>(D, true).total; per = wgs_per_cu<8>(lds); }
     else { lds = sizeof(float) * lds16<16>(D, true).total; per = wgs_per_cu<16>(lds); }
     const int cap = 256 * per;
@@ -880,8 +1200,20 @@ static int launch_fwd16(const float* x, int M, int D, const float* img, float* o
     return PIME_OK;
 }
 
-int launch_forward16(int kind, const float* x, int M, int D, int md, const float* img, float* out, hipStream_t s) {
+int launch_forward16(int kind, const float* x, int M, int D, int Di, int md, const float* img, float* out, hipStream_t s) {
     const int T = md / 16;
+    if (kind == MLP_MODULAR_ACTOR) {
+        PIME_REQUIRE(T == 16, "the 16-tile modular actor serves width 256, got %d", md);
+        const size_t lds_bytes = sizeof(float) * (size_t)lds16m<16>(D, Di, false).total;
+        static LdsLimit lds_limit;
+        PIME_RAISE_LDS(lds_limit, (mlp16m_forward_kernel<16>), 160 * 1024);
+        const int ngroups = (M + k16Group - 1) / k16Group;
+        const int cap = 256 * wgs_per_cu<16>(lds_bytes);
+        hipLaunchKernelGGL((mlp16m_forward_kernel<16>), dim3(ngroups < cap ? ngroups : cap), dim3(k16Threads), lds_bytes, s, x, M, D, Di,
+                           img, out);
+        PIME_HIP_TRY(hipGetLastError());
+        return PIME_OK;
+    }
 #define PIME_F16(TT) \
     if (T == TT) return kind == MLP_CRITIC ? launch_fwd16<TT, 0>(x, M, D, img, out, s) : launch_fwd16<TT, 1>(x, M, D, img, out, s);
     PIME_F16(4) PIME_F16(8) PIME_F16(16)
@@ -896,13 +1228,23 @@ static int launch_grad16(const PpoArgs& a, hipStream_t s) {
     PIME_REQUIRE(lds_bytes <= 160 * 1024, "16-tile PPO kernel needs %zu B of LDS", lds_bytes);
     static LdsLimit lds_limit;  // per instantiation
     PIME_RAISE_LDS(lds_limit, (ppo16_kernel<T, ACTOR>), 160 * 1024);
-    hipLaunchKernelGGL((ppo16_kernel<T, ACTOR>), dim3(grid16(a.B, T * 16, a.D)), dim3(k16Threads), lds_bytes, s, a);
+    hipLaunchKernelGGL((ppo16_kernel<T, ACTOR>), dim3(grid16(ACTOR ? MLP_PLAIN_ACTOR : MLP_CRITIC, a.B, T * 16, a.D, 0)), dim3(k16Threads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 
 int launch_ppo16(int kind, int md, const PpoArgs& a, hipStream_t s) {
     const int T = md / 16;
+    if (kind == MLP_MODULAR_ACTOR) {
+        PIME_REQUIRE(T == 16, "the 16-tile modular actor serves width 256, got %d", md);
+        const size_t lds_bytes = sizeof(float) * (size_t)lds16m<16>(a.D, a.Di, true).total;
+        PIME_REQUIRE(lds_bytes <= 160 * 1024, "16-tile modular PPO kernel needs %zu B of LDS", lds_bytes);
+        static LdsLimit lds_limit;
+        PIME_RAISE_LDS(lds_limit, (ppo16m_kernel<16>), 160 * 1024);
+        hipLaunchKernelGGL((ppo16m_kernel<16>), dim3(grid16(kind, a.B, md, a.D, a.Di)), dim3(k16Threads), lds_bytes, s, a);
+        PIME_HIP_TRY(hipGetLastError());
+        return PIME_OK;
+    }
 #define PIME_G16(TT) \
     if (T == TT) return kind == MLP_CRITIC ? launch_grad16<TT, false>(a, s) : launch_grad16<TT, true>(a, s);
     PIME_G16(4) PIME_G16(8) PIME_G16(16)

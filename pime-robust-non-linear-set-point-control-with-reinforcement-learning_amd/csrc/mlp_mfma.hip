@@ -81,12 +81,12 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const float* _
 
 // ---- host launchers ---------------------------------------------------------------------------------------------
 bool family16(int kind, int md);
-int64_t packed16_floats(int D, int md);
+int64_t packed16_floats(int kind, int D, int Di, int md);
 int launch_pack16(const PackArgs& a, float* fwd, float* bwd, hipStream_t s);
-int launch_forward16(int kind, const float* x, int M, int D, int md, const float* img, float* out, hipStream_t s);
+int launch_forward16(int kind, const float* x, int M, int D, int Di, int md, const float* img, float* out, hipStream_t s);
 
 int64_t mlp_packed_floats(int kind, int D, int Di, int md) {
-    return family16(kind, md) ? packed16_floats(D, md) : (int64_t)mlp_layout(kind, D, Di, md).total;
+    return family16(kind, md) ? packed16_floats(kind, D, Di, md) : (int64_t)mlp_layout(kind, D, Di, md).total;
 }
 
 int mlp_check(int kind, int D, int Di, int md) {
@@ -94,7 +94,8 @@ int mlp_check(int kind, int D, int Di, int md) {
     PIME_REQUIRE(D >= 1 && D <= kMaxObsDim, "state_dim %d out of range [1,%d]", D, kMaxObsDim);
     if (kind == MLP_MODULAR_ACTOR) {
         PIME_REQUIRE(Di >= 1 && Di < D, "integrator_dim %d must be in [1, state_dim)", Di);
-        PIME_REQUIRE(md == 64 || md == 128, "fused modular-actor forward supports width 64 or 128, got %d", md);
+        // 64 / 128: LDS-resident (this file, ppo_fused.hip); 256: the streamed 16x16x4 family (mlp16.hip: mlp16m_forward_kernel, ppo16m_kernel)
+        PIME_REQUIRE(md == 64 || md == 128 || md == 256, "fused modular-actor kernels support width 64, 128 or 256, got %d", md);
     } else {
         // 64 / 128: the LDS-resident 32x32x2 family (this file, ppo_fused.hip); 256: the streamed 16x16x4 family (mlp16.hip)
         PIME_REQUIRE(md == 64 || md == 128 || md == 256, "fused MLP kernels support width 64, 128 or 256, got %d", md);
@@ -140,7 +141,7 @@ int launch_mlp_forward(int kind, const float* x, int M, int D, int Di, int md, c
                        hipStream_t s) {
     if (int rc = mlp_check(kind, D, Di, md)) return rc;
     PIME_REQUIRE(M >= 1, "M = %d rows", M);
-    if (family16(kind, md)) return launch_forward16(kind, x, M, D, md, packed, out, s);
+    if (family16(kind, md)) return launch_forward16(kind, x, M, D, Di, md, packed, out, s);
     const int T = md / 32;
 #define PIME_FWD(TT, KK) \
     if (T == TT && kind == KK) return launch_fwd<TT, KK>(x, M, D, Di, packed, out, s);

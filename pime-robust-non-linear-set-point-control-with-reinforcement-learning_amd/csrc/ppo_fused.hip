@@ -1368,7 +1368,16 @@ int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, 
     };
     auto add_net = [&](const PpoArgs& a, int kind, int md, bool f16, float* const* grads, int net, int* scalar_off) {
         const int np = kind == MLP_MODULAR_ACTOR ? 12 : 8;
-        if (f16) {   // block-major weight gradients (slab_layout16)
+        if (f16 && kind == MLP_MODULAR_ACTOR) {   // slab_layout16m: five block-major matrices
+            slab_layout16m(md, poff, psize);
+            const int T = md / 16, Do = a.D - a.Di;
+            for (int i = 0; i < np; ++i) {
+                if (i == 0) add(grads[i], poff[i], psize[i], net, 1, Do, Do);
+                else if (i == 4) add(grads[i], poff[i], psize[i], net, 1, a.Di, a.Di);
+                else if (i == 2 || i == 6 || i == 8) add(grads[i], poff[i], psize[i], net, T, md, md);
+                else add(grads[i], poff[i], psize[i], net);
+            }
+        } else if (f16) {   // block-major weight gradients (slab_layout16)
             slab_layout16(a.D, md, poff, psize);
             const int tb0 = ((a.D + 3) & ~3) <= 16 ? 1 : 2, T = md / 16;
             for (int i = 0; i < np; ++i) {

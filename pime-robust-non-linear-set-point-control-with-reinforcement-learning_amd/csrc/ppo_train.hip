@@ -515,29 +515,31 @@ int mlp_check(int kind, int D, int Di, int md);
 
 bool family16(int kind, int md);
 bool family16_grad(int kind, int md, int D, int Di);
-int64_t packed16_floats(int D, int md);
-int64_t bwd16_floats(int md);
-int grid16(int B, int md, int D);
+int64_t packed16_floats(int kind, int D, int Di, int md);
+int64_t bwd16_floats(int kind, int md);
+int grid16(int kind, int B, int md, int D, int Di);
 int launch_pack16(const PackArgs& a, float* fwd, float* bwd, hipStream_t s);
 
 int64_t ppo_bwd_image_floats(int kind, int D, int Di, int md) {
-    return family16_grad(kind, md, D, Di) ? bwd16_floats(md) : (int64_t)bwd_layout(kind, D, Di, md).total;
+    return family16_grad(kind, md, D, Di) ? bwd16_floats(kind, md) : (int64_t)bwd_layout(kind, D, Di, md).total;
 }
 int64_t ppo_fwd_image_floats(int kind, int D, int Di, int md) {
-    return family16_grad(kind, md, D, Di) ? packed16_floats(D, md) : (int64_t)mlp_layout(kind, D, Di, md).total;
+    return family16_grad(kind, md, D, Di) ? packed16_floats(kind, D, Di, md) : (int64_t)mlp_layout(kind, D, Di, md).total;
 }
 
 int64_t fused_workspace_floats(int kind, int B, int D, int Di, int md);
 
 int64_t ppo_workspace_floats(int kind, int B, int md) {
     int64_t f16 = 0;
+    int poff[13], psize[12];
     if (kind != MLP_MODULAR_ACTOR) {   // the 16-tile family: gradient slabs only (no activation stash), bound over the state widths
-        int poff[13], psize[12];
         const int64_t stride = slab_layout16(kMaxObsDim, md, poff, psize);
-        int g = grid16(B, md, 1);
-        const int g2 = grid16(B, md, kMaxObsDim);
+        int g = grid16(kind, B, md, 1, 0);
+        const int g2 = grid16(kind, B, md, kMaxObsDim, 0);
         g = g > g2 ? g : g2;
         f16 = (int64_t)g * stride;
+    } else if (md == 256) {
+        f16 = (int64_t)grid16(kind, B, md, 4, 1) * slab_layout16m(md, poff, psize);   // (the grid does not depend on the state width)
     }
     if (md == 256) return f16;
     const int64_t ntiles = ((B + 31) / 32 + 7) / 8 * 8;

@@ -88,6 +88,17 @@ inline int slab_layout16(int D, int md, int* poff, int* psize) {
     return o + 4;
 }
 
+// The modular actor in the 16-tile family (mlp16.hip: ppo16m_kernel), parameter order of pime_ppo_net (other_net.0, other_net.2,
+// integrator_net.0, integrator_net.2, net.0, net.2; W, b each): the five weight matrices block-major in accumulator order (first
+// layers padded to one 16-column tile), biases and the head in tensor order.
+inline int slab_layout16m(int md, int* poff, int* psize) {
+    const int s[12] = {md * 16, md, (md / 2) * md, md / 2, md * 16, md, (md / 2) * md, md / 2, md * md, md, md, 1};
+    int o = 0;
+    for (int i = 0; i < 12; ++i) { psize[i] = s[i]; poff[i] = o; o += (s[i] + 3) & ~3; }
+    poff[12] = o;
+    return o + 4;
+}
+
 constexpr int kMaxDwJobs = 16;
 
 struct DwArgs {

@@ -26,16 +26,18 @@ def check_forward(kind, md, D, M, seed=0):
     import oracle
     from pime_amd import ops
     from pime_amd.elegantrl.net import CriticAdv
-    from pime_amd.elegantrl.net_residual import ActorResidualPPO
+    from pime_amd.elegantrl.net_residual import ActorResidualIntegratorModularPPO, ActorResidualPPO
     torch.manual_seed(seed)
-    net = (CriticAdv(D, md) if kind == "critic" else ActorResidualPPO(md, D, 1)).to(DEV)
+    net = (CriticAdv(D, md) if kind == "critic" else ActorResidualIntegratorModularPPO(md, D, 1, 1) if kind == "modular"
+           else ActorResidualPPO(md, D, 1)).to(DEV)
     with torch.no_grad():
         net.net[-1].weight.mul_(5.0)
     x = (torch.randn(M, D) * torch.tensor(([3., 3., 8., 1.] * 8)[:D]) + torch.tensor(([7., 7., 0., 0.] * 8)[:D])).to(DEV)
     pk = ops.PackedMLP.from_module(net)
     got = pk(x).cpu().numpy()
     sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
-    want = (oracle.critic_forward if kind == "critic" else oracle.plain_actor_mean)(x.cpu().numpy(), sd)[:, 0]
+    want = (oracle.critic_forward if kind == "critic" else oracle.modular_actor_mean if kind == "modular"
+            else oracle.plain_actor_mean)(x.cpu().numpy(), sd)[:, 0]
     np.testing.assert_allclose(got, want, rtol=3e-5, atol=3e-5 * max(1.0, float(np.abs(want).max())))
     with torch.no_grad():   # and against torch fp32 on the device
         ref = (net(x)[:, 0] if kind == "critic" else net.mean(x)[:, 0]).cpu().numpy()
@@ -91,6 +93,56 @@ def test_gradients_width_256_match_autograd(D, B):
 
 def test_plain_ppo_actor_width_256():
     check_grads("ppo", 256, 3, 1024)
+
+
+# ---- the modular actor at width 256 (round 3: mlp16m_forward_kernel / ppo16m_kernel; run_watertank_changing.sh:11-18) -------------
+@pytest.mark.parametrize("D,M", [(4, 5000), (3, 64), (4, 70001), (3, 1)])
+def test_modular_forward_width_256(D, M):
+    check_forward("modular", 256, D, M)
+
+
+@pytest.mark.parametrize("D,B", [(4, 4096), (3, 1000), (4, 777), (3, 40000)])
+def test_modular_gradients_width_256_match_autograd(D, B):
+    """ActorResidualIntegratorModularPPO(256) + CriticAdv(256) against PyTorch fp32 autograd of the reference loss, 3e-4 of each
+    tensor's largest entry; bitwise repeatable; batch sizes that are / are not multiples of the 64-sample group and that give a
+    workgroup more than one group (slab accumulation: 40 000 samples = 625 groups on 256 workgroups)."""
+    check_grads("modular", 256, D, B)
+
+
+def test_width_256_modular_agent_takes_the_hip_path():
+    """AgentResidualIntegratorModularPPO at net_dim 256 on the Integrator water tank (the reference script's second block): packed
+    forwards + fused gradients + the image map (no torch fallback, no warning), whole explore + update_net; three updates of
+    the Adam-fused step keep the packed images equal to a re-pack."""
+    import warnings
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from pime_amd.elegantrl.run import make_buffer
+    env = gym_control.make_vec(gym_control.WT_INTEGRATOR, 512, device=DEV, seed=1, reward_type="distance", max_step=20)
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        ag = AgentResidualIntegratorModularPPO(device=DEV)
+        ag.init(256, env.state_dim, 1, env.n_integrator)
+        ag.init_residual({"init_K": env.K.reshape(-1, 1)})
+        with torch.no_grad():
+            ag.act.net[-1].weight.normal_(0, 0.05)
+        ag.weights_changed()
+        assert ag._packed_for("act") is not None and ag._packed_for("cri") is not None
+        buf = make_buffer(ag, env, 512 * 20)
+        for _ in range(3):
+            steps = ag.explore_env(env, buf, 512 * 20, 1.0, 0.99)
+            oa, oc = ag.update_net(buf, steps, 2048, 2)
+    fused = ag._packed.get("fused")
+    assert fused, "update_net fell back to torch autograd for the width-256 modular actor"
+    assert fused.images_follow_step, fused.image_map_error
+    assert np.isfinite(oa) and np.isfinite(oc)
+    torch.cuda.synchronize()
+    got = [(n["img_fwd"].clone(), n["img_bwd"].clone()) for n in fused.nets]
+    fused.repack()
+    torch.cuda.synchronize()
+    for (gf, gb), n in zip(got, fused.nets):
+        assert torch.equal(gf, n["img_fwd"]) and torch.equal(gb, n["img_bwd"]), "packed images drifted from the parameters"
+    env.close()
 
 
 @pytest.mark.parametrize("md,D,B", [(128, 30, 2048), (64, 30, 1000), (128, 12, 4096)])
