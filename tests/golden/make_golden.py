@@ -451,6 +451,16 @@ def golden_ppo_update_wide():
     save("ppo_update_wide.npz", **out)
 
 
+def golden_ppo_update_mod256():
+    """The second block of the reference's water-tank script (run_watertank_changing.sh:11-18): ResidualIntegratorModularPPO,
+    net_dim 256, on the Integrator observation -- the shape the HIP path serves through the 16-tile family's modular kernels
+    (csrc/mlp16.hip: mlp16m_forward_kernel, ppo16m_kernel).  Same recording as `ppo_update_wide.npz`."""
+    from elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    out = {}
+    _ppo_cases(out, [("wtmod256", AgentResidualIntegratorModularPPO, WT_ID, 256, 400, 128, 2, 0.97)], with_eval=False)
+    save("ppo_update_mod256.npz", **out)
+
+
 def golden_ppo_update_multi():
     """update_net at MULTI-WORKGROUP batch sizes, with the reference's own gradients (VERDICT r02 task 3).
 
@@ -653,7 +663,8 @@ def main():
                 ph_stepresponse=golden_ph_stepresponse, wt_rollouts=golden_wt_rollouts,
                 wt_stepresponse=golden_wt_stepresponse, wt_stacking=golden_wt_stacking,
                 gae=golden_gae, nets=golden_nets, ppo_update=golden_ppo_update_and_explore,
-                ppo_update_wide=golden_ppo_update_wide, ppo_update_multi=golden_ppo_update_multi,
+                ppo_update_wide=golden_ppo_update_wide, ppo_update_mod256=golden_ppo_update_mod256,
+                ppo_update_multi=golden_ppo_update_multi,
                 td3_update=golden_td3_update)
     for name, fn in jobs.items():
         if only and name not in only:

@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 CASES = {
+    "wtmod256": dict(agent="AgentResidualIntegratorModularPPO", integrator=1, K=[0., 0.4, -0.4, 0.], file="ppo_update_mod256.npz"),
     "ph128": dict(agent="AgentResidualIntegratorModularPPO", integrator=1, K=[-0.02, 0.02, 0.035]),
     "wt64": dict(agent="AgentResidualIntegratorModularPPO", integrator=1, K=[0., 0.4, -0.4, 0.]),
     "wts10_256": dict(agent="AgentResidualPPO", integrator=None, K=[0.] * 27 + [0., 0.4, -0.4]),
@@ -36,7 +37,7 @@ def _sd(g, prefix):
 def _run(tag, mode):
     from pime_amd.elegantrl import agent_residual
     from pime_amd.elegantrl.replay import ReplayBuffer
-    g = load_golden("ppo_update_wide.npz")
+    g = load_golden(CASES[tag].get("file", "ppo_update_wide.npz"))
     hyper = g[f"{tag}:hyper"]
     net_dim, target_step, batch, repeat, lam = int(hyper[0]), int(hyper[1]), int(hyper[2]), int(hyper[3]), float(hyper[4])
     c = CASES[tag]
@@ -68,7 +69,9 @@ def _run(tag, mode):
 
 
 @pytest.mark.parametrize("mode", ["two_graph", "one_graph"])
-@pytest.mark.parametrize("tag", ["ph128", "wt64", "wts10_256"])   # wts10_256: width 256 + 30-float stacked observation
+# wts10_256: width 256 + 30-float stacked observation (run_watertank_changing.sh:20-27); wtmod256: the modular actor at width 256
+# (:11-18; tests/golden/ppo_update_mod256.npz) through the 16-tile family's modular kernels
+@pytest.mark.parametrize("tag", ["ph128", "wt64", "wts10_256", "wtmod256"])
 def test_hip_update_net_matches_reference_weights(tag, mode):
     g, ag, fused, obj_a, obj_c = _run(tag, mode)
     assert fused, f"{tag}: update_net did not take the fused HIP gradient path"
