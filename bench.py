@@ -243,24 +243,29 @@ def bench_water_tank(args, device, json_fd):
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
-def bench_water_tank_256(args, device, json_fd):
+def bench_water_tank_256(args, device, json_fd, modular=False):
     """The reference's live water-tank script (/root/reference/run_watertank_changing.sh:20-27): ResidualPPO, net_dim 256, the
     30-float Stacking10 observation, reward 'distance'; 4096 lanes x 200-step episodes, batch 65536, repeat 8 as the other
     workloads.  The update runs on the streamed 16-tile kernels (csrc/mlp16.hip), the rollout step-wise (policy forward +
     fused residual env step per lock-step: the one-launch rollout serves widths 64 / 128).  `torch_update` is the same step with
     update_net on PyTorch-ROCm autograd + rocBLAS (use_fused_update = False): what width 256 fell back to in round 1."""
     from pime_amd import gym_control
-    from pime_amd.elegantrl.agent_residual import AgentResidualPPO
+    from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO, AgentResidualPPO
     from pime_amd.elegantrl.run import make_buffer
     lanes, T = 4096, 200
 
     def run(fused_update, steps, warmup):
-        env = gym_control.make_vec(gym_control.WT_STACKING.format(10), lanes, device=device, state_mode="mixed", seed=0,
-                                   reward_type="distance")
+        # modular: the script's second block (run_watertank_changing.sh:11-18): ResidualIntegratorModularPPO on the Integrator
+        # observation, served by the 16-tile family's modular kernels (mlp16m_forward_kernel, ppo16m_kernel) since round 3
+        env = gym_control.make_vec(gym_control.WT_INTEGRATOR if modular else gym_control.WT_STACKING.format(10), lanes, device=device,
+                                   state_mode="mixed", seed=0, reward_type="distance")
         torch.manual_seed(0)
-        agent = AgentResidualPPO(device=device)
+        agent = (AgentResidualIntegratorModularPPO if modular else AgentResidualPPO)(device=device)
         agent.use_fused_update = fused_update
-        agent.init(256, env.state_dim, 1)
+        if modular:
+            agent.init(256, env.state_dim, 1, env.n_integrator)
+        else:
+            agent.init(256, env.state_dim, 1)
         agent.init_residual({"init_K": env.K.reshape(-1, 1)})
         agent.init_actor_zero()
         agent.fix_K()
@@ -283,11 +288,15 @@ def bench_water_tank_256(args, device, json_fd):
     v, ms, hip = run(True, args.steps, args.warmup)
     assert hip, "width 256 did not take the HIP gradient path"
     v_t, ms_t, _ = run(False, max(1, args.steps // 2), 1)
-    out = {"metric": "env-steps/sec (rollout+update), water-tank Stacking10 env, 4096 parallel envs, net_dim 256", "value": v,
+    name = "Integrator env, ResidualIntegratorModularPPO" if modular else "Stacking10 env"
+    out = {"metric": f"env-steps/sec (rollout+update), water-tank {name}, 4096 parallel envs, net_dim 256", "value": v,
            "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "water tank Stacking10-v2 (30-float observation, reward 'distance'), 4096 lanes x 200-step "
-                                  "episodes, ResidualPPO net_dim 256 (run_watertank_changing.sh), batch 65536, repeat 8"},
+           "config": {"workload": ("water tank Integrator-v2 (reward 'distance'), 4096 lanes x 200-step episodes, "
+                                   "ResidualIntegratorModularPPO net_dim 256 (run_watertank_changing.sh:11-18), batch 65536, repeat 8")
+                      if modular else
+                                  ("water tank Stacking10-v2 (30-float observation, reward 'distance'), 4096 lanes x 200-step "
+                                   "episodes, ResidualPPO net_dim 256 (run_watertank_changing.sh), batch 65536, repeat 8")},
            "torch_update": {"value": v_t, "unit": "env-steps/s", "ms_per_step": ms_t,
                             "what": "same step, update_net on PyTorch-ROCm autograd + rocBLAS (round 1's width-256 path)"}}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -533,7 +542,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ph", choices=["ph", "wt", "wt_td3", "wt256", "mixed16"],
+    ap.add_argument("--workload", default="ph", choices=["ph", "wt", "wt_td3", "wt256", "wtmod256", "mixed16"],
                     help="ph: the headline config (BASELINE config 3); wt: config 2, water tank, 4096 lanes x 200 steps "
                          "(reported for DESIGN.md; the headline metric is the ph line)")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
@@ -573,6 +582,8 @@ def main():
         return bench_water_tank(args, device, json_fd)
     if args.workload == "wt256":
         return bench_water_tank_256(args, device, json_fd)
+    if args.workload == "wtmod256":
+        return bench_water_tank_256(args, device, json_fd, modular=True)
     if args.workload == "wt_td3":
         return bench_water_tank_td3(args, device, json_fd)
     env, agent, buf = build_stack(device, rank, world, dp)
