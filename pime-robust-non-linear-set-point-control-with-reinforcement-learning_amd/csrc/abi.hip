@@ -700,6 +700,7 @@ int pime_rollout_supported(const pime_env* e, int32_t kind, int32_t md) {
         if (e->cfg.state_mode == PIME_STATE_MIXED16) return 0;   // binary16 rows: pH and the Integrator tank (config 5)
     }
     if (kind != PIME_MLP_PLAIN_ACTOR && kind != PIME_MLP_MODULAR_ACTOR) return 0;
+    if (md == 256) return e->cfg.state_mode == PIME_STATE_MIXED ? 1 : 0;   // the streamed 16-tile rollout (mlp16.hip); float32 rows only
     return (md == 64 || md == 128) && !family16(kind, md) ? 1 : 0;
 }
 

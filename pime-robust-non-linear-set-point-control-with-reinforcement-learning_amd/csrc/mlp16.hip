@@ -30,8 +30,10 @@
 //   dW1 = dZ2^T h1 [h1 recomputed], dH1 = W1^T dZ2, dZ1,  dW0 = dZ1^T x
 //   partial gradients -> this workgroup's slab (16-byte stores in accumulator order, slab_layout16), summed in slab order and
 //   un-permuted by ppo_grad_reduce_kernel: reproducible bit for bit.
+#include "env_device.hpp"
 #include "ppo_device.hpp"
 #include "ppo_train.hpp"
+#include "rollout.hpp"
 
 namespace pime {
 
@@ -1132,6 +1134,176 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16m_kernel(PpoA
         atomicAdd(&a.loss_sums[1], (float)t[1]);
         sl[a.poff[12]] = (float)t[2];                 // d loss / d a_std_log
     }
+}
+
+// ==================================================================================================== fused rollout, width 256
+// The one-launch-per-episode rollout (csrc/rollout.hip: policy forward + exploration noise + residual composition + env step +
+// in-kernel auto-reset + trajectory writes, replacing agent_residual.py:52-69) for the width the LDS-resident kernel cannot hold:
+// a workgroup = four waves = 64 env lanes (one 16-lane tile per wave, every lane's env arithmetic replicated over the four
+// feature groups g of the 16x16x4 layout), the weight images streamed through LDS once per env step by the chain layers above.
+// 4 096 lanes are 64 workgroups: a quarter of the chip, each a serial chain of ~2 300 MFMAs per step -- latency-bound like the
+// 32x32 rollout, but one launch per episode instead of 200 x [mlp16 forward + env step] launches and their gaps (round 2:
+// 18 ms of the 134 ms width-256 step).
+constexpr uint32_t STREAM_EXPLORE16 = 2;   // = rollout.hip's STREAM_EXPLORE
+
+template <int D>
+__device__ __forceinline__ float pick_col(const float (&obs)[D], int c0, int g) {   // obs[c0 + g], 0 beyond the row (c0 compile-time)
+    const float v0 = c0 + 0 < D ? obs[c0 + 0 < D ? c0 + 0 : 0] : 0.f, v1 = c0 + 1 < D ? obs[c0 + 1 < D ? c0 + 1 : 0] : 0.f;
+    const float v2 = c0 + 2 < D ? obs[c0 + 2 < D ? c0 + 2 : 0] : 0.f, v3 = c0 + 3 < D ? obs[c0 + 3 < D ? c0 + 3 : 0] : 0.f;
+    return g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
+}
+
+template <int T, int KIND, int ENV, int STACK>
+__global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int D = ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), Di = ENV == 2 ? 0 : 1, Do = D - Di, H = T / 2;
+    constexpr bool MODULAR = KIND == MLP_MODULAR_ACTOR;
+    static_assert(!MODULAR || ENV != 2, "the Stacking observation has no integrator column: plain actors only");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sl = lane & 15, g = lane >> 4;
+    const Layout16 L = layout16(D, T * 16);
+    const Lds16 S = lds16<T>(D, false);
+    const Layout16M Lm = layout16m(D, Di > 0 ? Di : 1, T * 16);
+    const Lds16M Sm = lds16m<T>(D, Di > 0 ? Di : 1, false);
+    if constexpr (MODULAR) stage_small16m<T>(lds, Sm, a.img, Lm, tid);
+    else stage_small16<T>(lds, S, a.img, L, tid);
+    __syncthreads();
+    float* const region = lds + (MODULAR ? Sm.region : S.region);
+    const int N = a.n;
+    const int m = blockIdx.x * k16Group + wave * 16 + sl;
+    const bool valid = m < N;
+    const int i = valid ? m : N - 1;   // idle lanes shadow the last env (compute, never store)
+    const bool writer = valid && g == 0;
+    const uint32_t gid = a.env_offset + (uint32_t)i;
+    const float sigma = __expf(a.a_std_log[0]);
+
+    PhLane<float> E{};
+    WtLane<float> W{};
+    if constexpr (ENV == 0) ph_lane_load<float>(a.p, a.st, i, E);
+    else wt_lane_load<float>(a.wp, a.wst, i, W);
+    float obs[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) obs[j] = a.state[(size_t)D * i + j];
+    for (int t = 0; t < a.n_steps; ++t) {
+        PIME_NO_HOIST();
+        float a_avg;
+        if constexpr (MODULAR) {
+            float xo[8], xi[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float vo = pick_col<D>(obs, 4 * ks, g);
+                xo[ks] = 4 * ks + g < Do ? vo : 0.f;
+                // the integrator tower's columns start at Do: column Do + 4 ks + g
+                float vi = 0.f;
+#pragma unroll
+                for (int c = 0; c < Di; ++c)
+                    if (c / 4 == ks) vi = (c & 3) == g ? obs[Do + c] : vi;
+                xi[ks] = vi;
+            }
+            f32x4 cat[T], n0[T];
+            {
+                f32x4 t1[T];
+                first16<T, 1>(lds + Sm.w0o, lds + Sm.b0o, Lm.KS0o, lane, xo, t1);
+                PIME_NO_HOIST();
+                layer16r<T, H, 1, true>(a.img + Lm.w1o, lds + Sm.b1o, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[0]));
+                PIME_NO_HOIST();
+                first16<T, 1>(lds + Sm.w0i, lds + Sm.b0i, Lm.KS0i, lane, xi, t1);
+                PIME_NO_HOIST();
+                layer16r<T, H, 1, true>(a.img + Lm.w1i, lds + Sm.b1i, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[H]));
+            }
+            PIME_NO_HOIST();
+            layer16<T, 1, true>(a.img + Lm.wn, lds + Sm.bn, region, lane, tid, cat, n0);
+            a_avg = head16<T>(lds + Sm.w3, lds[Sm.b3], lane, n0);
+        } else {
+            float xr[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) xr[ks] = pick_col<D>(obs, 4 * ks, g);
+            f32x4 h1[T], h2[T];
+            first16<T, 1>(lds + S.w0, lds + S.b0, L.KS0, lane, xr, h1);
+            PIME_NO_HOIST();
+            layer16<T, 1, true>(a.img + L.w1, lds + S.b1, region, lane, tid, h1, h2);
+            PIME_NO_HOIST();
+            layer16<T, 1, true>(a.img + L.w2, lds + S.b2, region, lane, tid, h2, h1);
+            a_avg = head16<T>(lds + S.w3, lds[S.b3], lane, h1);
+        }
+        // from here on: rollout.hip's step, one env lane per (wave, lane & 15)
+        double ua, ub;
+        philox_pair(a.noise_seed, gid, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE16, ua, ub);
+        const float eps = (float)(sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586476925286766559 * ub));
+        const float a_pre = a_avg + eps * sigma;                                   // net_residual.py:179
+        double dot = 0.0;                                                          // agent_residual.py:61
+#pragma unroll
+        for (int j = 0; j < D; ++j) dot += (double)obs[j] * a.K.k[j];
+        const double a_env = residual_tanh(a_pre) + dot;
+        float nxt[D], rew;
+        bool d;
+        if constexpr (ENV == 0) {
+            float o3[3];
+            d = ph_lane_step<float>(a.p, a.st.table, a_env, E, o3, rew);
+            if (d) ph_lane_reset<float>(a.p, a.st.table, gid, nullptr, E, o3);     // in-kernel auto-reset
+            nxt[0] = o3[0]; nxt[1] = o3[1]; nxt[2] = o3[2];
+        } else {
+            double z1n, z2n;
+            wt_lane_noise<float>(a.wp, gid, W, nullptr, z1n, z2n);
+            d = wt_lane_step<float>(a.wp, a_env, z1n, z2n, W, rew);
+            if (d) wt_lane_reset<float>(a.wp, gid, nullptr, W);
+            if constexpr (ENV == 1) {
+                nxt[0] = W.h1; nxt[1] = W.h2; nxt[2] = W.r; nxt[D - 1] = W.I;
+            } else {   // deque(maxlen=S).append (:1143-1144), or after a reset every frame = the first one (:1181-1183)
+#pragma unroll
+                for (int j = 0; j < D - 3; ++j) nxt[j] = d ? (j % 3 == 0 ? W.h1 : (j % 3 == 1 ? W.h2 : W.r)) : obs[j + 3];
+                nxt[D - 3] = W.h1; nxt[D - 2] = W.h2; nxt[D - 1] = W.r;
+            }
+        }
+        const size_t k = (size_t)t * N + i;
+        if (writer) {
+            a.action[k] = a_pre;
+            a.noise[k] = eps;
+            a.done[k] = (uint8_t)d;
+            a.reward[k] = rew;
+            float* sp = a.state + ((size_t)(t + 1) * N + i) * D;
+#pragma unroll
+            for (int j = 0; j < D; ++j) sp[j] = nxt[j];
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) obs[j] = nxt[j];
+    }
+    if (writer) {
+        if constexpr (ENV == 0) ph_lane_store<float>(a.p, a.st, i, E);
+        else wt_lane_store<float>(a.wp, a.wst, i, W);
+        if constexpr (ENV == 2) {   // the frame ring of the step-per-launch kernels: slot j = frame j, oldest at slot 0
+#pragma unroll
+            for (int j = 0; j < D; ++j) a.wst.frames[(size_t)j * N + i] = obs[j];
+            a.wst.head[i] = 0;
+        }
+    }
+}
+
+template <int KIND, int ENV, int STACK>
+static int launch_rollout16_t(const RolloutArgs& a, hipStream_t s) {
+    constexpr int T = 16, D = ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK);
+    const size_t lds_bytes = sizeof(float) * (size_t)(KIND == MLP_MODULAR_ACTOR ? lds16m<T>(D, 1, false).total : lds16<T>(D, false).total);
+    static LdsLimit lds_limit;  // per instantiation
+    PIME_RAISE_LDS(lds_limit, (rollout16_kernel<T, KIND, ENV, STACK>), 160 * 1024);
+    hipLaunchKernelGGL((rollout16_kernel<T, KIND, ENV, STACK>), dim3((a.n + k16Group - 1) / k16Group), dim3(k16Threads), lds_bytes, s, a);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+// width 256 (csrc/rollout.hip dispatches here); binary16 rows (PIME_STATE_MIXED16) are not served at this width
+int launch_rollout16(int kind, const RolloutArgs& a, hipStream_t s) {
+    PIME_REQUIRE(a.I16 == nullptr, "the width-256 fused rollout serves PIME_STATE_MIXED handles");
+    if (kind == MLP_MODULAR_ACTOR) {
+        if (a.env == 0) return launch_rollout16_t<MLP_MODULAR_ACTOR, 0, 0>(a, s);
+        if (a.env == 1) return launch_rollout16_t<MLP_MODULAR_ACTOR, 1, 0>(a, s);
+    } else if (kind == MLP_PLAIN_ACTOR) {
+        if (a.env == 0) return launch_rollout16_t<MLP_PLAIN_ACTOR, 0, 0>(a, s);
+        if (a.env == 1) return launch_rollout16_t<MLP_PLAIN_ACTOR, 1, 0>(a, s);
+        if (a.env == 2 && a.wp.num_stack == 1) return launch_rollout16_t<MLP_PLAIN_ACTOR, 2, 1>(a, s);
+        if (a.env == 2 && a.wp.num_stack == 4) return launch_rollout16_t<MLP_PLAIN_ACTOR, 2, 4>(a, s);
+        if (a.env == 2 && a.wp.num_stack == 10) return launch_rollout16_t<MLP_PLAIN_ACTOR, 2, 10>(a, s);
+    }
+    set_error("no width-256 fused rollout for env %d kind %d", a.env, kind);
+    return PIME_ERR_ARG;
 }
 
 // ==================================================================================================== host side

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
 }
 
 int mlp_check(int kind, int D, int Di, int md);
+int launch_rollout16(int kind, const RolloutArgs& a, hipStream_t s);   // width 256: the streamed 16-tile family (mlp16.hip)
 
 template <int T, int KIND, int ENV, int STACK>
 static int launch_rollout_t(const RolloutArgs& a, hipStream_t s) {
@@ -163,6 +164,7 @@ int launch_rollout(int kind, int md, const RolloutArgs& a, hipStream_t s) {
     const int D = a.env == 0 ? 3 : (a.env == 1 ? 4 : 3 * a.wp.num_stack);
     if (int rc = mlp_check(kind, D, kind == MLP_MODULAR_ACTOR ? 1 : 0, md)) return rc;
     PIME_REQUIRE(kind != MLP_CRITIC, "rollout needs an actor image");
+    if (md == 256) return launch_rollout16(kind, a, s);
     const int T = md / 32;
 #define PIME_RS(TT, SS) \
     if (T == TT && kind == MLP_PLAIN_ACTOR && a.env == 2 && a.wp.num_stack == SS) return launch_rollout_t<TT, MLP_PLAIN_ACTOR, 2, SS>(a, s);

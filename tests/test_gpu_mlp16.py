@@ -155,7 +155,7 @@ def test_wide_observation_gradients_are_deterministic(md, D, B):
 
 def test_width_256_agent_takes_the_hip_path():
     """AgentResidualPPO at net_dim 256 on the Stacking10 env: packed forwards + fused gradients (no silent torch fallback),
-    step-wise rollout (the fused rollout kernel serves widths 64 / 128: pime_rollout_supported says so)."""
+    and since round 3 the fused rollout (rollout16_kernel; tests/test_gpu_rollout_oracle.py replays it through the oracle)."""
     from pime_amd import gym_control
     from pime_amd.elegantrl.agent_residual import AgentResidualPPO
     from pime_amd.elegantrl.run import make_buffer
@@ -165,7 +165,7 @@ def test_width_256_agent_takes_the_hip_path():
     ag.init(256, env.state_dim, 1)
     ag.init_residual({"init_K": env.K.reshape(-1, 1)})
     assert ag._packed_for("act") is not None and ag._packed_for("cri") is not None
-    assert not ag._fused_rollout_ok(env)
+    assert ag._fused_rollout_ok(env)
     buf = make_buffer(ag, env, 512 * 20)
     steps = ag.explore_env(env, buf, 512 * 20, 1.0, 0.99)
     oa, oc = ag.update_net(buf, steps, 2048, 2)

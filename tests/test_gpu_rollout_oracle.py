@@ -34,6 +34,12 @@ pytestmark = pytest.mark.gpu
     ("WT_STACKING10", "ResidualPPO", 2048, 128),                    # run_watertank_changing.sh:20-27 observation (30 floats)
     ("WT_STACKING4", "ResidualPPO", 1024, 64),
     ("WT_STACKING1", "PPO", 1024, 128),
+    # width 256 (round 3): the streamed 16-tile rollout kernel (csrc/mlp16.hip: rollout16_kernel)
+    ("WT_STACKING10", "ResidualPPO", 2048, 256),                    # run_watertank_changing.sh:20-27 as it is run
+    ("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 1024, 256),   # run_watertank_changing.sh:11-18
+    ("PH_V35", "ResidualIntegratorModularPPO", 1000, 256),          # ragged lane count: 15 full 64-lane workgroups + 40 lanes
+    ("PH_V35", "ResidualPPO", 512, 256),
+    ("WT_STACKING4", "PPO", 256, 256),
 ])
 def test_fused_rollout_replays_through_oracle(env_name, algo, N, md):
     import oracle
