@@ -308,8 +308,9 @@ int pime_ppo_minibatch_step(const pime_ppo_net* actor, const pime_ppo_net* criti
  *   state  [dev] float32[n_steps+1, N, obs_dim]: slot 0 must hold the current observation on entry (pime_env_reset /
  *          pime_env_observe), slots 1..n_steps are written;  action (pre-tanh), noise, reward [dev] float32[n_steps, N];
  *          done [dev] uint8[n_steps, N];  priorK [host] float64[obs_dim]. */
-/* 1 if pime_rollout serves this env handle with this actor (PIME_STATE_MIXED, pH or water-tank Integrator observation,
- * width 64 / 128), else 0: the caller then steps the env launch by launch (pime_mlp_forward + pime_env_step_residual). */
+/* 1 if pime_rollout serves this env handle with this actor (PIME_STATE_MIXED / MIXED16, pH or water-tank Integrator / Stacking
+ * observation, width 64 / 128 with the actor image resident in LDS, width 256 with the images streamed -- float32 rows only),
+ * else 0: the caller then steps the env launch by launch (pime_mlp_forward + pime_env_step_residual). */
 int pime_rollout_supported(const pime_env* env, int32_t kind, int32_t md);
 int pime_rollout(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const float* a_std_log,
                  const double* priorK, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch, float* state,
