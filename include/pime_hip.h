@@ -218,9 +218,7 @@ int pime_mlp_forward(int32_t kind, const float* x, int32_t M, int32_t D, int32_t
  * pime_ppo_net describes one net: the same (kind, D, Di, md, params) as pime_mlp_pack; `grads` are the .grad tensors in
  * the same order and are ACCUMULATED into (zero them first); img_fwd = pime_mlp_pack image,
  * img_bwd = pime_ppo_pack_bwd image (both must be re-packed after the weights change); workspace =
- * pime_ppo_workspace_floats(kind, B, md) floats, ZEROED ONCE by the caller after allocation (its first 16 floats hold device-side
- * synchronisation words that the kernels leave consistent: the single launch that serves both nets of width 64 / 128 reduces the
- * workgroups' partial gradients in its own tail).  action_dim must be 1. */
+ * pime_ppo_workspace_floats(kind, B, md) floats.  action_dim must be 1. */
 typedef struct pime_ppo_net {
     int32_t kind, D, Di, md;
     const float* const* params;   /* [host] array of [dev] pointers, W,b pairs */

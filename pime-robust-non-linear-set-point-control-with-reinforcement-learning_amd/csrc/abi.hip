@@ -48,14 +48,11 @@ int launch_mlp_forward(int, const float*, int, int, int, int, const float*, floa
 // ppo_train.hip
 int64_t ppo_bwd_image_floats(int, int, int, int);
 int64_t ppo_workspace_floats(int, int, int);
-constexpr int kFusedWsHead = 16;   // floats reserved at the head of a fused net's workspace (sync words of the dual kernel's tail)
 inline int stash_tiles_of(int kind, int md) { return (kind == 2 ? 6 : 5) * (md / 32); }
 int launch_pack_bwd(int, int, int, int, const float* const*, float*, hipStream_t);
 int launch_ppo_net(int, int, const PpoArgs&, hipStream_t);
 int launch_ppo_fused(int, int, const PpoArgs&, hipStream_t);
 int launch_ppo_fused_dual(int, int, const PpoArgs&, const PpoArgs&, hipStream_t);
-int launch_ppo_fused_dual_reduce(int, int, const PpoArgs&, const PpoArgs&, float* const*, float* const*, float*, float*, double*, float*, int,
-                                 int64_t*, const ReduceAdam*, unsigned*, hipStream_t);
 int64_t fused_stash_floats(int, int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
@@ -1023,9 +1020,6 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
     // keeps one launch per net (A/B, and the per-net phase trace)
     static const bool dual_off = std::getenv("PIME_PPO_DUAL") != nullptr && std::atoi(std::getenv("PIME_PPO_DUAL")) == 0;
     const bool dual = mode[0] == FUSED && mode[1] == FUSED && critic->md == actor->md && !dual_off && !tracing;
-    static const bool tail_off = std::getenv("PIME_PPO_TAIL") != nullptr && std::atoi(std::getenv("PIME_PPO_TAIL")) == 0;
-    const bool tail_reduce = dual && !tail_off;
-    bool tail_fallback = false;
     for (int k = 0; k < 2; ++k) {
         const pime_ppo_net* n = nets[k];
         PpoArgs a{};
@@ -1052,29 +1046,12 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
             slab_args[k] = a;
             if (int rc = launch_ppo16(n->kind, n->md, a, s)) return rc;
         } else if (mode[k] == FUSED) {
-            // the first kFusedWsHead floats of a fused net's workspace are reserved: the critic's hold the two sync words of
-            // ppo_fused_dual_reduce_kernel (zeroed once by the owner of the workspace)
-            a.stash = n->workspace + kFusedWsHead;
-            a.slab = a.stash + fused_stash_floats(n->kind, b->B, n->md);
+            a.slab = n->workspace + fused_stash_floats(n->kind, b->B, n->md);
             a.slab_stride = slab_layout(n->kind, n->D, n->Di, n->md, a.poff, psize);
             slab_args[k] = a;
             if (dual) {
-                if (k == 1) {
-                    // ONE launch per optimizer step: both bodies and, in the critic workgroups' tail, the slab reduction
-                    // (+ Adam + packed images); PIME_PPO_TAIL=0 keeps the reduction a launch of its own (A/B)
-                    if (tail_reduce) {
-                        const int rc = launch_ppo_fused_dual_reduce(actor->kind, actor->md, slab_args[1], slab_args[0], critic->grads, actor->grads,
-                                                                  actor->g_a_std_log, critic_scale, moments, loss_sums + 3,
-                                                                  b->flags & PIME_PPO_OVERWRITE_GRADS, b->index_row, opt ? &adam : nullptr,
-                                                                  reinterpret_cast<unsigned*>(critic->workspace), s);
-                        if (rc == PIME_ERR_STATE) {   // fewer compute units than critic workgroups: two launches after all
-                            tail_fallback = true;
-                            if (int rc2 = launch_ppo_fused_dual(actor->kind, actor->md, slab_args[1], slab_args[0], s)) return rc2;
-                        } else if (rc) {
-                            return rc;
-                        }
-                    } else if (int rc = launch_ppo_fused_dual(actor->kind, actor->md, slab_args[1], slab_args[0], s)) return rc;
-                }
+                if (k == 1)
+                    if (int rc = launch_ppo_fused_dual(actor->kind, actor->md, slab_args[1], slab_args[0], s)) return rc;
             } else if (int rc = launch_ppo_fused(n->kind, n->md, a, s)) return rc;
         } else {
             slab_args[k] = a;
@@ -1118,7 +1095,7 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
                              (e1 - s0) * 0.01);
         }
     }
-    if (any_slab && (!tail_reduce || tail_fallback)) {
+    if (any_slab) {
         const int nslabs[2] = {mode[0] == F16 ? grid16(critic->kind, b->B, critic->md, critic->D, critic->Di) : fused_grid(b->B),
                                mode[1] == F16 ? grid16(actor->kind, b->B, actor->md, actor->D, actor->Di) : fused_grid(b->B)};
         if (int rc = launch_grad_reduce(slab_args[0], slab_args[1], critic->kind, critic->md, actor->kind, actor->md,

@@ -1161,16 +1161,12 @@ struct ReduceArgs {
     double* moments_out;
 };
 
-// One chunk (64 consecutive float4 of one parameter tensor) of the slab reduction, by a 512-thread workgroup.  chunk / nchunks: the
-// chunk's index and the number of chunks of the call (ppo_grad_reduce_kernel: its block index and grid size; the dual kernel's
-// tail: the critic workgroups walk the chunks).  part / sh: 8 KB + 4 floats of LDS scratch.
-__device__ __forceinline__ void grad_reduce_chunk(const ReduceArgs& a, const int chunk, const int nchunks, float4 (*part)[64],
-                                                  float* __restrict__ sh) {
-    float& scale_sh = sh[0];
-    float* const adam_sh = sh + 1;   // t_new, step_size, bc2_sqrt
+__global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
+    __shared__ float4 part[8][64];
+    __shared__ float scale_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // which segment / chunk
-    int c = chunk, si = 0;
+    int c = blockIdx.x, si = 0;
     for (; si < a.nseg; ++si) {
         const int chunks = ((a.seg[si].n + 3) / 4 + 63) / 64;
         if (c < chunks) break;
@@ -1181,6 +1177,7 @@ __device__ __forceinline__ void grad_reduce_chunk(const ReduceArgs& a, const int
     // Adam's bias corrections (two float64 pow, a dependent load of the step count in front of them) are worked out by wave 1 and
     // handed over through LDS: wave 0, which finishes the elements, is the workgroup's critical path.  Every workgroup reads the
     // OLD step count; the last one to finish stores the new one.
+    __shared__ float adam_sh[3];   // t_new, step_size, bc2_sqrt
     if (a.adam.flat_grad && wave == 1) {
         const float tn = a.adam.step[0] + 1.0f;
         const double t = (double)tn;
@@ -1188,7 +1185,7 @@ __device__ __forceinline__ void grad_reduce_chunk(const ReduceArgs& a, const int
         const float bs = (float)sqrt(1.0 - pow((double)a.adam.b2, t));
         if (lane == 0) { adam_sh[0] = tn; adam_sh[1] = ss; adam_sh[2] = bs; }
     }
-    if (wave == 0 && (!a.has_critic || (sg.net != 0 && chunk != 0))) {
+    if (wave == 0 && (!a.has_critic || (sg.net != 0 && blockIdx.x != 0))) {
         if (lane == 0) scale_sh = 1.0f;   // an actor segment needs no scale (workgroup 0 publishes it: always computed there)
     } else if (wave == 0) {  // critic scale from the moments (every workgroup that needs it: same slabs, same order, same value)
         double m1 = 0.0, m2 = 0.0;
@@ -1215,7 +1212,7 @@ __device__ __forceinline__ void grad_reduce_chunk(const ReduceArgs& a, const int
         const float scale = (float)(1.0 / ((double)(float)sqrt(var) + 1e-5));
         if (lane == 0) {
             scale_sh = scale;
-            if (chunk == 0) {
+            if (blockIdx.x == 0) {
                 a.scale_out[0] = scale; a.moments_out[0] = m1; a.moments_out[1] = m2; a.scale_sum[0] += scale;
                 // loss_sums[4] += (this call's SmoothL1 sum) * scale: the logged united loss is the mean of the per-step
                 // values actor + critic * scale (agent.py:652), not mean(critic) * mean(scale).  scale_sum = loss_sums + 3.
@@ -1319,61 +1316,11 @@ __device__ __forceinline__ void grad_reduce_chunk(const ReduceArgs& a, const int
         __syncthreads();
         if (tid == 0) {
             unsigned int* arrivals = reinterpret_cast<unsigned int*>(a.adam.step + 1);
-            if (atomicAdd(arrivals, 1u) == (unsigned)nchunks - 1u) {
+            if (atomicAdd(arrivals, 1u) == gridDim.x - 1) {
                 *arrivals = 0;
                 a.adam.step[0] = t_new;
             }
         }
-    }
-}
-
-__global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
-    __shared__ float4 part[8][64];
-    __shared__ float sh[4];
-    grad_reduce_chunk(a, (int)blockIdx.x, (int)gridDim.x, part, sh);
-}
-
-// The dual gradient kernel with the slab reduction in its TAIL (round 3): the reduction needs every workgroup's slab, i.e. a
-// grid-wide barrier -- which a launch boundary provides at the price of an in-graph dependency gap (~3.5 us), a launch ramp and
-// the reduce kernel's own start-up.  Here every workgroup, when its body is done, makes its slab visible (__threadfence) and
-// arrives at a counter; the CRITIC workgroups (the last ones dispatched: every compute unit runs exactly one of them at the end,
-// so all of them are resident together and none waits for a compute unit held by a waiting one) then spin -- bounded -- until all
-// na + nc have arrived, and walk the reduction's chunks (Adam and the packed images included) with the code of
-// ppo_grad_reduce_kernel.  sync: [0] arrivals, [1] generation; zeroed once by the owner of the workspace they live in.
-template <int T, int AKIND>
-__global__ __launch_bounds__(kFusedThreads) void ppo_fused_dual_reduce_kernel(PpoArgs actor, PpoArgs critic, int na, ReduceArgs r,
-                                                                                int nchunks, unsigned* sync) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = (int)blockIdx.x, total = (int)gridDim.x;
-    unsigned gen0 = 0;
-    if (threadIdx.x == 0) gen0 = __hip_atomic_load(sync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    if (b < na) ppo_fused_body<T, AKIND>(actor, lds, b, na);
-    else ppo_fused_body<T, MLP_CRITIC>(critic, lds, b - na, total - na);
-    __threadfence();    // this workgroup's slab (and loss sums) are visible device-wide ...
-    __syncthreads();    // ... for every one of its threads, before it arrives
-    if (threadIdx.x == 0) {
-        if (__hip_atomic_fetch_add(sync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)total - 1u) {
-            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sync + 1, gen0 + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (b >= na) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(sync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
-                __builtin_amdgcn_s_sleep(16);
-                if (++spins > 20000000u) {   // ~2 s: never hang the device on a workgroup that does not arrive -- but be loud:
-                    critic.loss_sums[2] = __builtin_nanf("");   // the logged critic loss of this update goes NaN
-                    break;
-                }
-            }
-        }
-    }
-    if (b < na) return;
-    __syncthreads();
-    __threadfence();    // acquire: the other workgroups' slabs
-    float4(*part)[64] = reinterpret_cast<float4(*)[64]>(lds);
-    float* const sh = lds + 8 * 64 * 4;
-    for (int chunk = b - na; chunk < nchunks; chunk += total - na) {
-        grad_reduce_chunk(r, chunk, nchunks, part, sh);
-        __syncthreads();   // part / sh are reused by the next chunk
     }
 }
 
@@ -1408,12 +1355,11 @@ int fused_grid(int B) {
     return grid > 256 ? 256 : grid;
 }
 
-// The reduction's argument block and its chunk count (0: nothing to reduce).
-static int build_reduce_args(ReduceArgs& r, const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
-                             bool f16_c, bool f16_a, bool use_c, bool use_a, int nslabs_c, int nslabs_a, float* const* grads_c,
-                             float* const* grads_a, float* g_std, float* scale_out, double* moments_out, float* scale_sum,
-                             int overwrite, int64_t* index_row, const ReduceAdam* adam) {
-    r = ReduceArgs{};
+int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
+                       bool f16_c, bool f16_a, bool use_c, bool use_a, int nslabs_c, int nslabs_a, float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
+                       double* moments_out, float* scale_sum, int overwrite, int64_t* index_row, const ReduceAdam* adam,
+                       hipStream_t s) {
+    ReduceArgs r{};
     if (adam) r.adam = *adam;
     int poff[13], psize[12], chunks = 0;
     auto add = [&](float* dst, int off, int n, int net, int perm_tb = 0, int ldw = 0, int ncols = 0) {
@@ -1454,21 +1400,11 @@ static int build_reduce_args(ReduceArgs& r, const PpoArgs& critic, const PpoArgs
         add_net(actor, kind_a, md_a, f16_a, grads_a, 1, &scalar_a);
         add(g_std, scalar_a, 1, 1);
     }
+    if (chunks == 0) return PIME_OK;
     r.nslabs[0] = nslabs_c; r.nslabs[1] = nslabs_a; r.B = critic.B;
     r.slab[0] = critic.slab; r.slab[1] = actor.slab;
     r.stride[0] = critic.slab_stride; r.stride[1] = actor.slab_stride;
     r.scale_out = scale_out; r.moments_out = moments_out; r.scale_sum = scale_sum; r.overwrite = overwrite; r.index_row = index_row;
-    return chunks;
-}
-
-int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
-                       bool f16_c, bool f16_a, bool use_c, bool use_a, int nslabs_c, int nslabs_a, float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
-                       double* moments_out, float* scale_sum, int overwrite, int64_t* index_row, const ReduceAdam* adam,
-                       hipStream_t s) {
-    ReduceArgs r;
-    const int chunks = build_reduce_args(r, critic, actor, kind_c, md_c, kind_a, md_a, f16_c, f16_a, use_c, use_a, nslabs_c, nslabs_a,
-                                         grads_c, grads_a, g_std, scale_out, moments_out, scale_sum, overwrite, index_row, adam);
-    if (chunks == 0) return PIME_OK;
     hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3(chunks), dim3(512), 0, s, r);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
@@ -1523,48 +1459,6 @@ int launch_ppo_fused_dual(int actor_kind, int md, const PpoArgs& actor, const Pp
     if (T == TT && actor_kind == KK) return launch_dual<TT, KK>(actor, critic, s);
     PIME_DUAL(4, MLP_MODULAR_ACTOR) PIME_DUAL(4, MLP_PLAIN_ACTOR) PIME_DUAL(2, MLP_MODULAR_ACTOR) PIME_DUAL(2, MLP_PLAIN_ACTOR)
 #undef PIME_DUAL
-    set_error("no dual fused PPO instantiation for actor kind %d width %d", actor_kind, md);
-    return PIME_ERR_ARG;
-}
-
-template <int T, int AKIND>
-static int launch_dual_reduce(const PpoArgs& actor, const PpoArgs& critic, const ReduceArgs& r, int nchunks, unsigned* sync, hipStream_t s) {
-    const size_t la = sizeof(float) * (size_t)fused_lds(AKIND, actor.D, actor.Di, T).total;
-    const size_t lc = sizeof(float) * (size_t)fused_lds(MLP_CRITIC, critic.D, critic.Di, T).total;
-    const size_t lds_bytes = la > lc ? la : lc;
-    PIME_REQUIRE(lds_bytes <= 160 * 1024 && lds_bytes >= 8 * 64 * 16 + 16, "fused PPO kernels need %zu B of LDS", lds_bytes);
-    static LdsLimit lds_limit;  // per instantiation
-    PIME_RAISE_LDS(lds_limit, (ppo_fused_dual_reduce_kernel<T, AKIND>), 160 * 1024);
-    const int na = fused_grid(actor.B), nc = fused_grid(critic.B);
-    hipLaunchKernelGGL((ppo_fused_dual_reduce_kernel<T, AKIND>), dim3(na + nc), dim3(kFusedThreads), lds_bytes, s, actor, critic, na, r,
-                       nchunks, sync);
-    PIME_HIP_TRY(hipGetLastError());
-    return PIME_OK;
-}
-
-// ppo_fused_dual_kernel + the slab reduction in its tail (see ppo_fused_dual_reduce_kernel): ONE launch per optimizer step.  Needs
-// every critic workgroup resident at the end: one workgroup per compute unit and nc <= 256 -- fused_grid caps the grid at 256 per net.
-int launch_ppo_fused_dual_reduce(int actor_kind, int md, const PpoArgs& actor, const PpoArgs& critic, float* const* grads_c,
-                                 float* const* grads_a, float* g_std, float* scale_out, double* moments_out, float* scale_sum,
-                                 int overwrite, int64_t* index_row, const ReduceAdam* adam, unsigned* sync, hipStream_t s) {
-    // every critic workgroup must be resident while it waits for the others: one compute unit each
-    static std::atomic<int> cus{0};
-    if (cus.load(std::memory_order_relaxed) == 0) {
-        int dev = 0, n = 0;
-        PIME_HIP_TRY(hipGetDevice(&dev));
-        PIME_HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        cus.store(n, std::memory_order_relaxed);
-    }
-    if (fused_grid(critic.B) > cus.load(std::memory_order_relaxed)) return PIME_ERR_STATE;   // the caller launches the reduction itself
-    ReduceArgs r;
-    const int nchunks = build_reduce_args(r, critic, actor, MLP_CRITIC, md, actor_kind, md, false, false, true, true,
-                                          fused_grid(critic.B), fused_grid(actor.B), grads_c, grads_a, g_std, scale_out, moments_out,
-                                          scale_sum, overwrite, index_row, adam);
-    const int T = md / 32;
-#define PIME_DUALR(TT, KK) \
-    if (T == TT && actor_kind == KK) return launch_dual_reduce<TT, KK>(actor, critic, r, nchunks, sync, s);
-    PIME_DUALR(4, MLP_MODULAR_ACTOR) PIME_DUALR(4, MLP_PLAIN_ACTOR) PIME_DUALR(2, MLP_MODULAR_ACTOR) PIME_DUALR(2, MLP_PLAIN_ACTOR)
-#undef PIME_DUALR
     set_error("no dual fused PPO instantiation for actor kind %d width %d", actor_kind, md);
     return PIME_ERR_ARG;
 }

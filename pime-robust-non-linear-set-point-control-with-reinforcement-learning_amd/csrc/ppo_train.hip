@@ -544,7 +544,7 @@ int64_t ppo_workspace_floats(int kind, int B, int md) {
     if (md == 256) return f16;
     const int64_t ntiles = ((B + 31) / 32 + 7) / 8 * 8;
     const int64_t split = ntiles * stash_tiles(kind, md / 32) * 1024 + ntiles * 32 + ntiles * 32 * kMaxObsDim;
-    const int64_t fused = 16 + fused_workspace_floats(kind, B, kMaxObsDim, 1, md);  // slab size bound: widest state; + the reserved head (abi.hip: kFusedWsHead)
+    const int64_t fused = fused_workspace_floats(kind, B, kMaxObsDim, 1, md);  // slab size bound: widest state
     const int64_t old = split > fused ? split : fused;
     return old > f16 ? old : f16;   // the caller does not say the state width: room for whichever family serves it
 }

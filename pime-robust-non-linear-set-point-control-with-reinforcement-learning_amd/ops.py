@@ -164,7 +164,7 @@ class FusedPPOGrad:
             net = dict(kind=k, D=D, Di=Di, md=md, plist=plist,
                        img_fwd=torch.zeros(n_fwd, dtype=torch.float32, device=self.device),   # zeros: the padding the pack
                        img_bwd=torch.zeros(n_bwd, dtype=torch.float32, device=self.device),   # kernels never write is defined
-                       ws=torch.zeros(n_ws, dtype=torch.float32, device=self.device))   # zeroed once: its head holds sync words
+                       ws=torch.empty(n_ws, dtype=torch.float32, device=self.device))
             self.nets.append(net)
         self._structs = None
         self._image_map = None
