@@ -81,7 +81,10 @@ def test_mlp_pack_size_and_argument_errors():
     # width 256: the streamed 16-tile family (csrc/mlp16.hip): first-layer image 1 k-step x 16 tiles x 64, three biases,
     # two 256 x 256 images, head weights, 4-float head-bias slot
     assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 256) == 16 * 64 + 3 * 256 + 2 * 256 * 256 + 256 + 4
-    assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 3, 1, 256) == 0 and "256" in nt.last_error()
+    # the modular actor at width 256 (round 3: mlp16m kernels): two towers (first-layer image, bias, md -> md/2 image, bias) + net.0
+    # image and bias + head weights + head-bias slot
+    assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 3, 1, 256) == 2 * (16 * 64 + 256 + 256 * 128 + 128) + 256 * 256 + 256 + 256 + 4
+    assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 3, 1, 512) == 0 and "512" in nt.last_error()
     assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 192) == 0 and "192" in nt.last_error()
     assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 3, 3, 128) == 0
 
