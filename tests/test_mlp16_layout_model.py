@@ -23,12 +23,14 @@ def test_mlp16_layout_maps(md, D):
 
 
 def test_library_reports_width_256_support():
-    """Size queries need no GPU: width 256 is served for the critic / plain actor (16-tile family), refused for the modular actor."""
+    """Size queries need no GPU: width 256 is served for every net kind by the 16-tile family (the modular actor since round 3)."""
     import pime_amd.native as nt
     L = nt.lib()
     assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 30, 0, 256) > 2 * 256 * 256
     assert L.pime_mlp_packed_floats(nt.MLP_PLAIN_ACTOR, 30, 0, 256) > 2 * 256 * 256
     assert L.pime_ppo_bwd_image_floats(nt.MLP_CRITIC, 30, 0, 256) == 2 * 256 * 256
     assert L.pime_ppo_workspace_floats(nt.MLP_CRITIC, 4096, 256) > 0
-    assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 4, 1, 256) == 0 and "256" in nt.last_error()
+    assert L.pime_mlp_packed_floats(nt.MLP_MODULAR_ACTOR, 4, 1, 256) > 256 * 256 + 2 * 256 * 128
+    assert L.pime_ppo_bwd_image_floats(nt.MLP_MODULAR_ACTOR, 4, 1, 256) == 2 * 256 * 256      # net.0^T + the two towers' 128 -> 256 transposes
+    assert L.pime_ppo_workspace_floats(nt.MLP_MODULAR_ACTOR, 4096, 256) > 0
     assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 96) == 0
