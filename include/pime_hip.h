@@ -338,7 +338,9 @@ int pime_rollout_h(pime_env* env, int32_t kind, int32_t md, const float* packed_
  *   ret          [dev] float64[N] or NULL: += the launch's per-lane sum of (float32) rewards, as run.py:613 accumulates them
  *   trace        [dev] float64[n_steps, 6, N] or NULL, per step and lane: pH (y, r, I BEFORE the step; action, reward, x after it: the
  *                protocol's per-step records, utils/test.py:1388-1396), water tank (h1, h2, r, I after the step; reward; action)
- * Leaves every lane n_steps further; the caller resets the env before it rolls out again. */
+ * Leaves every lane n_steps further; the caller resets the env before it rolls out again.
+ * pime_rollout_eval_supported: 0 = not served; 1 = served; 2 = served for per-lane returns only (width 256, any observation the
+ * width-256 rollout serves, PIME_STATE_MIXED: trace and set-point schedule must be NULL / 0). */
 int pime_rollout_eval_supported(const pime_env* env, int32_t kind, int32_t md);
 int pime_rollout_eval(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const double* priorK, int32_t n_steps,
                       int32_t seg_len, const double* setpoints, int32_t n_setpoints, double* ret, double* trace,

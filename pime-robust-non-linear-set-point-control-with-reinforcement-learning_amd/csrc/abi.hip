@@ -752,9 +752,13 @@ int pime_rollout_h(pime_env* e, int32_t kind, int32_t md, const float* packed_ac
 int pime_rollout_eval_supported(const pime_env* e, int32_t kind, int32_t md) {
     if (e == nullptr) return 0;
     if (e->cfg.state_mode != PIME_STATE_MIXED && e->cfg.state_mode != PIME_STATE_F64) return 0;
-    if (e->cfg.kind != PIME_ENV_PH && e->cfg.num_stack != 0) return 0;   // pH and the Integrator tank
+    if (e->cfg.kind != PIME_ENV_PH && e->cfg.num_stack != 0) {   // Stacking: the width-256 kernel only (plain actor, returns only)
+        const int S = e->cfg.num_stack;
+        return (md == 256 && kind == PIME_MLP_PLAIN_ACTOR && e->cfg.state_mode == PIME_STATE_MIXED && (S == 1 || S == 4 || S == 10)) ? 2 : 0;
+    }
     if (kind == -1) return 1;                                            // the prior controller alone
     if (kind != PIME_MLP_PLAIN_ACTOR && kind != PIME_MLP_MODULAR_ACTOR) return 0;
+    if (md == 256) return e->cfg.state_mode == PIME_STATE_MIXED ? 2 : 0;   // 2: returns only (no trace, no set-point schedule)
     return (md == 64 || md == 128) && !family16(kind, md) ? 1 : 0;
 }
 
@@ -770,6 +774,21 @@ int pime_rollout_eval(pime_env* e, int32_t kind, int32_t md, const float* packed
                  "pime_rollout_eval: the set-point schedule does not cover n_steps (at most %d segments)", kMaxSetpoints);
     if (!e->was_reset) { set_error("pime_rollout_eval before pime_env_reset"); return PIME_ERR_STATE; }
     if (int rc = use_device(e)) return rc;
+    if (md == 256 && kind != -1) {   // the streamed 16-tile rollout kernel in evaluation mode (mlp16.hip): returns only
+        PIME_REQUIRE(trace == nullptr && seg_len == 0 && ret != nullptr, "pime_rollout_eval at width 256 returns per-lane returns only "
+                     "(no trace, no set-point schedule)");
+        RolloutArgs a{};
+        a.env = e->cfg.kind == PIME_ENV_PH ? 0 : (e->cfg.num_stack == 0 ? 1 : 2);
+        a.n = e->cfg.n_envs;
+        a.env_offset = e->cfg.env_offset;
+        if (a.env == 0) { a.p = e->ph; a.p.auto_reset = 0; a.st = e->ph32; }
+        else { a.wp = e->wt; a.wp.auto_reset = 0; a.wst = e->wt32; }
+        a.img = packed_actor;
+        a.a_std_log = nullptr;                  // not read in evaluation mode (no exploration noise)
+        for (int j = 0; j < e->obs_dim; ++j) a.K.k[j] = priorK[j];
+        a.n_steps = n_steps; a.eval_mode = 1; a.ret = ret;
+        return launch_rollout(kind, md, a, static_cast<hipStream_t>(stream));
+    }
     if (e->cfg.state_mode == PIME_STATE_F64)
         return rollout_eval_t<double>(e, e->ph64, e->wt64, kind, md, packed_actor, priorK, n_steps, seg_len, setpoints, n_setpoints,
                                       ret, trace, stream);

@@ -1174,15 +1174,33 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
     const int i = valid ? m : N - 1;   // idle lanes shadow the last env (compute, never store)
     const bool writer = valid && g == 0;
     const uint32_t gid = a.env_offset + (uint32_t)i;
-    const float sigma = __expf(a.a_std_log[0]);
+    const bool evaluating = a.eval_mode != 0;   // wave-uniform
+    const float sigma = evaluating ? 0.f : __expf(a.a_std_log[0]);
 
     PhLane<float> E{};
     WtLane<float> W{};
     if constexpr (ENV == 0) ph_lane_load<float>(a.p, a.st, i, E);
     else wt_lane_load<float>(a.wp, a.wst, i, W);
     float obs[D];
+    if (evaluating) {   // the lanes' current observation from the state (what pime_env_observe writes)
+        if constexpr (ENV == 0) {
+            obs[0] = (float)ph_lookup<float>(a.p, a.st.table, E.C, E.x); obs[1] = E.r; obs[2] = E.I;
+        } else if constexpr (ENV == 1) {
+            obs[0] = W.h1; obs[1] = W.h2; obs[2] = W.r; obs[3] = W.I;
+        } else {
+            const int head = a.wst.head[i];   // frame ring, oldest first
 #pragma unroll
-    for (int j = 0; j < D; ++j) obs[j] = a.state[(size_t)D * i + j];
+            for (int f = 0; f < STACK; ++f) {
+                const int slot = (head + f) % STACK;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) obs[3 * f + c] = a.wst.frames[(size_t)(3 * slot + c) * a.n + i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) obs[j] = a.state[(size_t)D * i + j];
+    }
+    double ret = 0.0;
     for (int t = 0; t < a.n_steps; ++t) {
         PIME_NO_HOIST();
         float a_avg;
@@ -1226,10 +1244,13 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
             a_avg = head16<T>(lds + S.w3, lds[S.b3], lane, h1);
         }
         // from here on: rollout.hip's step, one env lane per (wave, lane & 15)
-        double ua, ub;
-        philox_pair(a.noise_seed, gid, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE16, ua, ub);
-        const float eps = (float)(sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586476925286766559 * ub));
-        const float a_pre = a_avg + eps * sigma;                                   // net_residual.py:179
+        float eps = 0.f;
+        if (!evaluating) {
+            double ua, ub;
+            philox_pair(a.noise_seed, gid, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE16, ua, ub);
+            eps = (float)(sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586476925286766559 * ub));
+        }
+        const float a_pre = a_avg + eps * sigma;                                   // net_residual.py:179 (evaluation: the mean, run.py:608)
         double dot = 0.0;                                                          // agent_residual.py:61
 #pragma unroll
         for (int j = 0; j < D; ++j) dot += (double)obs[j] * a.K.k[j];
@@ -1239,23 +1260,25 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
         if constexpr (ENV == 0) {
             float o3[3];
             d = ph_lane_step<float>(a.p, a.st.table, a_env, E, o3, rew);
-            if (d) ph_lane_reset<float>(a.p, a.st.table, gid, nullptr, E, o3);     // in-kernel auto-reset
+            if (d && !evaluating) ph_lane_reset<float>(a.p, a.st.table, gid, nullptr, E, o3);     // in-kernel auto-reset
             nxt[0] = o3[0]; nxt[1] = o3[1]; nxt[2] = o3[2];
         } else {
             double z1n, z2n;
             wt_lane_noise<float>(a.wp, gid, W, nullptr, z1n, z2n);
             d = wt_lane_step<float>(a.wp, a_env, z1n, z2n, W, rew);
-            if (d) wt_lane_reset<float>(a.wp, gid, nullptr, W);
+            const bool rst = d && !evaluating;
+            if (rst) wt_lane_reset<float>(a.wp, gid, nullptr, W);
             if constexpr (ENV == 1) {
                 nxt[0] = W.h1; nxt[1] = W.h2; nxt[2] = W.r; nxt[D - 1] = W.I;
             } else {   // deque(maxlen=S).append (:1143-1144), or after a reset every frame = the first one (:1181-1183)
 #pragma unroll
-                for (int j = 0; j < D - 3; ++j) nxt[j] = d ? (j % 3 == 0 ? W.h1 : (j % 3 == 1 ? W.h2 : W.r)) : obs[j + 3];
+                for (int j = 0; j < D - 3; ++j) nxt[j] = rst ? (j % 3 == 0 ? W.h1 : (j % 3 == 1 ? W.h2 : W.r)) : obs[j + 3];
                 nxt[D - 3] = W.h1; nxt[D - 2] = W.h2; nxt[D - 1] = W.r;
             }
         }
+        ret += (double)rew;
         const size_t k = (size_t)t * N + i;
-        if (writer) {
+        if (writer && !evaluating) {
             a.action[k] = a_pre;
             a.noise[k] = eps;
             a.done[k] = (uint8_t)d;
@@ -1275,6 +1298,7 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
             for (int j = 0; j < D; ++j) a.wst.frames[(size_t)j * N + i] = obs[j];
             a.wst.head[i] = 0;
         }
+        if (evaluating && a.ret) a.ret[i] += ret;
     }
 }
 

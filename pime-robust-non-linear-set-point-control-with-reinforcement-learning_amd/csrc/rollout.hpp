@@ -22,5 +22,9 @@ struct RolloutArgs {
     // PIME_STATE_MIXED16 (pime_rollout_h): the handle's binary16 integrated-error array (st.I / wst.I are NULL then) and binary16
     // observation / reward rows instead of `state` / `reward`; the policy sees the binary16 observation, as with the *_h steps
     half_t *I16, *state_h, *reward_h;
+    // evaluation mode of the width-256 kernel (pime_rollout_eval at width 256): deterministic policy (no exploration noise), no
+    // auto-reset, no trajectory writes; ret[lane] += the launch's sum of rewards (state / action / noise / reward / done unused)
+    int eval_mode;
+    double* ret;
 };
 }  // namespace pime

@@ -387,15 +387,20 @@ class VecControlEnv:
         else:
             self._t_lanes = (self._t_lanes + n_steps) % self.max_step
 
-    def eval_supported(self, packed_actor=None):
+    def eval_supported(self, packed_actor=None, trace=False):
         """Does the fused evaluation kernel serve this env (with this packed actor, or the prior controller alone)?
-        (pime_rollout_eval_supported: float64 or mixed state, pH / Integrator tank, in-kernel draws)"""
+        (pime_rollout_eval_supported: 1 = everything, 2 = per-lane returns only -- the width-256 kernel: no trace, no set-point
+        schedule; float64 or mixed state, in-kernel draws)"""
         if self.draws.injects:
             return False
         if packed_actor is None:
-            return bool(self._lib.pime_rollout_eval_supported(self._h, -1, 0))
-        kind = native.MLP_MODULAR_ACTOR if packed_actor.kind == "modular_actor" else native.MLP_PLAIN_ACTOR
-        return packed_actor.D == self.obs_dim and bool(self._lib.pime_rollout_eval_supported(self._h, kind, int(packed_actor.md)))
+            level = self._lib.pime_rollout_eval_supported(self._h, -1, 0)
+        else:
+            if packed_actor.kind not in ("modular_actor", "plain_actor") or packed_actor.D != self.obs_dim:
+                return False
+            kind = native.MLP_MODULAR_ACTOR if packed_actor.kind == "modular_actor" else native.MLP_PLAIN_ACTOR
+            level = self._lib.pime_rollout_eval_supported(self._h, kind, int(packed_actor.md))
+        return level == 1 or (level == 2 and not trace)
 
     def rollout_eval(self, packed_actor, priorK, n_steps, setpoints=None, seg_len=0, want_trace=False, ret=None):
         """`n_steps` steps of every lane under the deterministic residual policy in ONE launch (csrc/rollout_eval.hip; no

@@ -45,7 +45,9 @@ def test_protocols_run_as_one_launch_and_match_the_golden_records():
 
 
 @pytest.mark.parametrize("env_name,algo,md", [("PH_V35", "ResidualIntegratorModularPPO", 128), ("PH_V35", "ResidualPPO", 64),
-                                              ("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 128)])
+                                              ("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 128),
+                                              # width 256: the streamed rollout kernel in evaluation mode
+                                              ("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 256), ("PH_V35", "ResidualPPO", 256)])
 def test_fused_episode_returns_against_oracle_and_stepwise(env_name, algo, md):
     """One deterministic episode per lane: the fused launch vs (1) the oracle env driven by the oracle's forward of the same
     weights, step by step in float64 (per-lane returns 1e-4 relative: float32 policy mean + mixed-mode state), (2) the
@@ -112,3 +114,22 @@ def test_evaluator_uses_the_fused_path_and_explore_resets_afterwards():
     ag.explore_env(env, buf, N * 50, 1.0, 0.99)      # resets (episode + 1), rolls out one episode, auto-resets (episode + 1)
     assert (env.get_field("episode") == ep0 + 2).all() and env.fresh
     env.close()
+
+
+def test_stacking10_width_256_evaluation_is_one_launch():
+    """The reference's live water-tank configuration (ResidualPPO, net_dim 256, Stacking10): the evaluator's episode through the
+    width-256 kernel's evaluation mode against the launch-by-launch path."""
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.run import get_episode_return_vec
+    N = 1000
+    envs = [gym_control.make_vec(gym_control.WT_STACKING.format(10), N, device=DEV, state_mode="mixed", seed=4, reward_type="distance",
+                                 max_step=60) for _ in range(2)]
+    ag = make_agent("ResidualPPO", envs[0], 256)
+    fused = ag.fused_eval_policy(envs[0])
+    assert fused is not None and not envs[0].eval_supported(fused[0], trace=True)
+    _no_stepwise(envs[0])
+    got = get_episode_return_vec(envs[0], ag.act, fused=fused)
+    slow = get_episode_return_vec(envs[1], ag.act)
+    np.testing.assert_allclose(got, slow, rtol=1e-4, atol=1e-3)
+    for e in envs:
+        e.close()
