@@ -44,6 +44,12 @@ constexpr int kFusedWaves = kFusedThreads / 64;
 // consecutive features), the MFMA operand reads take consecutive features on consecutive lanes: both conflict-free.
 __host__ __device__ constexpr int tpitch(int nt) { return nt * 32 + 4; }
 __host__ __device__ constexpr int tsize(int nt) { return 32 * tpitch(nt); }   // floats of one 32-sample tile image
+// The B operand of a weight-gradient round (the activation tile) is FEATURE-major instead: row = one feature's 32 samples, even
+// samples in columns 0..15, odd ones in 16..31, pitch 36 -- a lane's operands of the 16 k-steps (samples 2s + h of feature li) are 16
+// consecutive floats = four ds_read_b128 per output block instead of sixteen ds_read_b32 (LDS instructions cost SIMD issue slots,
+// not bytes: tools/dw_round_bench.hip); the eight waves publish their slices as ds_write_b32 (lanes = samples: conflict-free).
+constexpr int kBPitch = 36;
+__host__ __device__ constexpr int bsize(int nt) { return nt * 32 * kBPitch; }
 
 // first-layer gradients on the vector ALUs up to this fan-in (first_grad_valu); its state rows are padded to 4 / 8 floats
 constexpr int kFirstValuMaxD = 7;
@@ -81,8 +87,8 @@ __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
     seg(F.wbuf, T * T * 1024);
     // X: two (A+B) buffers of the widest job that keeps W alive (2T blocks each); the merged modular jobs (3T and 2T+1
     // blocks per buffer) run while W is dead and use W and X as one region
-    int xf = 2 * (tsize(T) + tsize(T));
-    const int need3 = 2 * (tsize(T) + tsize(2 * T)) - T * T * 1024, need1 = 2 * (tsize(2 * T) + tsize(1)) - T * T * 1024;
+    int xf = 2 * (tsize(T) + bsize(T));
+    const int need3 = 2 * (tsize(T) + bsize(2 * T)) - T * T * 1024, need1 = 2 * (tsize(2 * T) + bsize(1)) - T * T * 1024;
     if (kind == MLP_MODULAR_ACTOR) xf = xf > need3 ? (xf > need1 ? xf : need1) : (need3 > need1 ? need3 : need1);
     seg(F.x, xf);
     F.total = o;
@@ -289,7 +295,7 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
                                           float* __restrict__ stage_dst, const float* __restrict__ stage_src,
                                           int stage_n4, long long* tr = nullptr) {
     constexpr int PER = Plan::PER, NKS = 16;
-    constexpr int BUF = tsize(AT) + tsize(BT);
+    constexpr int BUF = tsize(AT) + bsize(BT);
     constexpr int NP = BT * 16 / kFusedWaves;                               // B elements this wave publishes per round
     const Plan pl(wave);
     const int tid = wave * 64 + lane, h = lane >> 5, li = lane & 31;
@@ -306,16 +312,10 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
     typename BSrc::template Pre<NP> pre;   // what a wave's slice does not re-derive per round (first-layer weights)
     bsrc.template prepare<NP>(pt, pr0, lane, pre);
     auto b_fetch = [&](int ow, float (&v)[NP]) { bsrc.template fetch<NP>(ow, pt, pr0, lane, pre, v); };
-    auto b_publish = [&](float* buf) {
-        float* p = buf + tsize(AT) + li * tpitch(BT) + pt * 32 + 4 * h + 8 * (pr0 >> 2) + (pr0 & 3);
-        if constexpr (NP >= 4) {
+    auto b_publish = [&](float* buf) {   // register pr0 + i of tile pt = feature pt * 32 + 4 h + 8 ((pr0 + i) >> 2) + ((pr0 + i) & 3)
+        float* p = buf + tsize(AT) + (pt * 32 + 4 * h) * kBPitch + (li & 1) * 16 + (li >> 1);
 #pragma unroll
-            for (int g = 0; g < NP / 4; ++g)
-                *reinterpret_cast<float4*>(p + 8 * g) = make_float4(pv[4 * g], pv[4 * g + 1], pv[4 * g + 2], pv[4 * g + 3]);
-        } else {
-            static_assert(NP == 2, "publish slice");
-            *reinterpret_cast<float2*>(p) = make_float2(pv[0], pv[1]);
-        }
+        for (int i = 0; i < NP; ++i) p[(8 * ((pr0 + i) >> 2) + ((pr0 + i) & 3)) * kBPitch] = pv[i];
     };
 
     unsigned long long tsum[5] = {0, 0, 0, 0, 0}, tprev = 0;
@@ -350,14 +350,17 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
         PIME_NO_HOIST();
         if (pl.active) {
             const float* Ap = cur + h * tpitch(AT) + pl.ao * 32 + li;                  // k-step s: samples 2s + h
-            const float* Bp = cur + tsize(AT) + h * tpitch(BT) + pl.bi0 * 32 + li;
+            const float* Bp = cur + tsize(AT) + (pl.bi0 * 32 + li) * kBPitch + h * 16;
             float av[NKS], bv[PER][NKS];
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                av[s] = Ap[2 * s * tpitch(AT)];
+            for (int s = 0; s < NKS; ++s) av[s] = Ap[2 * s * tpitch(AT)];
 #pragma unroll
-                for (int n = 0; n < PER; ++n) bv[n][s] = Bp[2 * s * tpitch(BT) + n * 32];
-            }
+            for (int n = 0; n < PER; ++n)
+#pragma unroll
+                for (int q = 0; q < NKS / 4; ++q) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(Bp + n * 32 * kBPitch + 4 * q);
+                    bv[n][4 * q] = b4.x; bv[n][4 * q + 1] = b4.y; bv[n][4 * q + 2] = b4.z; bv[n][4 * q + 3] = b4.w;
+                }
             PIME_STAMP(1);   // operand reads back
 #pragma unroll
             for (int s = 0; s < NKS; ++s) {
