@@ -4,7 +4,13 @@
 # (ResidualPPO / ResidualIntegratorModularPPO, net_dim 256) to 1e8, and residual TD3 on 4096 tank lanes.
 TAG=$1; OUT=gpurun_out; mkdir -p $OUT; cd ${GRAFT_REPO_ROOT:-/root/repo}
 LOG=/tmp/pime_logs
-run() { name=$1; shift; /usr/bin/time -f "wall %e s" timeout -k 10 400 python -m pime_amd.train "$@" --log_root $LOG > $OUT/${TAG}_${name}_training_console.txt 2>&1; tail -3 $OUT/${TAG}_${name}_training_console.txt; }
+run() {
+  name=$1; shift
+  t0=$(date +%s.%N)
+  timeout -k 10 400 python -m pime_amd.train "$@" --log_root $LOG > $OUT/${TAG}_${name}_training_console.txt 2>&1
+  echo "wall clock of the whole command (imports, table, graph capture, evaluations included): $(echo "$(date +%s.%N) - $t0" | bc) s" >> $OUT/${TAG}_${name}_training_console.txt
+  tail -4 $OUT/${TAG}_${name}_training_console.txt
+}
 run ph --algo ResidualIntegratorModularPPO --fix_K --env PH1DChangingParamUniformGoalIntegrator-SqaureDistance-v35 --net_dim 128 \
     --num_envs 16384 --target_step 819200 --batch_size 65536 --repeat_times 8 --lambda_gae_adv 0.99 --break_step 400000000 \
     --eval_times1 4096 --eval_times2 4096
