@@ -6,9 +6,9 @@ TAG=$1; OUT=gpurun_out; mkdir -p $OUT; cd ${GRAFT_REPO_ROOT:-/root/repo}
 LOG=/tmp/pime_logs
 run() {
   name=$1; shift
-  t0=$(date +%s.%N)
+  t0=$(date +%s)
   timeout -k 10 400 python -m pime_amd.train "$@" --log_root $LOG > $OUT/${TAG}_${name}_training_console.txt 2>&1
-  echo "wall clock of the whole command (imports, table, graph capture, evaluations included): $(echo "$(date +%s.%N) - $t0" | bc) s" >> $OUT/${TAG}_${name}_training_console.txt
+  echo "wall clock of the whole command (imports, table, graph capture, evaluations included): $(( $(date +%s) - t0 )) s" >> $OUT/${TAG}_${name}_training_console.txt
   tail -4 $OUT/${TAG}_${name}_training_console.txt
 }
 run ph --algo ResidualIntegratorModularPPO --fix_K --env PH1DChangingParamUniformGoalIntegrator-SqaureDistance-v35 --net_dim 128 \
