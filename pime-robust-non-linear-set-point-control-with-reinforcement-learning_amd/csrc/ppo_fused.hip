@@ -16,8 +16,8 @@
 // holds the second MFMA image).  The last hidden layer stays in registers across the loss: its dZ is formed in place and
 // the head weight gradient is a DPP lane reduction.  Per earlier layer l of the backward:
 //   dW_l = dZ_l^T H_{l-1}: eight rounds, round t multiplies tile t (dw_rounds).  The owning wave publishes its dZ_l tile,
-//          ALL waves publish 1/8 of the matching H_{l-1} tile each (from the stash, fetched two rounds ahead, or
-//          recomputed from the group's states for a first-layer activation); every wave owns 1/8 of the output blocks
+//          ALL waves publish 1/8 of the matching H_{l-1} tile each (from the stash -- first-layer activations included since
+//          round 3 --, fetched two rounds ahead, FEATURE-major: dw_rounds); every wave owns 1/8 of the output blocks
 //          in accumulators for the eight rounds.  X is double buffered (one LDS-only barrier per round); the next
 //          layer's transposed weight image is copied into W one slice per round, behind the MFMAs.  The bias gradient
 //          is the sum of the A operands a wave reads anyway.
@@ -159,106 +159,23 @@ __device__ __forceinline__ void stash_get(const float* __restrict__ base, int la
 
 // ---- B-operand sources: NP consecutive registers r0..r0+NP-1 of tile t of the accumulator-layout activation tile of
 // wave `ow`, for this lane.  Any wave can produce any tile's elements, so the eight waves share the publishing work.
-// A wave publishes the SAME (t, r0) slice in every round (only the sample tile `ow` changes): `prepare` runs once in front
-// of the rounds and keeps what does not depend on `ow` in registers (Pre<NP>).
-struct NoPre {};
+// (Rounds 1-2 also had sources that RECOMPUTED a first-layer activation from the group's states; since round 3 those
+// activations come from the stash like every other.)
 struct StashB {   // a hidden activation stashed by the forward: [wave tile][t][16][64]
-    static constexpr bool kLate = false;  // global loads: issue early, they land behind the MFMAs
-    template <int NP> using Pre = NoPre;
     const float* base;   // stash of the group's first tile, at the wanted activation
     int tile_stride;     // floats between consecutive tiles
     template <int NP>
-    __device__ __forceinline__ void prepare(int, int, int, NoPre&) const {}
-    template <int NP>
-    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, const NoPre&, float (&v)[NP]) const {
+    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, float (&v)[NP]) const {
         const float* p = base + (size_t)ow * tile_stride + (t * 16 + r0) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NP; ++i) v[i] = p[i * 64];
     }
 };
-constexpr int kPreD = 4;   // fan-in up to which a wave keeps its slice of the first-layer weights in registers over the rounds
-template <int NP>
-struct FirstPre {
-    float w[NP][kPreD + 1];   // [element][input column | bias]
-};
-template <int ACT, bool HOIST = true>
-struct FirstB {   // a first-layer activation, recomputed from the group's states in LDS (same arithmetic as layer_first)
-    static constexpr bool kLate = true;   // VALU / LDS work: waves 4-7 do it after their MFMAs (see dw_rounds)
-    // HOIST: the slice's weights stay in registers over the rounds; otherwise (no registers to spare: the modular actor's
-    // merged job, 16 elements per wave and round) every fetch re-reads them column by column
-    template <int NP> using Pre = std::conditional_t<HOIST, FirstPre<NP>, NoPre>;
-    const float* w0;   // FIRST image [Din+1][OT][16][2]
-    const float* xs;   // [wave][32][D]
-    int Din, D, col0, ot32;
-    // The slice's weights: NP * (Din + 1) LDS reads once instead of once per round (as dependent reads in front of every
-    // round's MFMAs they cost ~2 000 cycles per round and wave: r02 phase trace).
-    template <int NP>
-    __device__ __forceinline__ void prepare(int t, int r0, int lane, NoPre&) const {}
-    template <int NP>
-    __device__ __forceinline__ void prepare(int t, int r0, int lane, FirstPre<NP>& p) const {
-        if (Din > kPreD) return;
-        const float* w = w0 + (t * 16 + r0) * 2 + (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < NP; ++i) p.w[i][kPreD] = w[Din * ot32 + 2 * i];
-#pragma unroll
-        for (int j = 0; j < kPreD; ++j)
-            if (j < Din) {   // one wave-uniform branch per column
-#pragma unroll
-                for (int i = 0; i < NP; ++i) p.w[i][j] = w[j * ot32 + 2 * i];
-            }
-    }
-    template <int NP>
-    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, const NoPre&, float (&v)[NP]) const {
-        const float* x = xs + (ow * 32 + (lane & 31)) * D + col0;
-        const float* w = w0 + (t * 16 + r0) * 2 + (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < NP; ++i) v[i] = w[Din * ot32 + 2 * i];
-        for (int j = 0; j < Din; ++j) {   // j outermost: one wait per input column, not one per element
-            const float xj = x[j];
-#pragma unroll
-            for (int i = 0; i < NP; ++i) v[i] = fmaf(xj, w[j * ot32 + 2 * i], v[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < NP; ++i) v[i] = activate<ACT>(v[i]);
-    }
-    template <int NP>
-    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, const FirstPre<NP>& p, float (&v)[NP]) const {
-        const float* x = xs + (ow * 32 + (lane & 31)) * D + col0;
-        if (Din <= kPreD) {
-            float xv[kPreD];
-#pragma unroll
-            for (int j = 0; j < kPreD; ++j) xv[j] = x[j < Din ? j : 0];   // unconditional reads: issued together, one wait
-#pragma unroll
-            for (int i = 0; i < NP; ++i) v[i] = p.w[i][kPreD];
-#pragma unroll
-            for (int j = 0; j < kPreD; ++j)   // same order as layer_first: bias, then columns 0, 1, ...
-                if (j < Din) {
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) v[i] = fmaf(xv[j], p.w[i][j], v[i]);
-                }
-        } else {
-            const float* w = w0 + (t * 16 + r0) * 2 + (lane >> 5);
-#pragma unroll
-            for (int i = 0; i < NP; ++i) v[i] = w[Din * ot32 + 2 * i];
-            for (int j = 0; j < Din; ++j) {   // j outermost: one wait per input column, not one per element
-                const float xj = x[j];
-#pragma unroll
-                for (int i = 0; i < NP; ++i) v[i] = fmaf(xj, w[j * ot32 + 2 * i], v[i]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NP; ++i) v[i] = activate<ACT>(v[i]);
-    }
-};
 struct StateB {   // the raw state columns [col0, col0+Din) padded with zeros to one 32-feature tile
-    static constexpr bool kLate = false;
-    template <int NP> using Pre = NoPre;
     const float* xs;
     int Din, D, col0;
     template <int NP>
-    __device__ __forceinline__ void prepare(int, int, int, NoPre&) const {}
-    template <int NP>
-    __device__ __forceinline__ void fetch(int ow, int, int r0, int lane, const NoPre&, float (&v)[NP]) const {
+    __device__ __forceinline__ void fetch(int ow, int, int r0, int lane, float (&v)[NP]) const {
         const float* x = xs + (ow * 32 + (lane & 31)) * D + col0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -309,9 +226,7 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
     const float4* src4 = reinterpret_cast<const float4*>(stage_src);
     float4* dst4 = reinterpret_cast<float4*>(stage_dst);
     float pv[NP], pv2[NP];
-    typename BSrc::template Pre<NP> pre;   // what a wave's slice does not re-derive per round (first-layer weights)
-    bsrc.template prepare<NP>(pt, pr0, lane, pre);
-    auto b_fetch = [&](int ow, float (&v)[NP]) { bsrc.template fetch<NP>(ow, pt, pr0, lane, pre, v); };
+    auto b_fetch = [&](int ow, float (&v)[NP]) { bsrc.template fetch<NP>(ow, pt, pr0, lane, v); };
     auto b_publish = [&](float* buf) {   // register pr0 + i of tile pt = feature pt * 32 + 4 h + 8 ((pr0 + i) >> 2) + ((pr0 + i) & 3)
         float* p = buf + tsize(AT) + (pt * 32 + 4 * h) * kBPitch + (li & 1) * 16 + (li >> 1);
 #pragma unroll
@@ -341,10 +256,8 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
         float* nxt = X + ((t + 1) & 1) * BUF;
         float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < per4) sv = src4[t * per4 + tid];
-        // B elements for round t+2.  Recomputed sources are VALU / LDS work: waves 0-3 do it before their MFMAs and
-        // waves 4-7 (their SIMD partners) after, so that one partner's MFMAs run while the other computes.
-        const bool late = BSrc::kLate && wave >= kFusedWaves / 2;
-        if (!late && t + 2 < kFusedWaves) b_fetch(t + 2, pv2);
+        // B elements for round t+2: global loads (or a few LDS reads), issued now, landed behind this round's MFMAs
+        if (t + 2 < kFusedWaves) b_fetch(t + 2, pv2);
         if (wave == t + 1) put_tile<AT>(nxt, lane, az);
         PIME_STAMP(0);   // fetch (+ A publish on the owner)
         PIME_NO_HOIST();
@@ -375,8 +288,6 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
             }
             PIME_STAMP(2);   // MFMAs
         }
-        PIME_NO_HOIST();
-        if (late && t + 2 < kFusedWaves) b_fetch(t + 2, pv2);
         PIME_NO_HOIST();
         if (t + 1 < kFusedWaves) b_publish(nxt);
 #pragma unroll
@@ -481,29 +392,11 @@ struct CatPlan {
     }
 };
 template <int T>
-struct CatB {   // tiles [0,T): other branch, [T,2T): integrator branch
-    static constexpr bool kLate = true;
-    template <int NP> using Pre = NoPre;
-    FirstB<1, false> o, i;
-    template <int NP>
-    __device__ __forceinline__ void prepare(int, int, int, NoPre&) const {}
-    template <int NP>
-    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, const NoPre& p, float (&v)[NP]) const {
-        if (t < T) o.template fetch<NP>(ow, t, r0, lane, p, v);
-        else i.template fetch<NP>(ow, t - T, r0, lane, p, v);
-    }
-};
-
-template <int T>
 struct CatStashB {   // tiles [0,T): other_net's first-layer activation (stash region 1), [T,2T): integrator_net's (region 2)
-    static constexpr bool kLate = false;  // global loads: issue early, they land behind the MFMAs
-    template <int NP> using Pre = NoPre;
     const float *o, *i;   // the group's first tile in either region
     int tile_stride;
     template <int NP>
-    __device__ __forceinline__ void prepare(int, int, int, NoPre&) const {}
-    template <int NP>
-    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, const NoPre&, float (&v)[NP]) const {
+    __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, float (&v)[NP]) const {
         const float* p = (t < T ? o : i) + (size_t)ow * tile_stride + ((t < T ? t : t - T) * 16 + r0) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < NP; ++k) v[k] = p[k * 64];
@@ -534,29 +427,6 @@ __device__ __forceinline__ void bias_store(float bsum, float* __restrict__ gb, i
     if (lane < 32) {
         float* q = &gb[lane];
         *q = accum ? *q + bsum : bsum;
-    }
-}
-
-// d[ot] *= act'(h1[ot]) with the first-layer activation h1 recomputed one 32-feature tile at a time (16 live registers
-// instead of a whole T-tile activation; same arithmetic as layer_first).
-template <int OT, int ACT>
-__device__ __forceinline__ void first_times_act_grad(const float* __restrict__ w0, const float* __restrict__ x, int Din,
-                                                     int h, f32x16 (&d)[OT]) {
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
-        PIME_NO_HOIST();
-        f32x16 v;
-        const float* wb = w0 + Din * (OT * 32) + ot * 32 + h;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = wb[r * 2];
-        for (int j = 0; j < Din; ++j) {
-            const float xj = x[j];
-            const float* wj = w0 + j * (OT * 32) + ot * 32 + h;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = fmaf(xj, wj[r * 2], v[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d[ot][r] *= act_grad_from_output<ACT>(activate<ACT>(v[r]));
     }
 }
 
