@@ -14,10 +14,12 @@ enum { MLP_CRITIC = 0, MLP_PLAIN_ACTOR = 1, MLP_MODULAR_ACTOR = 2 };
 __host__ __device__ __forceinline__ constexpr int feat32(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
 // ---- packed image layout (identical in HBM and LDS) -------------------------------------------------------
-// FIRST  layer (D_in -> 32*OT):   [D_in+1][OT][16][2]        column j of W for feature feat(ot,r,h); row D_in = bias
-//                                 (j outermost so every LDS read of the unrolled (ot,r) loop is base + immediate)
+// FIRST  layer (D_in -> 32*OT):   [D_in+1][2][OT][16]        column j of W for feature feat(ot,r,h); row D_in = bias
+//                                 (j outermost; lane half h next, so that the 16 values a lane reads per output tile are
+//                                 contiguous: four ds_read_b128 instead of sixteen ds_read_b32 -- round 3; LDS instructions cost
+//                                 SIMD issue slots, not bytes)
 // MFMA   layer (32*KT -> 32*OT):  [KT*16][64][OT]            W[ot*32 + (lane&31)][kt*32 + feat32(s, lane>>5)]
-// VEC    (bias / head weights):   [OT][16][2]                v[ot*32 + feat32(r,h)]
+// VEC    (bias / head weights):   [2][OT][16]                v[ot*32 + feat32(r,h)] at h*OT*16 + ot*16 + r
 struct MlpLayout {
     int T;          // md / 32
     int off[12];    // float offsets of the segments
@@ -62,7 +64,7 @@ __device__ inline void pack_first(float* dst, const float* W, const float* b, in
     const int per = OT * 32, n = per * (Din + 1);
     for (int idx = tid; idx < n; idx += nthr) {
         const int j = idx / per, q = idx % per;
-        const int h = q & 1, r = (q >> 1) & 15, ot = q >> 5;
+        const int h = q / (OT * 16), r = q & 15, ot = (q >> 4) % OT;
         const int f = ot * 32 + feat32(r, h);
         dst[idx] = j < Din ? W[(size_t)f * ldw + col0 + j] : b[f];
     }
@@ -91,7 +93,7 @@ __device__ inline void pack_mfma_t(float* dst, const float* W, int KT, int OT, i
 
 __device__ inline void pack_vec(float* dst, const float* v, int OT, int tid, int nthr) {
     for (int idx = tid; idx < OT * 32; idx += nthr) {
-        const int h = idx & 1, r = (idx >> 1) & 15, ot = idx >> 5;
+        const int h = idx / (OT * 16), r = idx & 15, ot = (idx >> 4) % OT;
         dst[idx] = v[ot * 32 + feat32(r, h)];
     }
 }
@@ -175,22 +177,40 @@ __device__ __forceinline__ float activate(float v) {
     else return v;                                      // identity (backward chains)
 }
 
+// the 16 values of lane half h for output tile ot of a VEC / FIRST row (16-byte aligned: segments are multiples of 4 floats)
+__device__ __forceinline__ void load16(const float* __restrict__ p, float (&v)[16]) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 w = q[g];
+        v[4 * g] = w.x; v[4 * g + 1] = w.y; v[4 * g + 2] = w.z; v[4 * g + 3] = w.w;
+    }
+}
+template <int OT>
+__device__ __forceinline__ const float* vec_at(const float* __restrict__ v, int ot, int h) { return v + h * (OT * 16) + ot * 16; }
+
 // y[ot][r] = act( b[f] + sum_j x[m][col0 + j] * W[f][j] ),  f = ot*32 + feat32(r, h)
 template <int OT, int ACT>
 __device__ __forceinline__ void layer_first(const float* __restrict__ w0, const float* __restrict__ xrow, int Din,
                                             int h, f32x16 (&out)[OT]) {
-    const float* wb = w0 + Din * (OT * 32) + h;  // bias row
+    const float* wb = w0 + Din * (OT * 32);  // bias row
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+    for (int ot = 0; ot < OT; ++ot) {
+        float v[16];
+        load16(vec_at<OT>(wb, ot, h), v);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[ot][r] = wb[(ot * 16 + r) * 2];
+        for (int r = 0; r < 16; ++r) out[ot][r] = v[r];
+    }
     for (int j = 0; j < Din; ++j) {
         const float xj = xrow[j];
-        const float* wj = w0 + j * (OT * 32) + h;
+        const float* wj = w0 + j * (OT * 32);
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot)
+        for (int ot = 0; ot < OT; ++ot) {
+            float v[16];
+            load16(vec_at<OT>(wj, ot, h), v);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[ot][r] = fmaf(xj, wj[(ot * 16 + r) * 2], out[ot][r]);
+            for (int r = 0; r < 16; ++r) out[ot][r] = fmaf(xj, v[r], out[ot][r]);
+        }
     }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
@@ -218,9 +238,12 @@ __device__ __forceinline__ void layer_mfma(const float* __restrict__ wp, const f
     using Frag = typename WFrag<OT>::type;
     const int h = lane >> 5;
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+    for (int ot = 0; ot < OT; ++ot) {
+        float bv[16];
+        if constexpr (HAS_BIAS) load16(vec_at<OT>(bp, ot, h), bv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[ot][r] = HAS_BIAS ? bp[(ot * 16 + r) * 2 + h] : 0.f;
+        for (int r = 0; r < 16; ++r) out[ot][r] = HAS_BIAS ? bv[r] : 0.f;
+    }
     const Frag* wl = reinterpret_cast<const Frag*>(wp) + lane;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
@@ -249,9 +272,12 @@ __device__ __forceinline__ void layer_mfma_in(const float* __restrict__ wp, cons
     using Frag = typename WFrag<OT>::type;
     const int h = lane >> 5;
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+    for (int ot = 0; ot < OT; ++ot) {
+        float bv[16];
+        if constexpr (HAS_BIAS) load16(vec_at<OT>(bp, ot, h), bv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[ot][r] = HAS_BIAS ? bp[(ot * 16 + r) * 2 + h] : 0.f;
+        for (int r = 0; r < 16; ++r) out[ot][r] = HAS_BIAS ? bv[r] : 0.f;
+    }
     const Frag* wl = reinterpret_cast<const Frag*>(wp) + lane;
     in[0][0] = activate<ACT_IN>(in[0][0]);
 #pragma unroll
@@ -329,9 +355,12 @@ __device__ __forceinline__ float layer_head(const float* __restrict__ w, float b
     const int h = lane >> 5;
     float acc = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KT; ++kt) {
+        float wv[16];
+        load16(vec_at<KT>(w, kt, h), wv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc = fmaf(in[kt][r], w[(kt * 16 + r) * 2 + h], acc);
+        for (int r = 0; r < 16; ++r) acc = fmaf(in[kt][r], wv[r], acc);
+    }
     acc += __shfl_xor(acc, 32);  // the other lane half holds the other 16 features of every tile
     return acc + bias;
 }

@@ -96,9 +96,12 @@ template <int NTL>
 __device__ __forceinline__ void head_backward(const float* __restrict__ w, int lane, float dout, f32x16 (&d)[NTL]) {
     const int h = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < NTL; ++t)
+    for (int t = 0; t < NTL; ++t) {
+        float wv[16];
+        load16(vec_at<NTL>(w, t, h), wv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d[t][r] = w[(t * 16 + r) * 2 + h] * dout;
+        for (int r = 0; r < 16; ++r) d[t][r] = wv[r] * dout;
+    }
 }
 
 // Sum over the 64 lanes on the DPP path (6 VALU ops, no LDS crossbar); the total is valid in LANE 63 only.

@@ -761,15 +761,17 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
         // is still in registers; the sum over the tile's samples is a DPP reduction over the lanes.
         {   // one 32-feature tile at a time: 16 live temporaries instead of a whole T-tile dl (the actor kernel sits at the
             // 256-VGPR cap; spill reloads here queue behind the 64 stash stores just issued on the same vmcnt counter)
-            const float* hw = lds + F.headw + h;
+            const float* hw = lds + F.headw;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 PIME_NO_HOIST();
                 f32x16 dl;
+                float hwv[16];
+                load16(vec_at<T>(hw, t, h), hwv);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float hv = hl[t][r];
-                    dl[r] = hw[(t * 16 + r) * 2] * dout * act_grad_from_output<ACT>(hv);   // head_backward . act'
+                    dl[r] = hwv[r] * dout * act_grad_from_output<ACT>(hv);   // head_backward . act'
                     const float hs = half_sum_dpp(dout * hv);
                     if (li == 31) hacc[wave * md + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] += hs;   // own slots: reproducible
                 }

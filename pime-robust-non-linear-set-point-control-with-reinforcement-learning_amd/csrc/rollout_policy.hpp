@@ -10,18 +10,24 @@ namespace pime {
 // first layer from a register-resident input of compile-time width
 template <int OT, int ACT, int DIN>
 __device__ __forceinline__ void layer_first_regs(const float* __restrict__ w0, const float* x, int h, f32x16 (&out)[OT]) {
-    const float* wb = w0 + DIN * (OT * 32) + h;
+    const float* wb = w0 + DIN * (OT * 32);
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
+    for (int ot = 0; ot < OT; ++ot) {
+        float v[16];
+        load16(vec_at<OT>(wb, ot, h), v);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[ot][r] = wb[(ot * 16 + r) * 2];
+        for (int r = 0; r < 16; ++r) out[ot][r] = v[r];
+    }
 #pragma unroll
     for (int j = 0; j < DIN; ++j) {
-        const float* wj = w0 + j * (OT * 32) + h;
+        const float* wj = w0 + j * (OT * 32);
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot)
+        for (int ot = 0; ot < OT; ++ot) {
+            float v[16];
+            load16(vec_at<OT>(wj, ot, h), v);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[ot][r] = fmaf(x[j], wj[(ot * 16 + r) * 2], out[ot][r]);
+            for (int r = 0; r < 16; ++r) out[ot][r] = fmaf(x[j], v[r], out[ot][r]);
+        }
     }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
