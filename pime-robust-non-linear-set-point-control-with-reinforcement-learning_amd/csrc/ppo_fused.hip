@@ -137,38 +137,53 @@ __device__ __forceinline__ void put_tile(float* __restrict__ dst, int lane, cons
 }
 
 // Stash tiles through a wave-uniform base: one 32-bit lane offset + immediates instead of a 64-bit address per row
-// (which the compiler hoists out of the group loop and spills).
+// (which the compiler hoists out of the group loop and spills).  Layout of a tile: [t][g = r >> 2][lane][4] -- a lane's four
+// consecutive accumulator registers are ONE 16-byte word, a wave instruction moves 1 KB contiguous: 16 vector-memory
+// instructions per activation instead of 64 (round 3; a vector-memory instruction costs ~10 issue cycles on the SIMD).
 template <int NTL>
 __device__ __forceinline__ void stash_put(float* __restrict__ base, int lane, const f32x16 (&a)[NTL]) {
-    int off = lane;
+    int off = lane * 4;
     asm volatile("" : "+v"(off));
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) base[(t * 16 + r) * 64 + off] = a[t][r];
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(base + (t * 4 + g) * 256 + off) = make_float4(a[t][4 * g], a[t][4 * g + 1], a[t][4 * g + 2], a[t][4 * g + 3]);
 }
 template <int NTL>
 __device__ __forceinline__ void stash_get(const float* __restrict__ base, int lane, f32x16 (&a)[NTL]) {
-    int off = lane;
+    int off = lane * 4;
     asm volatile("" : "+v"(off));
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[t][r] = base[(t * 16 + r) * 64 + off];
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (t * 4 + g) * 256 + off);
+            a[t][4 * g] = v.x; a[t][4 * g + 1] = v.y; a[t][4 * g + 2] = v.z; a[t][4 * g + 3] = v.w;
+        }
+}
+// NP consecutive registers r0 .. r0 + NP - 1 (r0 and NP multiples of 4) of tile t of a stashed activation: NP / 4 16-byte loads
+template <int NP>
+__device__ __forceinline__ void stash_fetch(const float* __restrict__ tile, int t, int r0, int lane, float (&v)[NP]) {
+    static_assert(NP % 4 == 0, "whole 16-byte words");
+    const float* p = tile + (t * 4 + (r0 >> 2)) * 256 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < NP / 4; ++q) {
+        const float4 w = *reinterpret_cast<const float4*>(p + q * 256);
+        v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+    }
 }
 
 // ---- B-operand sources: NP consecutive registers r0..r0+NP-1 of tile t of the accumulator-layout activation tile of
 // wave `ow`, for this lane.  Any wave can produce any tile's elements, so the eight waves share the publishing work.
 // (Rounds 1-2 also had sources that RECOMPUTED a first-layer activation from the group's states; since round 3 those
 // activations come from the stash like every other.)
-struct StashB {   // a hidden activation stashed by the forward: [wave tile][t][16][64]
+struct StashB {   // a hidden activation stashed by the forward: [wave tile][t][4][64][4] (stash_put)
     const float* base;   // stash of the group's first tile, at the wanted activation
     int tile_stride;     // floats between consecutive tiles
     template <int NP>
     __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, float (&v)[NP]) const {
-        const float* p = base + (size_t)ow * tile_stride + (t * 16 + r0) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) v[i] = p[i * 64];
+        stash_fetch<NP>(base + (size_t)ow * tile_stride, t, r0, lane, v);
     }
 };
 struct StateB {   // the raw state columns [col0, col0+Din) padded with zeros to one 32-feature tile
@@ -397,9 +412,7 @@ struct CatStashB {   // tiles [0,T): other_net's first-layer activation (stash r
     int tile_stride;
     template <int NP>
     __device__ __forceinline__ void fetch(int ow, int t, int r0, int lane, float (&v)[NP]) const {
-        const float* p = (t < T ? o : i) + (size_t)ow * tile_stride + ((t < T ? t : t - T) * 16 + r0) * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) v[k] = p[k * 64];
+        stash_fetch<NP>((t < T ? o : i) + (size_t)ow * tile_stride, t < T ? t : t - T, r0, lane, v);
     }
 };
 
@@ -624,6 +637,8 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
         __syncthreads();  // the previous group's backward is done with W / X
         // the forward images, in the order the layers read them; each layer waits for its own (see the forward below)
         constexpr int NI_TT = T * T * 1024 / (kFusedThreads * 4), NI_TH = T * H * 1024 / (kFusedThreads * 4);   // 8 KB pieces
+        constexpr int kStashOps = T * 4;   // vector-memory instructions of one stash_put (vmcnt is an in-order 6-bit counter: the
+        //                                   counted waits below name how many YOUNGER operations may stay outstanding)
         static_assert(T * H * 1024 % (kFusedThreads * 4) == 0, "image = whole 8 KB pieces");
         if constexpr (MODULAR) {
             dma_image<NI_TH>(X, a.img_fwd + L.off[1], tid);
@@ -672,17 +687,16 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
                 layer_mfma_in<T, H, 2, 1>(X, lds + F.bias[0], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[0]));
                 stash_put<T>(st1, lane, a0);                         // h_o1 (activated in place by the layer above)
             }
-            // (vmcnt is a 6-bit in-order counter: with T * 16 stash stores younger than the image DMAs, "all but the 63 youngest
-            //  done" is the weakest encodable wait that covers the DMAs; it forces at most one store, issued a layer ago)
+            // (counted waits: the stash stores issued since are YOUNGER than the image DMAs and may stay in flight)
             {
                 f32x16 a0[T];
                 PIME_NO_HOIST();
                 layer_first<T, 2>(lds + F.first1, xl + Do, a.Di, h, a0);
-                wait_dma_then_barrier<(NI_TT + T * 16 < 63 ? NI_TT + T * 16 : 63)>();   // integrator_net.2's
+                wait_dma_then_barrier<NI_TT + kStashOps>();   // integrator_net.2's: net.0's pieces and other_net's stash stores are younger
                 layer_mfma_in<T, H, 2, 1>(X + T * H * 1024, lds + F.bias[1], lane, a0, *reinterpret_cast<f32x16(*)[H]>(&cat[H]));
                 stash_put<T>(st2, lane, a0);                         // h_i1
             }
-            wait_dma_then_barrier<(2 * T * 16 < 63 ? 2 * T * 16 : 63)>();   // net.0's (older than every stash store)
+            wait_dma_then_barrier<2 * kStashOps>();   // net.0's (older than both towers' stash stores)
             layer_mfma_in<T, T, 1, 1>(wbuf, lds + F.bias[2], lane, cat, hl);   // cat: tanh applied in place
             stash_put<T>(st, lane, cat);
             PIME_NO_HOIST();
@@ -696,9 +710,9 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
                 layer_mfma_in<T, T, 2, ACT>(wbuf, lds + F.bias[0], lane, a0, a1);
                 stash_put<T>(st1, lane, a0);                         // H1 (activated in place by the layer above)
             }
-            // net.4's image (older than the T * 16 stash stores just issued: see the note on vmcnt in the modular branch); every
+            // net.4's image (older than the stash stores just issued, which may stay in flight); every
             // wave is done with net.2's (wbuf)
-            wait_dma_then_barrier<(T * 16 < 63 ? T * 16 : 63)>();
+            wait_dma_then_barrier<kStashOps>();
             if constexpr (DX_FIRST) dma_image<NI_TT>(wbuf, a.img_bwd + Lb.off[2], tid);
             layer_mfma_in<T, T, ACT, ACT>(X, lds + F.bias[1], lane, a1, hl);     // a1 (H2): activated in place
             stash_put<T>(st, lane, a1);
@@ -779,9 +793,9 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
             }
         }
         // ---------------------------------------------------------------------------------- backward + weight gradients
-        // forward images dead; net.4's transposed image is in: the only vector-memory operations issued after its DMA are the T * 16
-        // stash stores (vmcnt is a 6-bit counter: at most 63 may stay outstanding)
-        if constexpr (DX_FIRST) wait_dma_then_barrier<(T * 16 < 63 ? T * 16 : 63)>();
+        // forward images dead; net.4's transposed image is in: the only vector-memory operations issued after its DMA are the
+        // stash stores of H2, which may stay outstanding
+        if constexpr (DX_FIRST) wait_dma_then_barrier<kStashOps>();
         else __syncthreads();                                  // forward images dead, stash visible to the whole workgroup
         PIME_MARK(3);
         float* const sl = a.slab + (size_t)bid * a.slab_stride;   // this workgroup's partial gradients
