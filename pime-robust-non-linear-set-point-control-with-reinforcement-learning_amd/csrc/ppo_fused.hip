@@ -64,24 +64,20 @@ __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
     int o = 0;
     auto seg = [&](int& f, int floats) { f = o; o = align4(o + floats); };
     const int md = T * 32;
+    // Everything whose size depends on the state width comes LAST: the offsets in front are then compile-time constants in the
+    // kernels (T and the kind are template parameters) -- immediates in the ds instructions instead of live scalars.
     if (kind == MLP_MODULAR_ACTOR) {
-        const int Do = D - Di, H = T / 2;
-        seg(F.first0, md * (Do + 1));
-        seg(F.first1, md * (Di + 1));
+        const int H = T / 2;
         seg(F.bias[0], H * 32);
         seg(F.bias[1], H * 32);
         seg(F.bias[2], md);
     } else {
-        seg(F.first0, md * (D + 1));
-        F.first1 = 0;
         seg(F.bias[0], md);
         seg(F.bias[1], md);
         F.bias[2] = 0;
     }
     seg(F.headw, md);
     seg(F.headb, 4);
-    seg(F.xs, kFusedWaves * 32 * D);   // the group's gathered states [wave][sample][D]
-    seg(F.xsp, kFusedWaves * 32 * first_valu_pad(D));   // the same rows padded to 4 / 8 floats: (x, 1, 0 ..) for first_grad_valu
     seg(F.hacc, kFusedWaves * md);     // per-wave head weight gradients (summed in wave order at the end)
     seg(F.wsum, kFusedWaves * 6 * 2);  // per-wave float64 totals of the scalar sums
     seg(F.wbuf, T * T * 1024);
@@ -91,6 +87,16 @@ __host__ __device__ inline FusedLds fused_lds(int kind, int D, int Di, int T) {
     const int need3 = 2 * (tsize(T) + bsize(2 * T)) - T * T * 1024, need1 = 2 * (tsize(2 * T) + bsize(1)) - T * T * 1024;
     if (kind == MLP_MODULAR_ACTOR) xf = xf > need3 ? (xf > need1 ? xf : need1) : (need3 > need1 ? need3 : need1);
     seg(F.x, xf);
+    seg(F.xsp, kFusedWaves * 32 * first_valu_pad(D));   // the group's rows padded to 4 / 8 floats: (x, 1, 0 ..) for first_grad_valu
+    seg(F.xs, kFusedWaves * 32 * D);   // the group's gathered states [wave][sample][D]
+    if (kind == MLP_MODULAR_ACTOR) {
+        const int Do = D - Di;
+        seg(F.first0, md * (Do + 1));
+        seg(F.first1, md * (Di + 1));
+    } else {
+        seg(F.first0, md * (D + 1));
+        F.first1 = 0;
+    }
     F.total = o;
     return F;
 }
@@ -525,14 +531,53 @@ __device__ __forceinline__ float half_sum_dpp(float v) {
     return v;
 }
 
+// Sums over the 32 lanes of a half for SIXTEEN registers at once (the head weight gradient: one register = one feature, a lane =
+// one sample).  Sixteen separate DPP ladders cost 80 vector instructions; here every level adds a PAIR of registers into one, each
+// lane group keeping the partner's sum of the register it "owns", so the register count halves from level to level:
+//   rows (16 lanes):   v_permlane16_swap + add                 16 -> 8 registers, 2 instructions per pair
+//   8-lane groups:     x + ror8(x) for both, masked dpp select  8 -> 4, 3 per pair
+//   banks (4 lanes):   x + half_mirror(x), masked dpp select    4 -> 2, 3 per pair
+//   quad:              two quad_perm adds on the last 2 registers
+// = 38 instructions.  Result: out[k] (k = 0, 1) in lane li holds the sum over the half's 32 lanes of register
+// 8 k + 4 bit2(li) + 2 bit3(li) + bit4(li), the same value in the four lanes of a quad.  Fixed order: reproducible.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <int BANK_MASK>
+__device__ __forceinline__ float dpp_select(float old, float v) {   // v in the banks of the mask, old elsewhere
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0xe4, 0xf, BANK_MASK, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_full(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void half_sums16(const float (&p)[16], float (&out)[2]) {
+    float a8[8], a4[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // rows 0 / 2 keep p[2i]'s sum over the row pair, rows 1 / 3 p[2i+1]'s
+        const u32x2_t sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[2 * i]), __float_as_uint(p[2 * i + 1]), false, false);
+        a8[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)     // lanes 0-7 of a row: a8[2i] + its lane 8 apart; lanes 8-15: a8[2i+1]
+        a4[i] = dpp_select<0xc>(dpp_add_full<0x128>(a8[2 * i]), dpp_add_full<0x128>(a8[2 * i + 1]));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // banks 0 / 2: a4[2i] + its mirror inside the 8 lanes; banks 1 / 3: a4[2i+1]
+        float v = dpp_select<0xa>(dpp_add_full<0x141>(a4[2 * i]), dpp_add_full<0x141>(a4[2 * i + 1]));
+        v = dpp_add_full<0xb1>(v);  // quad_perm [1,0,3,2]
+        out[i] = dpp_add_full<0x4e>(v);  // quad_perm [2,3,0,1]
+    }
+}
+
+// TRACE = false compiles the marks out (the dual kernel: the trace pointers and the traced workgroup's index are live scalars of the
+// whole body otherwise)
 #define PIME_MARK(i)                                                             \
     do {                                                                         \
-        if (a.trace && bid == a.trace_wg && threadIdx.x == 0) a.trace[i] = wall_clock64(); \
+        if constexpr (TRACE)                                                     \
+            if (a.trace && bid == a.trace_wg && threadIdx.x == 0) a.trace[i] = wall_clock64(); \
     } while (0)
 
 // bid / nb: this workgroup's index among the nb workgroups that work on THIS net (ppo_fused_kernel: the grid; ppo_fused_dual_kernel:
 // the net's share of a grid that serves both nets)
-template <int T, int KIND>
+template <int T, int KIND, bool TRACE>
 __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restrict__ lds, const int bid, const int nb) {
     constexpr bool MODULAR = KIND == MLP_MODULAR_ACTOR;
     constexpr bool CRITIC = KIND == MLP_CRITIC;
@@ -554,7 +599,8 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
     const int Do = a.D - a.Di;
 
     PIME_MARK(0);
-    if (a.trace_span && threadIdx.x == 0 && bid < 512) a.trace_span[2 * bid] = wall_clock64();
+    if constexpr (TRACE)
+        if (a.trace_span && threadIdx.x == 0 && bid < 512) a.trace_span[2 * bid] = wall_clock64();
     const float asl = CRITIC ? 0.f : a.a_std_log[0];
     for (int e = tid; e < kFusedWaves * md; e += kFusedThreads) hacc[e] = 0.f;
     // small segments live in LDS for the whole kernel.  All their loads are issued before the first LDS write: one
@@ -780,14 +826,19 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
             for (int t = 0; t < T; ++t) {
                 PIME_NO_HOIST();
                 f32x16 dl;
-                float hwv[16];
+                float hwv[16], prod[16], hs[2];
                 load16(vec_at<T>(hw, t, h), hwv);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float hv = hl[t][r];
                     dl[r] = hwv[r] * dout * act_grad_from_output<ACT>(hv);   // head_backward . act'
-                    const float hs = half_sum_dpp(dout * hv);
-                    if (li == 31) hacc[wave * md + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] += hs;   // own slots: reproducible
+                    prod[r] = dout * hv;
+                }
+                half_sums16(prod, hs);   // hs[k]: register r = 8 k + 4 bit2(li) + 2 bit3(li) + bit4(li), feature (r&3) + 8 (r>>2) + 4h
+                if ((li & 3) == 0) {     // own slots: reproducible
+                    float* q = hacc + wave * md + t * 32 + 4 * h + ((li >> 3) & 1) * 2 + ((li >> 4) & 1) + 8 * ((li >> 2) & 1);
+                    q[0] += hs[0];
+                    q[16] += hs[1];
                 }
                 hl[t] = dl;
             }
@@ -828,7 +879,7 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
                 PIME_NO_HOIST();
                 dw_rounds<T, 2 * T, CatStashB<T>, CatPlan<T>>(
                     wbuf, lane, wave, dcat, CatStashB<T>{st1_0, st2_0, T * 1024},
-                    acc, bsum, nullptr, nullptr, 0, (a.trace && bid == a.trace_wg) ? a.trace + 16 : nullptr);
+                    acc, bsum, nullptr, nullptr, 0, (TRACE && a.trace && bid == a.trace_wg) ? a.trace + 16 : nullptr);
                 const CatPlan<T> pl(wave);
                 if (pl.active) {
                     const int br = pl.ao >= H ? 1 : 0;
@@ -951,7 +1002,7 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
                 PIME_NO_HOIST();
                 dw_rounds<T, T>(X, lane, wave, d2, StashB{st1_0, T * 1024}, acc, bsum,
                                 DX_FIRST ? nullptr : wbuf, DX_FIRST ? nullptr : a.img_bwd + Lb.off[3], DX_FIRST ? 0 : T * T * 256,
-                                (a.trace && bid == a.trace_wg) ? a.trace + 16 : nullptr);
+                                (TRACE && a.trace && bid == a.trace_wg) ? a.trace + 16 : nullptr);
                 dw_store_full<T, T>(lane, wave, acc, bsum, sl + a.poff[2], sl + a.poff[3], accum);      // net.2
             }
             PIME_LDS_BARRIER();
@@ -976,7 +1027,8 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
     }
 
     PIME_MARK(12);
-    if (a.trace_span && threadIdx.x == 0 && bid < 512) a.trace_span[2 * bid + 1] = wall_clock64();
+    if constexpr (TRACE)
+        if (a.trace_span && threadIdx.x == 0 && bid < 512) a.trace_span[2 * bid + 1] = wall_clock64();
     // ---- workgroup totals of the scalar sums, combined in a fixed order (the slabs make the gradients reproducible
     // bit for bit; only the loss sums, which are for logging, use atomics)
     __syncthreads();
@@ -1007,7 +1059,7 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
 template <int T, int KIND>
 __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    ppo_fused_body<T, KIND>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+    ppo_fused_body<T, KIND, true>(a, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Both nets of an optimizer step in ONE launch: workgroups [0, na) run the actor's body, [na, na + nc) the critic's.  The two
@@ -1020,8 +1072,8 @@ template <int T, int AKIND>
 __global__ __launch_bounds__(kFusedThreads) void ppo_fused_dual_kernel(PpoArgs actor, PpoArgs critic, int na) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = (int)blockIdx.x;
-    if (b < na) ppo_fused_body<T, AKIND>(actor, lds, b, na);
-    else ppo_fused_body<T, MLP_CRITIC>(critic, lds, b - na, (int)gridDim.x - na);
+    if (b < na) ppo_fused_body<T, AKIND, false>(actor, lds, b, na);
+    else ppo_fused_body<T, MLP_CRITIC, false>(critic, lds, b - na, (int)gridDim.x - na);
 }
 
 // ==================================================================================================== slab reduction
