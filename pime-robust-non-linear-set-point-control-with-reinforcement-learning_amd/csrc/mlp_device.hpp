@@ -170,6 +170,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);   // (explicit fma: the library is built with -ffp-contract=off)
 }
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));   // packed f32 pairs (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32)
+
 template <int ACT>
 __device__ __forceinline__ float activate(float v) {
     if constexpr (ACT == 0) return v > 0.f ? v : 0.f;  // nn.ReLU

@@ -216,10 +216,12 @@ struct DwPlan {
     int ao, bi0;
     bool active;  // with fewer blocks than waves the spare waves only help publishing (every output element has ONE
                   // owner lane, so the partial gradients can be plain stores)
+    bool bias;    // this wave stores the bias gradient of its A tile (the first of the waves that share the tile)
     __device__ __forceinline__ explicit DwPlan(int wave) {
         const int b0 = wave * PER;
         active = b0 < NBLK;
         ao = active ? b0 / BT : 0; bi0 = active ? b0 % BT : 0;
+        bias = active && bi0 == 0;
     }
 };
 
@@ -242,7 +244,7 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
     for (int n = 0; n < PER; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    bsum = 0.f;
+    f32x2_t bs2 = {0.f, 0.f};   // bias gradient: the A operands summed, two k-steps per v_pk_add_f32, on the wave that stores it only
     const int per4 = stage_n4 / kFusedWaves;
     const float4* src4 = reinterpret_cast<const float4*>(stage_src);
     float4* dst4 = reinterpret_cast<float4*>(stage_dst);
@@ -301,7 +303,10 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
 #pragma unroll
                 for (int n = 0; n < PER; ++n)
                     acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[n][s], acc[n], 0, 0, 0);
-                bsum += av[s];
+            }
+            if (pl.bias) {
+#pragma unroll
+                for (int s = 0; s < NKS; s += 2) bs2 += f32x2_t{av[s], av[s + 1]};
             }
             if (stamping) {
                 float sink;
@@ -317,6 +322,7 @@ __device__ __forceinline__ void dw_rounds(float* __restrict__ X, int lane, int w
         PIME_STAMP(3);   // B publish, staging write
     }
 #undef PIME_STAMP
+    bsum = bs2.x + bs2.y;
     if (tr && tid == 0) {
         tr[8] = wall_clock64();
         for (int k = 0; k < 5; ++k) tr[16 + k] = (long long)tsum[k];
@@ -403,13 +409,14 @@ struct CatPlan {
     static constexpr int NBLK = 2 * H * T;
     static constexpr int PER = NBLK >= kFusedWaves ? NBLK / kFusedWaves : 1;
     int ao, bi0;
-    bool active;
+    bool active, bias;
     __device__ __forceinline__ explicit CatPlan(int wave) {
         const int b0 = wave * PER;
         active = b0 < NBLK;
         const int branch = active ? b0 / (H * T) : 0, within = active ? b0 % (H * T) : 0;
         ao = branch * H + within / T;
         bi0 = branch * T + within % T;
+        bias = active && bi0 % T == 0;
     }
 };
 template <int T>
@@ -887,7 +894,7 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
 #pragma unroll
                     for (int n = 0; n < CatPlan<T>::PER; ++n)
                         block_store(acc[n], gW, md, (pl.ao - br * H) * 32, (pl.bi0 + n - br * T) * 32 + li, true, lane, accum);
-                    if (pl.bi0 % T == 0) bias_store(bsum, sl + a.poff[br ? 7 : 3] + (pl.ao - br * H) * 32, lane, accum);
+                    if (pl.bias) bias_store(bsum, sl + a.poff[br ? 7 : 3] + (pl.ao - br * H) * 32, lane, accum);
                 }
             }
             PIME_LDS_BARRIER();   // the rounds are done with the region
