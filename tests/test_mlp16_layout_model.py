@@ -34,3 +34,14 @@ def test_library_reports_width_256_support():
     assert L.pime_ppo_bwd_image_floats(nt.MLP_MODULAR_ACTOR, 4, 1, 256) == 2 * 256 * 256      # net.0^T + the two towers' 128 -> 256 transposes
     assert L.pime_ppo_workspace_floats(nt.MLP_MODULAR_ACTOR, 4096, 256) > 0
     assert L.pime_mlp_packed_floats(nt.MLP_CRITIC, 3, 0, 96) == 0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_head_gradient_butterfly_model(seed):
+    """tools/butterfly_model.py executes half_sums16's cross-lane steps (v_permlane16_swap, row_ror:8, row_half_mirror, quad_perm,
+    bank-masked selects) on 64-lane arrays: every lane's two results are the 32-lane sums of the registers the kernel says it owns,
+    and the writer lanes cover each of the 32 features of a tile exactly once (csrc/ppo_fused.hip: head weight gradient)."""
+    spec = importlib.util.spec_from_file_location("butterfly_model", os.path.join(ROOT, "tools", "butterfly_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.self_check(seed)
