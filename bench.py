@@ -689,12 +689,14 @@ def main():
     if ro_key in ks:   # fused rollout: policy forward + noise + env step + buffer writes for a whole episode per launch
         n_env, ms_env = ks[ro_key]
         ro_tf = MLP_FLOPS_PER_ROW["modular_actor"] * LANES * T_EP / (ms_env * 1e-3) / 1e12
-        roofline_env = {"kernel": "rollout_ph_kernel<4, modular_actor> (16384 lanes x 50 steps per launch)", "bound": "mfma",
+        roofline_env = {"kernel": "rollout_kernel<4, modular_actor, pH, 16-lane tiles> (16384 lanes x 50 steps per launch)", "bound": "mfma",
                         "achieved": ro_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ro_tf / F32_MFMA_PEAK_TFLOPS,
                         "traffic": None, "avg_launch_ms": ms_env,
-                        "note": "one 32-lane tile per SIMD, serial 512-MFMA chain per env step: latency bound by design; the "
-                                "step-per-launch env kernels move 5.1 TB/s (pH) / 3.1 TB/s (WT) of PMC-counted HBM traffic at 4M "
-                                "lanes, profiles/r02_p_env_pmc.json"}
+                        "note": "one 16-lane tile per wave, one wave on each of the 1 024 SIMDs, a serial chain of 512 "
+                                "v_mfma_f32_16x16x4_f32 (6.8 us) per env step plus the env arithmetic: latency bound by design "
+                                "(round 3: 32-lane tiles left half of the SIMDs idle, 1.20 ms -> 0.69 ms per launch); the "
+                                "step-per-launch env kernels move 5.4 TB/s (pH) / 4.6 TB/s (WT) of PMC-counted HBM traffic at 4M "
+                                "lanes, profiles/r03_e_env_pmc.json"}
     else:
         n_env, ms_env = ks["ph_step_kernel (fused residual)"]
         env_gbs = PH_STEP_BYTES * LANES / (ms_env * 1e-3) / 1e9

@@ -10,6 +10,7 @@
 // tiles spread over all 256 CUs with one wave per SIMD: per step a wave is latency-bound on its own 3-layer MFMA chain
 // (512 MFMAs x 64 cycles), so sharing a SIMD would only stretch the episode.
 // The env arithmetic is env_device.hpp -- literally the code of ph_step_kernel / ph_reset_kernel.
+#include <cstdlib>
 #include "env_device.hpp"
 #include "rollout.hpp"
 #include "rollout_policy.hpp"
@@ -19,6 +20,7 @@ namespace pime {
 constexpr uint32_t STREAM_EXPLORE = 2;
 
 constexpr int kRolloutThreads = 128;
+constexpr int kRolloutNarrowThreads = 256;
 
 __device__ __forceinline__ PhPtrs<float, half_t> with_half_I(const PhPtrs<float>& s, half_t* I16) {
     PhPtrs<float, half_t> h{};
@@ -38,8 +40,11 @@ __device__ __forceinline__ float through_half(float v) { return (float)(half_t)v
 // [h1, h2, r], oldest first (nonlinear_watertank.py:1056-1208).  For ENV 2 the observation registers ARE the frame deque: a step
 // shifts them by one frame and appends the new one, a reset fills every frame with the first (:1181-1183); the SoA ring in HBM
 // is only written back when the launch ends.
-template <int T, int KIND, int ENV, int STACK>
-__global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a) {
+// NARROW: 16 lanes per wave (four workgroup waves, policy_forward16) -- every SIMD has a wave when the 32-lane tiles of a launch
+// would cover only half of them, and a layer's serial MFMA chain is half as long.  Same image, same env code, same Philox keys (the
+// noise of a lane does not depend on the tiling); the policy mean differs in the last bits (another summation order).
+template <int T, int KIND, int ENV, int STACK, bool NARROW = false>
+__global__ __launch_bounds__(NARROW ? kRolloutNarrowThreads : kRolloutThreads) void rollout_kernel(RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), Di = ENV == 2 ? 0 : 1;
     static_assert(ENV != 2 || KIND == MLP_PLAIN_ACTOR, "the Stacking observation has no integrator column: plain actors only");
@@ -48,10 +53,11 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int N = a.n;
-    const int m = (blockIdx.x * (kRolloutThreads / 64) + wave) * 32 + (lane & 31);
+    constexpr int LW = NARROW ? 16 : 32, WAVES = (NARROW ? kRolloutNarrowThreads : kRolloutThreads) / 64;   // env lanes per wave
+    const int m = (blockIdx.x * WAVES + wave) * LW + (lane & (LW - 1));
     const bool valid = m < N;
     const int i = valid ? m : N - 1;  // idle lanes shadow the last env (compute, never store)
-    const bool writer = valid && h == 0;
+    const bool writer = valid && (NARROW ? (lane >> 4) == 0 : h == 0);   // the lane groups carry copies of the same envs
     const uint32_t gid = a.env_offset + (uint32_t)i;
     const float sigma = __expf(a.a_std_log[0]);
 
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
     for (int j = 0; j < D; ++j) obs[j] = h16 ? (float)a.state_h[(size_t)D * i + j] : a.state[(size_t)D * i + j];
     for (int t = 0; t < a.n_steps; ++t) {
         PIME_NO_HOIST();
-        const float a_avg = policy_forward<T, KIND, D, Di>(lds, L, obs, lane);
+        const float a_avg = NARROW ? policy_forward16<T, KIND, D, Di>(lds, L, obs, lane) : policy_forward<T, KIND, D, Di>(lds, L, obs, lane);
         // exploration noise eps ~ N(0,1): Box-Muller on a Philox pair keyed by the global lane (net_residual.py:178)
         double ua, ub;
         philox_pair(a.noise_seed, gid, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE, ua, ub);
@@ -147,17 +153,28 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(RolloutArgs a)
 int mlp_check(int kind, int D, int Di, int md);
 int launch_rollout16(int kind, const RolloutArgs& a, hipStream_t s);   // width 256: the streamed 16-tile family (mlp16.hip)
 
-template <int T, int KIND, int ENV, int STACK>
-static int launch_rollout_t(const RolloutArgs& a, hipStream_t s) {
+// 16-lane tiles when 32-lane tiles would leave SIMDs without a wave (n <= 16 384 on 1 024 SIMDs); PIME_ROLLOUT_NARROW=0 / 1 forces
+// either (A/B, tests)
+static bool narrow_tiles(int n) {
+    if (const char* e = std::getenv("PIME_ROLLOUT_NARROW")) return std::atoi(e) != 0;   // read per launch: tests flip it
+    return (n + 31) / 32 <= 512;
+}
+
+template <int T, int KIND, int ENV, int STACK, bool NARROW>
+static int launch_rollout_n(const RolloutArgs& a, hipStream_t s) {
     const MlpLayout L = mlp_layout(KIND, ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), ENV == 2 ? 0 : 1, T * 32);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);
     static LdsLimit lds_limit;  // per instantiation
-    PIME_RAISE_LDS(lds_limit, (rollout_kernel<T, KIND, ENV, STACK>), 160 * 1024);
-    const int tiles = (a.n + 31) / 32, per_wg = kRolloutThreads / 64;
-    hipLaunchKernelGGL((rollout_kernel<T, KIND, ENV, STACK>), dim3((tiles + per_wg - 1) / per_wg), dim3(kRolloutThreads),
-                       lds_bytes, s, a);
+    PIME_RAISE_LDS(lds_limit, (rollout_kernel<T, KIND, ENV, STACK, NARROW>), 160 * 1024);
+    constexpr int threads = NARROW ? kRolloutNarrowThreads : kRolloutThreads, per_wg = threads / 64 * (NARROW ? 16 : 32);
+    hipLaunchKernelGGL((rollout_kernel<T, KIND, ENV, STACK, NARROW>), dim3((a.n + per_wg - 1) / per_wg), dim3(threads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
+}
+template <int T, int KIND, int ENV, int STACK>
+static int launch_rollout_t(const RolloutArgs& a, hipStream_t s) {
+    if (narrow_tiles(a.n)) return launch_rollout_n<T, KIND, ENV, STACK, true>(a, s);
+    return launch_rollout_n<T, KIND, ENV, STACK, false>(a, s);
 }
 
 int launch_rollout(int kind, int md, const RolloutArgs& a, hipStream_t s) {

@@ -25,6 +25,7 @@ from rollout_replay import DEV, make_agent, replay_through_oracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("tiles", ["wide", "narrow"])   # 32- / 16-lane tiles per wave (csrc/rollout.hip: NARROW; widths <= 128)
 @pytest.mark.parametrize("env_name,algo,N,md", [
     ("PH_V35", "ResidualIntegratorModularPPO", 16384, 128),   # the bench configuration
     ("PH_V35", "ResidualPPO", 16384, 128),
@@ -41,8 +42,13 @@ pytestmark = pytest.mark.gpu
     ("PH_V35", "ResidualPPO", 512, 256),
     ("WT_STACKING4", "PPO", 256, 256),
 ])
-def test_fused_rollout_replays_through_oracle(env_name, algo, N, md):
+def test_fused_rollout_replays_through_oracle(env_name, algo, N, md, tiles, monkeypatch):
     import oracle
+    if md == 256:
+        if tiles == "narrow":
+            pytest.skip("width 256 has one kernel (the streamed 16-tile family)")
+    else:   # the library picks 16-lane tiles for n <= 16 384 by itself; both kernels must replay
+        monkeypatch.setenv("PIME_ROLLOUT_NARROW", "1" if tiles == "narrow" else "0")
     from pime_amd import gym_control
     from pime_amd.elegantrl.run import make_buffer
     is_ph = env_name == "PH_V35"
