@@ -40,7 +40,7 @@ __device__ __forceinline__ float through_half(float v) { return (float)(half_t)v
 // [h1, h2, r], oldest first (nonlinear_watertank.py:1056-1208).  For ENV 2 the observation registers ARE the frame deque: a step
 // shifts them by one frame and appends the new one, a reset fills every frame with the first (:1181-1183); the SoA ring in HBM
 // is only written back when the launch ends.
-// NARROW: 16 lanes per wave (four workgroup waves, policy_forward16) -- every SIMD has a wave when the 32-lane tiles of a launch
+// NARROW (the default): 16 lanes per wave (four workgroup waves, policy_forward16) -- every SIMD has a wave where the 32-lane tiles of a launch
 // would cover only half of them, and a layer's serial MFMA chain is half as long.  Same image, same env code, same Philox keys (the
 // noise of a lane does not depend on the tiling); the policy mean differs in the last bits (another summation order).
 template <int T, int KIND, int ENV, int STACK, bool NARROW = false>
@@ -153,11 +153,13 @@ __global__ __launch_bounds__(NARROW ? kRolloutNarrowThreads : kRolloutThreads) v
 int mlp_check(int kind, int D, int Di, int md);
 int launch_rollout16(int kind, const RolloutArgs& a, hipStream_t s);   // width 256: the streamed 16-tile family (mlp16.hip)
 
-// 16-lane tiles when 32-lane tiles would leave SIMDs without a wave (n <= 16 384 on 1 024 SIMDs); PIME_ROLLOUT_NARROW=0 / 1 forces
-// either (A/B, tests)
-static bool narrow_tiles(int n) {
+// 16-lane tiles by default, whatever the lane count: the image fills LDS, so a compute unit holds ONE workgroup -- four waves of 16
+// lanes give each of its SIMDs a wave with half the serial chain of a 32-lane tile, where the 32-lane workgroup (two waves) leaves
+// two SIMDs idle at any launch size.  One kernel for every n also keeps a lane's trajectory independent of how the lanes are sharded
+// over ranks (tests/test_gpu_config4.py).  PIME_ROLLOUT_NARROW=0 selects the 32-lane tiles (A/B, and the tests replay both).
+static bool narrow_tiles(int) {
     if (const char* e = std::getenv("PIME_ROLLOUT_NARROW")) return std::atoi(e) != 0;   // read per launch: tests flip it
-    return (n + 31) / 32 <= 512;
+    return true;
 }
 
 template <int T, int KIND, int ENV, int STACK, bool NARROW>

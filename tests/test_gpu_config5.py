@@ -119,9 +119,13 @@ def test_config5_mixed16_rank_slice_rollout_and_update():
     ph.close(); wt.close()
 
 
-def test_config5_stepwise_half_rollout_matches_fused():
+@pytest.mark.parametrize("tiles", ["wide", "narrow"])
+def test_config5_stepwise_half_rollout_matches_fused(tiles, monkeypatch):
     """The launch-by-launch form (policy forward + pime_env_step_residual_h per lock-step, what a shape without a fused rollout
-    takes) writes the same binary16 trajectory as the fused kernel when fed the same exploration noise."""
+    takes) writes the same binary16 trajectory as the fused kernel when fed the same exploration noise.  32-lane tiles run the
+    forward kernel's own MFMA chain; the default 16-lane tiles sum in another order, and a last-bit difference of a policy mean now
+    and then moves a binary16 row by one ulp (1e-3 relative), which the next policy means see: looser bounds there."""
+    monkeypatch.setenv("PIME_ROLLOUT_NARROW", "1" if tiles == "narrow" else "0")
     from pime_amd import gym_control
     from pime_amd.elegantrl.run import make_buffer
     N = 1024
@@ -141,7 +145,7 @@ def test_config5_stepwise_half_rollout_matches_fused():
     assert torch.equal(a.done, b.done)
     # the step-wise policy mean comes from mlp_forward_kernel, the fused one from the rollout kernel's own chain: same weights,
     # same order of operations up to the MFMA accumulation order -> actions agree to rounding, rows to a binary16 ulp
-    assert float((a.action - b.action).abs().max()) <= 3e-5
+    assert float((a.action - b.action).abs().max()) <= (3e-5 if tiles == "wide" else 5e-4)
     same = (a.state[:50] == b.state[:50]).float().mean().item()
-    assert same > 0.995, f"only {same:.4f} of the binary16 rows are bit-equal"
+    assert same > (0.995 if tiles == "wide" else 0.99), f"only {same:.4f} of the binary16 rows are bit-equal"
     np.testing.assert_allclose(a.state[:50].float().cpu().numpy(), b.state[:50].float().cpu().numpy(), rtol=2 * H, atol=0.03)

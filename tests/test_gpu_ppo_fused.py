@@ -212,8 +212,9 @@ def test_fused_rollout_matches_stepwise_rollout(env_name, algo):
     the step-wise agent replays the noise the fused kernel drew (noise_hook), the envs share seed and Philox streams
     (resets AND water-tank process noise), so states / actions / rewards / done flags must agree step for step over
     two episodes (auto-reset in between).  The env arithmetic is literally the same device functions
-    (csrc/env_device.hpp); the policy mean is the same MFMA code; what differs is f32 rounding of `a_avg + eps*sigma`,
-    i.e. ulps -> for pH 'within one LUT cell' on rare lanes, which are dropped once they diverge."""
+    (csrc/env_device.hpp); the policy mean comes from two MFMA chains with different summation orders (16-lane tiles in the
+    fused kernel, 32-lane tiles in the forward kernel), i.e. ulps -> for pH 'within one LUT cell' on rare lanes, which are dropped
+    once they diverge."""
     from pime_amd import gym_control
     from pime_amd.elegantrl.run import make_buffer
     from pime_amd.utils import MODELS
@@ -260,12 +261,18 @@ def test_fused_rollout_matches_stepwise_rollout(env_name, algo):
         fa, sa = f.action[t, :, 0].cpu().numpy(), s.action[t, :, 0].cpu().numpy()
         fs, ss = f.state[t + 1].cpu().numpy(), s.state[t + 1].cpu().numpy()
         np.testing.assert_allclose(fa[alive], sa[alive], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(f.reward[t].cpu().numpy()[alive], s.reward[t].cpu().numpy()[alive], rtol=3e-4, atol=3e-4)
-        if is_ph:
-            dy = np.abs(fs[:, 0] - ss[:, 0])
+        if is_ph:   # a lane whose action differs in the last bit may read the neighbouring titration cell at THIS step: its reward
+            dy = np.abs(fs[:, 0] - ss[:, 0])   # and next state differ from here on, so it leaves the comparison before they are checked
             if t not in (T - 1, 2 * T - 1):
                 assert dy[alive].max() <= 0.0297
             alive &= dy <= 1e-5
+        fr, sr = f.reward[t].cpu().numpy()[alive], s.reward[t].cpu().numpy()[alive]
+        if is_ph and t in (T - 1, 2 * T - 1):
+            # the episode's last step: state[t + 1] is the reset observation, so a cell flip of this step shows in the reward only
+            off = np.abs(fr - sr) > 3e-4 + 3e-4 * np.abs(sr)
+            assert off.mean() <= 0.005 and np.abs(fr - sr).max() <= 0.5, (off.mean(), np.abs(fr - sr).max())
+        else:
+            np.testing.assert_allclose(fr, sr, rtol=3e-4, atol=3e-4)
         np.testing.assert_allclose(fs[alive], ss[alive], rtol=1e-4, atol=1e-4)
     assert alive.mean() > 0.95
 

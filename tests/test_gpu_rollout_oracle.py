@@ -47,7 +47,7 @@ def test_fused_rollout_replays_through_oracle(env_name, algo, N, md, tiles, monk
     if md == 256:
         if tiles == "narrow":
             pytest.skip("width 256 has one kernel (the streamed 16-tile family)")
-    else:   # the library picks 16-lane tiles for n <= 16 384 by itself; both kernels must replay
+    else:   # the library runs 16-lane tiles by default; both kernels must replay
         monkeypatch.setenv("PIME_ROLLOUT_NARROW", "1" if tiles == "narrow" else "0")
     from pime_amd import gym_control
     from pime_amd.elegantrl.run import make_buffer
