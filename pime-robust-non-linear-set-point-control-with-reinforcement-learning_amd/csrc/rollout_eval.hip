@@ -18,7 +18,7 @@
 
 namespace pime {
 
-constexpr int kEvalThreads = 128;
+constexpr int kEvalThreads = 256;   // four waves of 16 lanes: one per SIMD (16-lane tiles, rollout_policy.hpp: policy_forward16)
 
 template <int T, int KIND, int ENV, typename S>
 __global__ __launch_bounds__(kEvalThreads) void rollout_eval_kernel(EvalArgs<S> a) {
@@ -31,12 +31,12 @@ __global__ __launch_bounds__(kEvalThreads) void rollout_eval_kernel(EvalArgs<S> 
         stage_image(lds, a.img, L.total / 4);
         __syncthreads();
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int N = a.n;
-    const int m = (blockIdx.x * (kEvalThreads / 64) + wave) * 32 + (lane & 31);
+    const int m = (blockIdx.x * (kEvalThreads / 64) + wave) * 16 + (lane & 15);
     const bool valid = m < N;
     const int i = valid ? m : N - 1;  // idle lanes shadow the last env (compute, never store)
-    const bool writer = valid && h == 0;
+    const bool writer = valid && (lane >> 4) == 0;   // the four lane groups carry copies of the same 16 envs
     const uint32_t gid = a.env_offset + (uint32_t)i;
 
     PhLane<S> E{};
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kEvalThreads) void rollout_eval_kernel(EvalArgs<S> 
         double a_env = 0.0;                                                        // agent_residual.py:61 without the noise
 #pragma unroll
         for (int j = 0; j < D; ++j) a_env += (double)obs[j] * a.K.k[j];
-        if constexpr (POLICY) a_env = residual_tanh(policy_forward<T, KIND, D, 1>(lds, L, obs, lane)) + a_env;
+        if constexpr (POLICY) a_env = residual_tanh(policy_forward16<T, KIND, D, 1>(lds, L, obs, lane)) + a_env;
         double tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr5 = 0;
         float rew;
         if constexpr (ENV == 0) {
@@ -100,7 +100,7 @@ static int launch_eval_t(const EvalArgs<S>& a, hipStream_t s) {
         static LdsLimit lds_limit;  // per instantiation
         PIME_RAISE_LDS(lds_limit, (rollout_eval_kernel<T, KIND, ENV, S>), 160 * 1024);
     }
-    const int tiles = (a.n + 31) / 32, per_wg = kEvalThreads / 64;
+    const int tiles = (a.n + 15) / 16, per_wg = kEvalThreads / 64;
     hipLaunchKernelGGL((rollout_eval_kernel<T, KIND, ENV, S>), dim3((tiles + per_wg - 1) / per_wg), dim3(kEvalThreads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;

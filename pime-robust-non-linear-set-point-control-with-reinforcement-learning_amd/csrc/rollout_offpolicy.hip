@@ -17,7 +17,7 @@
 namespace pime {
 
 constexpr uint32_t STREAM_EXPLORE_OFFPOLICY = 2;   // = rollout.hip's STREAM_EXPLORE
-constexpr int kOffThreads = 128;
+constexpr int kOffThreads = 256;   // four waves of 16 lanes: one per SIMD (16-lane tiles, rollout_policy.hpp: policy_forward16)
 
 template <int T, int ENV>
 __global__ __launch_bounds__(kOffThreads) void rollout_offpolicy_kernel(OffPolicyArgs a) {
@@ -26,12 +26,12 @@ __global__ __launch_bounds__(kOffThreads) void rollout_offpolicy_kernel(OffPolic
     const MlpLayout L = mlp_layout(MLP_CRITIC, D, 0, T * 32);
     stage_image(lds, a.img, L.total / 4);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int N = a.n;
-    const int m = (blockIdx.x * (kOffThreads / 64) + wave) * 32 + (lane & 31);
+    const int m = (blockIdx.x * (kOffThreads / 64) + wave) * 16 + (lane & 15);
     const bool valid = m < N;
     const int i = valid ? m : N - 1;  // idle lanes shadow the last env (compute, never store)
-    const bool writer = valid && h == 0;
+    const bool writer = valid && (lane >> 4) == 0;   // the four lane groups carry copies of the same 16 envs
     const uint32_t gid = a.env_offset + (uint32_t)i;
 
     PhLane<float> E{};
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kOffThreads) void rollout_offpolicy_kernel(OffPolic
     int slot = a.slot0;
     for (int t = 0; t < a.n_steps; ++t) {
         PIME_NO_HOIST();
-        const float mean = policy_forward<T, MLP_CRITIC, D, 0>(lds, L, obs, lane);
+        const float mean = policy_forward16<T, MLP_CRITIC, D, 0>(lds, L, obs, lane);
         double ua, ub;
         philox_pair(a.noise_seed, gid, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE_OFFPOLICY, ua, ub);
         const float eps = (float)(sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586476925286766559 * ub));
@@ -92,7 +92,7 @@ static int launch_off_t(const OffPolicyArgs& a, hipStream_t s) {
     const size_t lds_bytes = (size_t)mlp_layout(MLP_CRITIC, ENV == 0 ? 3 : 4, 0, T * 32).total * sizeof(float);
     static LdsLimit lds_limit;  // per instantiation
     PIME_RAISE_LDS(lds_limit, (rollout_offpolicy_kernel<T, ENV>), 160 * 1024);
-    const int tiles = (a.n + 31) / 32, per_wg = kOffThreads / 64;
+    const int tiles = (a.n + 15) / 16, per_wg = kOffThreads / 64;
     hipLaunchKernelGGL((rollout_offpolicy_kernel<T, ENV>), dim3((tiles + per_wg - 1) / per_wg), dim3(kOffThreads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
