@@ -7,6 +7,10 @@ PIME_FORCE_DP=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PO
 python -c "import json,sys; d=json.loads(open('$OUT/${TAG}_bench_dp.json').read().strip().splitlines()[-1]); print('forced-DP (1 rank):', d['value'])"
 grep -i "refused\|graph" $OUT/${TAG}_bench_dp.err | head -3
 timeout -k 10 200 python bench.py --workload wt --no-cpu-baseline > $OUT/${TAG}_bench_water_tank.json 2>/dev/null || exit 1
+for w in wt_td3 wt256 wtmod256 mixed16; do   # the other workloads (BASELINE configs 2 / 5, the reference script's width 256)
+  timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $OUT/${TAG}_bench_$w.json 2>/dev/null || exit 1
+  python -c "import json; d=json.load(open('$OUT/${TAG}_bench_$w.json')); print('$w', round(d['value'] / 1e6, 2), 'M env-steps/s')"
+done
 timeout -k 10 300 bash tools/profile_bench.sh $TAG || exit 1
 timeout -k 10 400 bash tools/pmc_traffic.sh $OUT/${TAG}_pmc_hbm_traffic.json bench.py --steps 2 --warmup 1 --no-cpu-baseline || exit 1
 timeout -k 10 400 bash tools/env_pmc.sh $OUT/${TAG}_env_pmc.json || exit 1
