@@ -45,3 +45,14 @@ def test_head_gradient_butterfly_model(seed):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.self_check(seed)
+
+
+@pytest.mark.parametrize("kt,ot", [(4, 4), (4, 2), (2, 2), (2, 1)])
+def test_narrow_tile_forward_model(kt, ot):
+    """tools/narrow_tile_model.py: the 16-lane-tile layer of the fused rollout kernels (v_mfma_f32_16x16x4_f32 re-addressing the
+    32x32x2 packed image and the lane-half-major vectors, csrc/rollout_policy.hpp) reproduces W x + b for the widths 128 / 64 and
+    the modular actor's 2:1 tower layers."""
+    spec = importlib.util.spec_from_file_location("narrow_tile_model", os.path.join(ROOT, "tools", "narrow_tile_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.self_check(kt, ot)
