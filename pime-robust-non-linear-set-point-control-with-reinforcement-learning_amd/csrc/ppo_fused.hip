@@ -525,19 +525,6 @@ __device__ __forceinline__ void first_grad_valu(float* __restrict__ X, int lane,
     }
 }
 
-// Sum of v over the 32 lanes of this lane's half; valid in lanes 31 and 63.
-__device__ __forceinline__ float half_sum_dpp(float v) {
-#define PIME_DPP_ADD(x, ctrl, row_mask) \
-    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, row_mask, 0xf, true))
-    PIME_DPP_ADD(v, 0x111, 0xf);  // row_shr:1
-    PIME_DPP_ADD(v, 0x112, 0xf);  // row_shr:2
-    PIME_DPP_ADD(v, 0x114, 0xf);  // row_shr:4
-    PIME_DPP_ADD(v, 0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds the row sum
-    PIME_DPP_ADD(v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the half sums
-#undef PIME_DPP_ADD
-    return v;
-}
-
 // Sums over the 32 lanes of a half for SIXTEEN registers at once (the head weight gradient: one register = one feature, a lane =
 // one sample).  Sixteen separate DPP ladders cost 80 vector instructions; here every level adds a PAIR of registers into one, each
 // lane group keeping the partner's sum of the register it "owns", so the register count halves from level to level:
