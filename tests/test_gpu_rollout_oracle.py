@@ -35,6 +35,8 @@ pytestmark = pytest.mark.gpu
     ("WT_STACKING10", "ResidualPPO", 2048, 128),                    # run_watertank_changing.sh:20-27 observation (30 floats)
     ("WT_STACKING4", "ResidualPPO", 1024, 64),
     ("WT_STACKING1", "PPO", 1024, 128),
+    ("PH_V35", "ResidualIntegratorModularPPO", 2048, 64),          # the modular actor's 64 -> 32 towers (one 32-feature tile each)
+    ("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 1000, 64),   # ... and a ragged lane count
     # width 256 (round 3): the streamed 16-tile rollout kernel (csrc/mlp16.hip: rollout16_kernel)
     ("WT_STACKING10", "ResidualPPO", 2048, 256),                    # run_watertank_changing.sh:20-27 as it is run
     ("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 1024, 256),   # run_watertank_changing.sh:11-18
