@@ -49,6 +49,26 @@ class HipBackend:
             return None
         return ops.PackedMLP.from_module(module)
 
+    def packed_twin_heads(self, cri):
+        """(PackedMLP, PackedMLP) for the two Q heads of a CriticTwin (net.py: trunk D+A -> md ReLU -> md ReLU, heads md -> 1), or
+        None.  The forward kernel's critic image is three hidden ReLU layers + a head; the twin is served by an IDENTITY third layer:
+        relu(I h + 0) = h exactly for h = relu(..) >= 0 (every product is h_j * 1 or h_j * 0), so q_k = head_k(trunk(s, a)) comes out of
+        one pime_mlp_forward launch per head with the trunk's own weights."""
+        sa = getattr(cri, "net_sa", None)
+        if sa is None or cri.net_q1.out_features != 1:
+            return None
+        md, din = sa[0].out_features, sa[0].in_features
+        if not ops.PackedMLP.supported("critic", din, 0, md):
+            return None
+        dev = sa[0].weight.device
+        eye, zero = torch.eye(md, device=dev), torch.zeros(md, device=dev)
+        out = []
+        for head in (cri.net_q1, cri.net_q2):
+            pk = ops.PackedMLP("critic", din, 0, md, dev)
+            pk._src = [sa[0].weight, sa[0].bias, sa[2].weight, sa[2].bias, eye, zero, head.weight, head.bias]
+            out.append(pk.repack())
+        return tuple(out)
+
     def fused_ppo(self, act, cri, max_batch):
         """ops.FusedPPOGrad for these nets, or False when their shape has no fused kernel."""
         if not ops.FusedPPOGrad.supported(act, cri):

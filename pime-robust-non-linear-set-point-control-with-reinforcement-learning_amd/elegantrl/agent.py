@@ -667,9 +667,14 @@ class AgentTD3(AgentBase):
         self.update_freq = 2
         self.use_hip_graphs = True
         self.use_fused_rollout = True   # vectorised env: the whole explore call as ONE launch (csrc/rollout_offpolicy.hip)
+        # target Q of the critic objective through pime_mlp_forward (_target_packs).  OFF by default: at the TD3 batch of 4 096 rows a
+        # forward is 16 workgroups on three serial 256-MFMA chains (~25 us each), slower than rocBLAS's small GEMMs -- 165 vs 157 ms
+        # per bench step.  PIME_TD3_FUSED_TARGETS=1 switches it on (parity: tests/test_gpu_td3.py).
+        self.use_fused_targets = os.environ.get("PIME_TD3_FUSED_TARGETS", "0") == "1"
         self._graphs = None
         self._obs = None
         self._packed_act = None
+        self._tpacks = None
 
     def init(self, net_dim, state_dim, action_dim, if_per=False):
         assert not if_per, "prioritised replay is not on the residual-control path"
@@ -689,6 +694,29 @@ class AgentTD3(AgentBase):
         self.act_optimizer = torch.optim.Adam(self.act.parameters(), lr=self.learning_rate, **kw)
         self._graphs = None
         self._packed_act = None
+        self._tpacks = None
+
+    def weights_changed(self):
+        super().weights_changed()
+        self._tpacks = None   # the target nets' packed images are stale (checkpoint load, rebuilt optimizer)
+        self._graphs = None
+
+    def _target_packs(self):
+        """(actor_target, q1 head, q2 head of cri_target) as packed images of the hand-written forward kernel, or None -> the torch
+        modules.  The no-grad half of the critic objective (agent.py:363-367: next_a = act_target.get_action(next_s),
+        next_q = min(cri_target.get_q1_q2(next_s, next_a))) is then three pime_mlp_forward launches on the f32 matrix cores (the twin
+        heads share the trunk through an identity layer: backend.packed_twin_heads) instead of ~15 rocBLAS / elementwise ones; the
+        images are re-packed right behind every soft update (_one_update), inside the same captured graph."""
+        if self._tpacks is None:
+            self._tpacks = False
+            ok = (self.use_fused_targets and self.device.type == "cuda" and hasattr(self.backend, "packed_twin_heads")
+                  and getattr(self.act_target, "action_dim", 1) == 1)
+            if ok:
+                a = self.backend.packed(self.act_target)
+                q = self.backend.packed_twin_heads(self.cri_target) if a is not None else None
+                if a is not None and q is not None:
+                    self._tpacks = (a, q[0], q[1])
+        return self._tpacks or None
 
     def _prior_term(self, states):
         """Prior-controller part of the env action (none for plain TD3)."""
@@ -788,8 +816,16 @@ class AgentTD3(AgentBase):
     def get_obj_critic_raw(self, buffer, batch_size):
         with torch.no_grad():
             reward, mask, action, state, next_s = buffer.sample_batch(batch_size)
-            next_a = self.act_target.get_action(next_s, self.policy_noise)
-            next_q = torch.min(*self.cri_target.get_q1_q2(next_s, next_a))
+            tp = self._target_packs() if next_s.is_cuda else None
+            if tp is not None:   # the same arithmetic, the forwards on the hand-written kernel (net.py: Actor.get_action)
+                a = tp[0](next_s).tanh().unsqueeze(1)
+                noise = (torch.randn_like(a) * self.policy_noise).clamp(-0.5, 0.5)
+                next_a = (a + noise).clamp(-1.0, 1.0)
+                sa = torch.cat((next_s, next_a), dim=1)
+                next_q = torch.min(tp[1](sa), tp[2](sa)).unsqueeze(1)
+            else:
+                next_a = self.act_target.get_action(next_s, self.policy_noise)
+                next_q = torch.min(*self.cri_target.get_q1_q2(next_s, next_a))
             q_label = reward + mask * next_q
         q1, q2 = self.cri.get_q1_q2(state, action)
         return self.criterion(q1, q_label) + self.criterion(q2, q_label), state
@@ -799,14 +835,19 @@ class AgentTD3(AgentBase):
         self.cri_optimizer.zero_grad(set_to_none=False)
         obj_critic.backward()
         self.cri_optimizer.step()
+        tp = self._tpacks or None
         if soft:
             self.soft_update(self.cri_target, self.cri, self.soft_update_tau)
+            if tp is not None:
+                tp[1].repack(); tp[2].repack()
         obj_actor = -self.cri_target(state, self.act(state)).mean()
         self.act_optimizer.zero_grad(set_to_none=False)
         obj_actor.backward()
         self.act_optimizer.step()
         if soft:
             self.soft_update(self.act_target, self.act, self.soft_update_tau)
+            if tp is not None:
+                tp[0].repack()
         return obj_actor.detach(), obj_critic.detach()
 
     def update_net(self, buffer, target_step, batch_size, repeat_times):

@@ -207,3 +207,52 @@ def test_fused_offpolicy_explore_matches_lock_step_launches():
         assert torch.equal(o_s[t][:, 1], o_f[t][:, 1]), "masks (episode ends) must agree exactly"
         n_done += int((o_f[t][:, 1] == 0).sum())
     assert n_done == 2 * N      # 70 lock-steps of 25-step episodes: every lane ended two
+
+
+def test_td3_target_q_on_the_forward_kernel_matches_the_torch_modules():
+    """AgentTD3._target_packs (opt-in, PIME_TD3_FUSED_TARGETS=1): next_a = act_target.get_action(next_s) and
+    min(cri_target.get_q1_q2(next_s, next_a)) served by three pime_mlp_forward launches -- the twin heads share the trunk through an
+    identity third layer -- against the torch modules on the same batch and the same policy-noise draws (agent.py:363-367,
+    net.py:305-332).  Also after a soft update: the images are re-packed behind it."""
+    from pime_amd.elegantrl.agent import AgentTD3
+    torch.manual_seed(3)
+    D, B = 4, 4096
+    ag = AgentTD3(device=DEV)
+    ag.init(128, D, 1)
+    with torch.no_grad():   # targets that differ from the online nets, heads away from their tiny initial scale
+        for p in list(ag.act_target.parameters()) + list(ag.cri_target.parameters()):
+            p.add_(torch.randn_like(p) * 0.05)
+    next_s = torch.randn(B, D, device=DEV) * 2 + 1
+
+    def label(fused):
+        ag.use_fused_targets, ag._tpacks = fused, None
+        torch.manual_seed(11)   # the same policy-noise draws on both paths
+        with torch.no_grad():
+            tp = ag._target_packs()
+            assert (tp is not None) == fused
+            if tp is not None:
+                a = tp[0](next_s).tanh().unsqueeze(1)
+                noise = (torch.randn_like(a) * ag.policy_noise).clamp(-0.5, 0.5)
+                next_a = (a + noise).clamp(-1.0, 1.0)
+                sa = torch.cat((next_s, next_a), 1)
+                return next_a, torch.min(tp[1](sa), tp[2](sa)).unsqueeze(1)
+            next_a = ag.act_target.get_action(next_s, ag.policy_noise)
+            return next_a, torch.min(*ag.cri_target.get_q1_q2(next_s, next_a))
+
+    a0, q0 = label(False)
+    a1, q1 = label(True)
+    assert a1.shape == a0.shape and q1.shape == q0.shape
+    np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(q1.cpu().numpy(), q0.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    # a soft update moves the targets; _one_update re-packs the images right behind it
+    ag.soft_update(ag.cri_target, ag.cri, 0.3)
+    ag.soft_update(ag.act_target, ag.act, 0.3)
+    for pk in ag._tpacks:
+        pk.repack()
+    with torch.no_grad():   # the re-packed images (not rebuilt ones) serve the moved targets
+        sa = torch.cat((next_s, a1), 1)
+        want = torch.min(*ag.cri_target.get_q1_q2(next_s, a1))
+        got = torch.min(ag._tpacks[1](sa), ag._tpacks[2](sa)).unsqueeze(1)
+        pre = ag.act_target.net(next_s)[:, 0]
+        np.testing.assert_allclose(ag._tpacks[0](next_s).cpu().numpy(), pre.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6)
