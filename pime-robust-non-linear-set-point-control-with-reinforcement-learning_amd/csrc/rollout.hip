@@ -43,7 +43,10 @@ __device__ __forceinline__ float through_half(float v) { return (float)(half_t)v
 // NARROW (the default): 16 lanes per wave (four workgroup waves, policy_forward16) -- every SIMD has a wave where the 32-lane tiles of a launch
 // would cover only half of them, and a layer's serial MFMA chain is half as long.  Same image, same env code, same Philox keys (the
 // noise of a lane does not depend on the tiling); the policy mean differs in the last bits (another summation order).
-template <int T, int KIND, int ENV, int STACK, bool NARROW = false>
+// QUAD (NARROW == 2; launches of <= 4 096 lanes): the four waves of a workgroup share ONE 16-lane tile and a quarter of every layer's
+// output tiles each (policy_forward16q: a quarter of the MFMA chain, two LDS exchanges per env step); the same MFMA sequence per
+// accumulator as NARROW, so the trajectories are bit-identical to it.
+template <int T, int KIND, int ENV, int STACK, int NARROW = 0>
 __global__ __launch_bounds__(NARROW ? kRolloutNarrowThreads : kRolloutThreads) void rollout_kernel(RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), Di = ENV == 2 ? 0 : 1;
@@ -54,10 +57,13 @@ __global__ __launch_bounds__(NARROW ? kRolloutNarrowThreads : kRolloutThreads) v
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int N = a.n;
     constexpr int LW = NARROW ? 16 : 32, WAVES = (NARROW ? kRolloutNarrowThreads : kRolloutThreads) / 64;   // env lanes per wave
-    const int m = (blockIdx.x * WAVES + wave) * LW + (lane & (LW - 1));
+    constexpr bool QUAD = NARROW == 2;
+    const int m = (QUAD ? blockIdx.x : blockIdx.x * WAVES + wave) * LW + (lane & (LW - 1));
     const bool valid = m < N;
     const int i = valid ? m : N - 1;  // idle lanes shadow the last env (compute, never store)
-    const bool writer = valid && (NARROW ? (lane >> 4) == 0 : h == 0);   // the lane groups carry copies of the same envs
+    // the lane groups (and, QUAD, the waves) carry copies of the same envs: one of them stores
+    const bool writer = valid && (NARROW ? (lane >> 4) == 0 && (!QUAD || wave == 0) : h == 0);
+    [[maybe_unused]] float* const xbuf = lds + L.total;   // QUAD: the activation exchange buffers behind the image
     const uint32_t gid = a.env_offset + (uint32_t)i;
     const float sigma = __expf(a.a_std_log[0]);
 
@@ -78,7 +84,10 @@ __global__ __launch_bounds__(NARROW ? kRolloutNarrowThreads : kRolloutThreads) v
     for (int j = 0; j < D; ++j) obs[j] = h16 ? (float)a.state_h[(size_t)D * i + j] : a.state[(size_t)D * i + j];
     for (int t = 0; t < a.n_steps; ++t) {
         PIME_NO_HOIST();
-        const float a_avg = NARROW ? policy_forward16<T, KIND, D, Di>(lds, L, obs, lane) : policy_forward<T, KIND, D, Di>(lds, L, obs, lane);
+        float a_avg;
+        if constexpr (QUAD) a_avg = policy_forward16q<T, KIND, D, Di>(lds, xbuf, L, obs, lane, wave);
+        else if constexpr (NARROW == 1) a_avg = policy_forward16<T, KIND, D, Di>(lds, L, obs, lane);
+        else a_avg = policy_forward<T, KIND, D, Di>(lds, L, obs, lane);
         // exploration noise eps ~ N(0,1): Box-Muller on a Philox pair keyed by the global lane (net_residual.py:178)
         double ua, ub;
         philox_pair(a.noise_seed, gid, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE, ua, ub);
@@ -153,30 +162,38 @@ __global__ __launch_bounds__(NARROW ? kRolloutNarrowThreads : kRolloutThreads) v
 int mlp_check(int kind, int D, int Di, int md);
 int launch_rollout16(int kind, const RolloutArgs& a, hipStream_t s);   // width 256: the streamed 16-tile family (mlp16.hip)
 
-// 16-lane tiles by default, whatever the lane count: the image fills LDS, so a compute unit holds ONE workgroup -- four waves of 16
+// Tiling of a launch.  Default: 16-lane tiles (NARROW) -- the image fills LDS, so a compute unit holds ONE workgroup; four waves of 16
 // lanes give each of its SIMDs a wave with half the serial chain of a 32-lane tile, where the 32-lane workgroup (two waves) leaves
-// two SIMDs idle at any launch size.  One kernel for every n also keeps a lane's trajectory independent of how the lanes are sharded
-// over ranks (tests/test_gpu_config4.py).  PIME_ROLLOUT_NARROW=0 selects the 32-lane tiles (A/B, and the tests replay both).
-static bool narrow_tiles(int) {
-    if (const char* e = std::getenv("PIME_ROLLOUT_NARROW")) return std::atoi(e) != 0;   // read per launch: tests flip it
-    return true;
+// two SIMDs idle at any launch size.  Launches of <= 4 096 lanes (256 tiles: at most one per compute unit) split every tile over the
+// four waves of its workgroup (QUAD) when the exchange buffers fit behind the image.  NARROW and QUAD give bit-identical
+// trajectories, so a lane's results do not depend on how the lanes are sharded over ranks (tests/test_gpu_config4.py).
+// PIME_ROLLOUT_NARROW=0 / 1 / 2 forces 32-lane tiles / NARROW / QUAD (A/B; the tests replay all of them).
+static int tiling(int n, size_t quad_lds_bytes) {
+    int mode = n <= 4096 ? 2 : 1;
+    if (const char* e = std::getenv("PIME_ROLLOUT_NARROW")) mode = std::atoi(e);   // read per launch: tests flip it
+    if (mode == 2 && quad_lds_bytes > 160 * 1024) mode = 1;                        // (the 30-float Stacking10 observation at width 128)
+    return mode < 0 || mode > 2 ? 1 : mode;
 }
 
-template <int T, int KIND, int ENV, int STACK, bool NARROW>
+template <int T, int KIND, int ENV, int STACK, int NARROW>
 static int launch_rollout_n(const RolloutArgs& a, hipStream_t s) {
     const MlpLayout L = mlp_layout(KIND, ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), ENV == 2 ? 0 : 1, T * 32);
-    const size_t lds_bytes = (size_t)L.total * sizeof(float);
+    const size_t lds_bytes = ((size_t)L.total + (NARROW == 2 ? quad_xchg_floats<T>() : 0)) * sizeof(float);
     static LdsLimit lds_limit;  // per instantiation
     PIME_RAISE_LDS(lds_limit, (rollout_kernel<T, KIND, ENV, STACK, NARROW>), 160 * 1024);
-    constexpr int threads = NARROW ? kRolloutNarrowThreads : kRolloutThreads, per_wg = threads / 64 * (NARROW ? 16 : 32);
+    constexpr int threads = NARROW ? kRolloutNarrowThreads : kRolloutThreads;
+    constexpr int per_wg = NARROW == 2 ? 16 : threads / 64 * (NARROW ? 16 : 32);
     hipLaunchKernelGGL((rollout_kernel<T, KIND, ENV, STACK, NARROW>), dim3((a.n + per_wg - 1) / per_wg), dim3(threads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 template <int T, int KIND, int ENV, int STACK>
 static int launch_rollout_t(const RolloutArgs& a, hipStream_t s) {
-    if (narrow_tiles(a.n)) return launch_rollout_n<T, KIND, ENV, STACK, true>(a, s);
-    return launch_rollout_n<T, KIND, ENV, STACK, false>(a, s);
+    const MlpLayout L = mlp_layout(KIND, ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), ENV == 2 ? 0 : 1, T * 32);
+    const int mode = tiling(a.n, ((size_t)L.total + quad_xchg_floats<T>()) * sizeof(float));
+    if (mode == 2) return launch_rollout_n<T, KIND, ENV, STACK, 2>(a, s);
+    if (mode == 1) return launch_rollout_n<T, KIND, ENV, STACK, 1>(a, s);
+    return launch_rollout_n<T, KIND, ENV, STACK, 0>(a, s);
 }
 
 int launch_rollout(int kind, int md, const RolloutArgs& a, hipStream_t s) {

@@ -194,4 +194,124 @@ __device__ __forceinline__ float policy_forward16(const float* __restrict__ lds,
     }
 }
 
+// ---- QUAD: one 16-lane tile per WORKGROUP, a layer's output tiles split over its four waves ----------------------------------------
+// For launches of at most 4 096 lanes (the water-tank configurations: 256 tiles of 16 lanes) even 16-lane tiles leave three of
+// four SIMDs idle.  Here the four waves of a workgroup share ONE tile: each computes a quarter of a layer's output tiles (a quarter
+// of the serial MFMA chain), the quarters meet in an 8 KB LDS buffer and every wave reads the whole activation back as the next
+// layer's operand.  Two exchanges per env step (towers / first hidden layer, then the last hidden layer); two buffers, so that one
+// LDS-only barrier per exchange orders both the publication and the reuse.  First layers and the head are computed by every wave
+// (vector ALUs, a few hundred cycles).  The env arithmetic runs in all four waves on the same 16 lanes; wave 0 stores.
+#define PIME_XCHG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+constexpr int kQuadWaves = 4;
+template <int T>
+__host__ __device__ constexpr int quad_xchg_floats() { return 2 * (T * 2) * 64 * 4; }   // two buffers of T * 2 tiles x 64 lanes x 4
+
+// this wave's share of out = act(W in + b): output tiles [t0, t0 + NT) of the layer's OT32 * 2
+template <int KT32, int OT32, int NT, int ACT>
+__device__ __forceinline__ void layer16_on32_part(const float* __restrict__ wp, const float* __restrict__ bp, int lane, int t0,
+                                                  const f32x4_t (&in)[KT32 * 2], f32x4_t (&out)[NT]) {
+    static_assert(NT == 1 || NT == 2, "one tile, or an (even, odd) pair");
+    const int c = lane & 15, g = lane >> 4;
+    // tile ot' = component ot' >> 1 of the OT32-wide word at lane32 = 16 (ot' & 1) + c + 32 (g & 1); NT == 2: t0 is even
+    const int comp = t0 >> 1;
+    const float* wl = wp + (size_t)(c + 32 * (g & 1) + 256 * (g >> 1) + (NT == 1 ? 16 * (t0 & 1) : 0)) * OT32 + comp;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        out[n] = *reinterpret_cast<const f32x4_t*>(bp + (g & 1) * (OT32 * 16) + ((t0 + n) >> 1) * 16 + 8 * ((t0 + n) & 1) + 4 * (g >> 1));
+#pragma unroll
+    for (int ok = 0; ok < KT32 * 2; ++ok) {
+        PIME_NO_HOIST();
+#pragma unroll
+        for (int rk = 0; rk < 4; ++rk) {
+            const int word = ((ok >> 1) * 16 + rk + 8 * (ok & 1)) * 64;
+            const float b = in[ok][rk];
+            out[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(size_t)word * OT32], b, out[0], 0, 0, 0);
+            if constexpr (NT == 2)
+                out[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(size_t)(word + 16) * OT32], b, out[1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) activate4<ACT>(out[n]);
+}
+
+template <int NTILES>
+__device__ __forceinline__ void xchg_read(const float* __restrict__ buf, int lane, f32x4_t (&v)[NTILES]) {
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) v[t] = *reinterpret_cast<const f32x4_t*>(buf + (t * 64 + lane) * 4);
+}
+__device__ __forceinline__ void xchg_write(float* __restrict__ buf, int lane, int tile, const f32x4_t& v) {
+    *reinterpret_cast<f32x4_t*>(buf + (tile * 64 + lane) * 4) = v;
+}
+
+// a_avg for this lane's sample; every wave of the workgroup returns the same value.  xbuf: quad_xchg_floats<T>() floats of LDS.
+template <int T, int KIND, int D, int Di>
+__device__ __forceinline__ float policy_forward16q(const float* __restrict__ lds, float* __restrict__ xbuf, const MlpLayout& L,
+                                                   const float (&obs)[D], int lane, int wave) {
+    constexpr int Do = D - Di, H = T / 2 > 0 ? T / 2 : 1, NT = T * 2;   // NT tiles of 16 features per full-width activation
+    static_assert(T == 4 || T == 2, "widths 128 and 64");
+    constexpr int PER = NT / kQuadWaves;                                 // output tiles per wave of a full-width layer: 2 (1 at width 64)
+    const int g = lane >> 4;
+    float* const buf0 = xbuf;
+    float* const buf1 = xbuf + NT * 64 * 4;
+    f32x4_t act[NT];
+    if constexpr (KIND == MLP_MODULAR_ACTOR) {
+        constexpr int PT = (H * 2) / kQuadWaves > 0 ? (H * 2) / kQuadWaves : 1;   // tiles per wave of a tower's H * 2
+        static_assert(H * 2 >= kQuadWaves || T == 2, "towers of at least four tiles, or width 64 (two tiles: waves 0-1 and 2-3 split the towers)");
+        {
+            f32x4_t a0[NT], o[PT];
+            first16_on32<T, 1, Do>(lds + L.off[0], obs, g, a0);
+            PIME_NO_HOIST();
+            if constexpr (T == 4) {
+                layer16_on32_part<T, H, PT, 1>(lds + L.off[1], lds + L.off[2], lane, wave * PT, a0, o);
+                xchg_write(buf0, lane, wave * PT, o[0]);
+                PIME_NO_HOIST();
+                first16_on32<T, 1, Di>(lds + L.off[3], obs + Do, g, a0);
+                PIME_NO_HOIST();
+                layer16_on32_part<T, H, PT, 1>(lds + L.off[4], lds + L.off[5], lane, wave * PT, a0, o);
+                xchg_write(buf0, lane, H * 2 + wave * PT, o[0]);
+            } else {   // width 64: each tower has two output tiles; waves 0-1 take other_net's, waves 2-3 integrator_net's
+                const int tw = wave >> 1, tile = wave & 1;
+                if (tw == 1) first16_on32<T, 1, Di>(lds + L.off[3], obs + Do, g, a0);
+                layer16_on32_part<T, H, 1, 1>(lds + L.off[tw ? 4 : 1], lds + L.off[tw ? 5 : 2], lane, tile, a0, o);
+                xchg_write(buf0, lane, tw * (H * 2) + tile, o[0]);
+            }
+        }
+        PIME_XCHG_BARRIER();
+        xchg_read<NT>(buf0, lane, act);   // cat
+        {
+            f32x4_t o[PER];
+            PIME_NO_HOIST();
+            layer16_on32_part<T, T, PER, 1>(lds + L.off[6], lds + L.off[7], lane, wave * PER, act, o);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) xchg_write(buf1, lane, wave * PER + n, o[n]);
+        }
+        PIME_XCHG_BARRIER();
+        xchg_read<NT>(buf1, lane, act);   // n0
+        PIME_NO_HOIST();
+        return head16_on32<T>(lds + L.off[8], lds[L.off[9]], lane, act);
+    } else {
+        constexpr int ACT = KIND == MLP_CRITIC ? 0 : 1;
+        f32x4_t o[PER];
+        {
+            f32x4_t a0[NT];
+            first16_on32<T, ACT, D>(lds + L.off[0], obs, g, a0);
+            PIME_NO_HOIST();
+            layer16_on32_part<T, T, PER, ACT>(lds + L.off[1], lds + L.off[2], lane, wave * PER, a0, o);
+        }
+#pragma unroll
+        for (int n = 0; n < PER; ++n) xchg_write(buf0, lane, wave * PER + n, o[n]);
+        PIME_XCHG_BARRIER();
+        xchg_read<NT>(buf0, lane, act);
+        PIME_NO_HOIST();
+        layer16_on32_part<T, T, PER, ACT>(lds + L.off[3], lds + L.off[4], lane, wave * PER, act, o);
+#pragma unroll
+        for (int n = 0; n < PER; ++n) xchg_write(buf1, lane, wave * PER + n, o[n]);
+        PIME_XCHG_BARRIER();
+        xchg_read<NT>(buf1, lane, act);
+        PIME_NO_HOIST();
+        return head16_on32<T>(lds + L.off[5], lds[L.off[6]], lane, act);
+    }
+}
+
 }  // namespace pime

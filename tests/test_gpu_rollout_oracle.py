@@ -25,7 +25,7 @@ from rollout_replay import DEV, make_agent, replay_through_oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tiles", ["wide", "narrow"])   # 32- / 16-lane tiles per wave (csrc/rollout.hip: NARROW; widths <= 128)
+@pytest.mark.parametrize("tiles", ["wide", "narrow", "quad"])   # 32- / 16-lane tiles per wave, one 16-lane tile per workgroup (csrc/rollout.hip)
 @pytest.mark.parametrize("env_name,algo,N,md", [
     ("PH_V35", "ResidualIntegratorModularPPO", 16384, 128),   # the bench configuration
     ("PH_V35", "ResidualPPO", 16384, 128),
@@ -47,10 +47,10 @@ pytestmark = pytest.mark.gpu
 def test_fused_rollout_replays_through_oracle(env_name, algo, N, md, tiles, monkeypatch):
     import oracle
     if md == 256:
-        if tiles == "narrow":
+        if tiles != "wide":
             pytest.skip("width 256 has one kernel (the streamed 16-tile family)")
-    else:   # the library runs 16-lane tiles by default; both kernels must replay
-        monkeypatch.setenv("PIME_ROLLOUT_NARROW", "1" if tiles == "narrow" else "0")
+    else:   # the library picks 16-lane tiles (one per workgroup up to 4 096 lanes) by itself; every tiling must replay
+        monkeypatch.setenv("PIME_ROLLOUT_NARROW", {"wide": "0", "narrow": "1", "quad": "2"}[tiles])
     from pime_amd import gym_control
     from pime_amd.elegantrl.run import make_buffer
     is_ph = env_name == "PH_V35"
@@ -79,3 +79,33 @@ def test_fused_rollout_replays_through_oracle(env_name, algo, N, md, tiles, monk
         np.testing.assert_allclose(env.get_field("a1"), ref.get("a1"), rtol=1e-7)
         np.testing.assert_allclose(env.get_field("Kp"), ref.get("Kp"), rtol=1e-7)
     env.close()
+
+
+@pytest.mark.parametrize("env_name,algo,N,md", [("PH_V35", "ResidualIntegratorModularPPO", 3000, 128),
+                                               ("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 1024, 64),
+                                               ("WT_STACKING4", "ResidualPPO", 2048, 128)])
+def test_quad_and_narrow_tilings_give_the_same_bits(env_name, algo, N, md, monkeypatch):
+    """One 16-lane tile per workgroup (QUAD: each wave a quarter of a layer's output tiles) runs the same MFMA sequence per
+    accumulator as one tile per wave (NARROW): actions, observations, rewards and done flags are bit-identical -- which is what keeps a
+    lane's trajectory independent of the launch size (<= 4 096 lanes take QUAD, larger launches NARROW)."""
+    from pime_amd import gym_control
+    from pime_amd.elegantrl.run import make_buffer
+    stack = int(env_name[len("WT_STACKING"):]) if env_name.startswith("WT_STACKING") else 0
+    env_id = gym_control.WT_STACKING.format(stack) if stack else getattr(gym_control, env_name)
+    kw = {} if env_name == "PH_V35" else dict(reward_type="distance", max_step=40)
+    bufs = []
+    for mode in ("1", "2"):
+        monkeypatch.setenv("PIME_ROLLOUT_NARROW", mode)
+        env = gym_control.make_vec(env_id, N, device=DEV, state_mode="mixed", seed=9, env_offset=77, **kw)
+        ag = make_agent(algo, env, md)
+        buf = make_buffer(ag, env, 2 * N * env.max_step)
+        ag.explore_env(env, buf, 2 * N * env.max_step, 1.0, 0.99)
+        torch.cuda.synchronize()
+        bufs.append(buf)
+        env.close()
+    a, b = bufs
+    T = a.length
+    assert T == b.length and T > 0
+    for name in ("action", "noise", "reward", "done"):
+        assert torch.equal(getattr(a, name)[:T], getattr(b, name)[:T]), name
+    assert torch.equal(a.state[:T + 1], b.state[:T + 1])
