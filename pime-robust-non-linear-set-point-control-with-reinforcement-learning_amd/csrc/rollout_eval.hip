@@ -12,6 +12,7 @@
 // KIND = -1: the prior controller alone (get_linear_action, ph.py:227-231 / nonlinear_watertank.py:755-759 without its clip).
 // S = float (PIME_STATE_MIXED) or double (PIME_STATE_F64: the golden-pinned protocol tests run here, 1e-11).
 // The policy forward is rollout_policy.hpp -- the code of the rollout kernel; the env arithmetic is env_device.hpp.
+#include <cstdlib>
 #include "env_device.hpp"
 #include "rollout_eval.hpp"
 #include "rollout_policy.hpp"
@@ -20,7 +21,8 @@ namespace pime {
 
 constexpr int kEvalThreads = 256;   // four waves of 16 lanes: one per SIMD (16-lane tiles, rollout_policy.hpp: policy_forward16)
 
-template <int T, int KIND, int ENV, typename S>
+// QUAD (launches of <= 4 096 lanes with a policy): one 16-lane tile per workgroup, split over its four waves (policy_forward16q)
+template <int T, int KIND, int ENV, typename S, bool QUAD>
 __global__ __launch_bounds__(kEvalThreads) void rollout_eval_kernel(EvalArgs<S> a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = ENV == 0 ? 3 : 4;
@@ -33,10 +35,10 @@ __global__ __launch_bounds__(kEvalThreads) void rollout_eval_kernel(EvalArgs<S> 
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int N = a.n;
-    const int m = (blockIdx.x * (kEvalThreads / 64) + wave) * 16 + (lane & 15);
+    const int m = (QUAD ? blockIdx.x : blockIdx.x * (kEvalThreads / 64) + wave) * 16 + (lane & 15);
     const bool valid = m < N;
     const int i = valid ? m : N - 1;  // idle lanes shadow the last env (compute, never store)
-    const bool writer = valid && (lane >> 4) == 0;   // the four lane groups carry copies of the same 16 envs
+    const bool writer = valid && (lane >> 4) == 0 && (!QUAD || wave == 0);   // the lane groups (QUAD: and the waves) carry copies of the same 16 envs
     const uint32_t gid = a.env_offset + (uint32_t)i;
 
     PhLane<S> E{};
@@ -60,7 +62,12 @@ __global__ __launch_bounds__(kEvalThreads) void rollout_eval_kernel(EvalArgs<S> 
         double a_env = 0.0;                                                        // agent_residual.py:61 without the noise
 #pragma unroll
         for (int j = 0; j < D; ++j) a_env += (double)obs[j] * a.K.k[j];
-        if constexpr (POLICY) a_env = residual_tanh(policy_forward16<T, KIND, D, 1>(lds, L, obs, lane)) + a_env;
+        if constexpr (POLICY) {
+            float mean;
+            if constexpr (QUAD) mean = policy_forward16q<T, KIND, D, 1>(lds, lds + L.total, L, obs, lane, wave);
+            else mean = policy_forward16<T, KIND, D, 1>(lds, L, obs, lane);
+            a_env = residual_tanh(mean) + a_env;
+        }
         double tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr5 = 0;
         float rew;
         if constexpr (ENV == 0) {
@@ -92,18 +99,27 @@ __global__ __launch_bounds__(kEvalThreads) void rollout_eval_kernel(EvalArgs<S> 
 
 int mlp_check(int kind, int D, int Di, int md);
 
-template <int T, int KIND, int ENV, typename S>
-static int launch_eval_t(const EvalArgs<S>& a, hipStream_t s) {
+template <int T, int KIND, int ENV, typename S, bool QUAD>
+static int launch_eval_q(const EvalArgs<S>& a, hipStream_t s) {
     size_t lds_bytes = 0;
     if constexpr (KIND >= 0) {
-        lds_bytes = (size_t)mlp_layout(KIND, ENV == 0 ? 3 : 4, 1, T * 32).total * sizeof(float);
+        lds_bytes = ((size_t)mlp_layout(KIND, ENV == 0 ? 3 : 4, 1, T * 32).total + (QUAD ? quad_xchg_floats<T>() : 0)) * sizeof(float);
         static LdsLimit lds_limit;  // per instantiation
-        PIME_RAISE_LDS(lds_limit, (rollout_eval_kernel<T, KIND, ENV, S>), 160 * 1024);
+        PIME_RAISE_LDS(lds_limit, (rollout_eval_kernel<T, KIND, ENV, S, QUAD>), 160 * 1024);
     }
-    const int tiles = (a.n + 15) / 16, per_wg = kEvalThreads / 64;
-    hipLaunchKernelGGL((rollout_eval_kernel<T, KIND, ENV, S>), dim3((tiles + per_wg - 1) / per_wg), dim3(kEvalThreads), lds_bytes, s, a);
+    const int per_wg = QUAD ? 16 : kEvalThreads / 64 * 16;
+    hipLaunchKernelGGL((rollout_eval_kernel<T, KIND, ENV, S, QUAD>), dim3((a.n + per_wg - 1) / per_wg), dim3(kEvalThreads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
+}
+template <int T, int KIND, int ENV, typename S>
+static int launch_eval_t(const EvalArgs<S>& a, hipStream_t s) {
+    if constexpr (KIND >= 0) {
+        bool quad = a.n <= 4096;   // at most one tile per compute unit: split it over the workgroup's waves (csrc/rollout.hip: tiling)
+        if (const char* e = std::getenv("PIME_ROLLOUT_NARROW")) quad = std::atoi(e) == 2;
+        if (quad) return launch_eval_q<T, KIND, ENV, S, true>(a, s);
+    }
+    return launch_eval_q<T, KIND, ENV, S, false>(a, s);
 }
 
 template <typename S>

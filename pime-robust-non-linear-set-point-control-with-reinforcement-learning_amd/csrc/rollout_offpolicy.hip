@@ -10,6 +10,7 @@
 // round 2 (42 ms per 200 lock-steps of 4 096 lanes, profiles/r03d_td3_kstats.txt).
 // Policy forward = rollout_policy.hpp with the TD3 Actor's activations (three ReLU layers: CriticAdv's image kind); env arithmetic
 // = env_device.hpp; exploration noise = the rollout kernel's Philox stream 2.
+#include <cstdlib>
 #include "env_device.hpp"
 #include "rollout_offpolicy.hpp"
 #include "rollout_policy.hpp"
@@ -19,7 +20,8 @@ namespace pime {
 constexpr uint32_t STREAM_EXPLORE_OFFPOLICY = 2;   // = rollout.hip's STREAM_EXPLORE
 constexpr int kOffThreads = 256;   // four waves of 16 lanes: one per SIMD (16-lane tiles, rollout_policy.hpp: policy_forward16)
 
-template <int T, int ENV>
+// QUAD (launches of <= 4 096 lanes): one 16-lane tile per workgroup, split over its four waves (rollout_policy.hpp: policy_forward16q)
+template <int T, int ENV, bool QUAD>
 __global__ __launch_bounds__(kOffThreads) void rollout_offpolicy_kernel(OffPolicyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = ENV == 0 ? 3 : 4;
@@ -28,10 +30,10 @@ __global__ __launch_bounds__(kOffThreads) void rollout_offpolicy_kernel(OffPolic
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int N = a.n;
-    const int m = (blockIdx.x * (kOffThreads / 64) + wave) * 16 + (lane & 15);
+    const int m = (QUAD ? blockIdx.x : blockIdx.x * (kOffThreads / 64) + wave) * 16 + (lane & 15);
     const bool valid = m < N;
     const int i = valid ? m : N - 1;  // idle lanes shadow the last env (compute, never store)
-    const bool writer = valid && (lane >> 4) == 0;   // the four lane groups carry copies of the same 16 envs
+    const bool writer = valid && (lane >> 4) == 0 && (!QUAD || wave == 0);   // the lane groups (QUAD: and the waves) carry copies of the same 16 envs
     const uint32_t gid = a.env_offset + (uint32_t)i;
 
     PhLane<float> E{};
@@ -44,7 +46,9 @@ __global__ __launch_bounds__(kOffThreads) void rollout_offpolicy_kernel(OffPolic
     int slot = a.slot0;
     for (int t = 0; t < a.n_steps; ++t) {
         PIME_NO_HOIST();
-        const float mean = policy_forward16<T, MLP_CRITIC, D, 0>(lds, L, obs, lane);
+        float mean;
+        if constexpr (QUAD) mean = policy_forward16q<T, MLP_CRITIC, D, 0>(lds, lds + L.total, L, obs, lane, wave);
+        else mean = policy_forward16<T, MLP_CRITIC, D, 0>(lds, L, obs, lane);
         double ua, ub;
         philox_pair(a.noise_seed, gid, a.noise_epoch, (uint32_t)t, STREAM_EXPLORE_OFFPOLICY, ua, ub);
         const float eps = (float)(sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586476925286766559 * ub));
@@ -87,15 +91,21 @@ __global__ __launch_bounds__(kOffThreads) void rollout_offpolicy_kernel(OffPolic
 
 int mlp_check(int kind, int D, int Di, int md);
 
-template <int T, int ENV>
-static int launch_off_t(const OffPolicyArgs& a, hipStream_t s) {
-    const size_t lds_bytes = (size_t)mlp_layout(MLP_CRITIC, ENV == 0 ? 3 : 4, 0, T * 32).total * sizeof(float);
+template <int T, int ENV, bool QUAD>
+static int launch_off_q(const OffPolicyArgs& a, hipStream_t s) {
+    const size_t lds_bytes = ((size_t)mlp_layout(MLP_CRITIC, ENV == 0 ? 3 : 4, 0, T * 32).total + (QUAD ? quad_xchg_floats<T>() : 0)) * sizeof(float);
     static LdsLimit lds_limit;  // per instantiation
-    PIME_RAISE_LDS(lds_limit, (rollout_offpolicy_kernel<T, ENV>), 160 * 1024);
-    const int tiles = (a.n + 15) / 16, per_wg = kOffThreads / 64;
-    hipLaunchKernelGGL((rollout_offpolicy_kernel<T, ENV>), dim3((tiles + per_wg - 1) / per_wg), dim3(kOffThreads), lds_bytes, s, a);
+    PIME_RAISE_LDS(lds_limit, (rollout_offpolicy_kernel<T, ENV, QUAD>), 160 * 1024);
+    const int per_wg = QUAD ? 16 : kOffThreads / 64 * 16;
+    hipLaunchKernelGGL((rollout_offpolicy_kernel<T, ENV, QUAD>), dim3((a.n + per_wg - 1) / per_wg), dim3(kOffThreads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
+}
+template <int T, int ENV>
+static int launch_off_t(const OffPolicyArgs& a, hipStream_t s) {
+    bool quad = a.n <= 4096;   // at most one tile per compute unit: split it over the workgroup's waves (csrc/rollout.hip: tiling)
+    if (const char* e = std::getenv("PIME_ROLLOUT_NARROW")) quad = std::atoi(e) == 2;
+    return quad ? launch_off_q<T, ENV, true>(a, s) : launch_off_q<T, ENV, false>(a, s);
 }
 
 int launch_rollout_offpolicy(int md, const OffPolicyArgs& a, hipStream_t s) {
