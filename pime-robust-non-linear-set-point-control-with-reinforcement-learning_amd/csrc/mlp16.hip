@@ -248,6 +248,82 @@ __device__ __forceinline__ void layer16(const float* __restrict__ gimg, const fl
     layer16r<T, T, ACT, HAS_BIAS>(gimg, bias, wbuf, lane, tid, in, out);
 }
 
+// QUAD form of a square layer (fused rollout, launches of <= 4 096 lanes: one 16-lane tile per WORKGROUP): the workgroup streams the
+// slices exactly as layer16r does, but wave w computes only the quad of output tiles [4 w, 4 w + 4) -- component q = w of every
+// k-step's fragments, a quarter of the MFMA chain -- and the quarters meet in an LDS exchange buffer (xb: T tiles x 64 lanes x 4
+// floats), from which every wave reads the whole activation back.  A fragment group is four k-steps of the wave's quad (16 MFMAs,
+// as in layer16r); per accumulator the k-steps run in the same order, so the result is bit-identical to layer16r's.
+template <int T, int ACT>
+__device__ __forceinline__ void layer16q(const float* __restrict__ gimg, const float* __restrict__ bias, float* __restrict__ wbuf,
+                                         float* __restrict__ xb, int lane, int tid, const f32x4 (&in)[T], f32x4 (&out)[T]) {
+    using G = Layer16Geom<T, T>;
+    static_assert(G::Q == k16Waves && G::SKS % 4 == 0, "one quad of output tiles per wave; whole groups of four k-steps per slice");
+    constexpr int Q = G::Q, SKS = G::SKS, NS = G::NS, SLICE = G::SLICE, PER = G::PER, NG = SKS / 4;
+    const int g = lane >> 4, wave = tid >> 6;
+    const int wave_base = wave * 256;
+    const unsigned voff = (unsigned)tid * 16u;
+    auto dma_slice = [&](int slice) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(gimg + slice * SLICE);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        const char* sbase = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+        float* ldst = wbuf + (slice % 3) * SLICE + wave_base;
+#pragma unroll
+        for (int p = 0; p < PER; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(sbase + p * (k16Threads * 16) + voff),
+                                             (lds_void_ptr)(ldst + p * k16Threads * 4), 16, 0, 0);
+    };
+    dma_slice(0);
+    if constexpr (NS > 1) dma_slice(1);
+    f32x4 o4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o4[j] = *reinterpret_cast<const f32x4*>(bias + (4 * wave + j) * 16 + 4 * g);
+    if constexpr (NS > 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+    PIME16_BARRIER();
+    float4 wf[2][4];
+    auto load_group = [&](int slice, int gidx, float4 (&dst)[4]) {
+        const float4* wl = reinterpret_cast<const float4*>(wbuf + (slice % 3) * SLICE) + lane;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dst[kk] = wl[((gidx * 4 + kk) * Q + wave) * 64];
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 2 < NS) dma_slice(s + 2);
+        load_group(s, 0, wf[(s * NG) & 1]);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int cur = (s * NG + gi) & 1;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int m = half * 2; m < half * 2 + 2; ++m) {
+                    const int ks = s * SKS + gi * 4 + m;
+                    const float b = in[ks >> 2][ks & 3];
+                    const float4 w = wf[cur][m];
+                    o4[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b, o4[0], 0, 0, 0);
+                    o4[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b, o4[1], 0, 0, 0);
+                    o4[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b, o4[2], 0, 0, 0);
+                    o4[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b, o4[3], 0, 0, 0);
+                }
+                if (half == 0 && gi + 1 < NG) load_group(s, gi + 1, wf[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (s + 2 < NS) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+        PIME16_BARRIER();
+    }
+    // the wave's quad -> the exchange buffer; everyone reads the whole activation back (the layer's last barrier above ordered the
+    // previous readers of xb: they read it before they entered this layer's slice loop)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[j][r] = act16<ACT>(o4[j][r]);
+        *reinterpret_cast<f32x4*>(xb + ((4 * wave + j) * 64 + lane) * 4) = o4[j];
+    }
+    PIME16_BARRIER();
+#pragma unroll
+    for (int t = 0; t < T; ++t) out[t] = *reinterpret_cast<const f32x4*>(xb + (t * 64 + lane) * 4);
+}
+
 template <int TK, int TO = TK>
 __host__ __device__ constexpr int layer16_lds_floats() {
     return Layer16Geom<TK, TO>::NBUFW * Layer16Geom<TK, TO>::SLICE;
@@ -1153,7 +1229,9 @@ __device__ __forceinline__ float pick_col(const float (&obs)[D], int c0, int g) 
     return g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
 }
 
-template <int T, int KIND, int ENV, int STACK>
+// QUAD (plain actor, launches of <= 4 096 lanes): the four waves share ONE 16-lane tile, each a quad of every layer's output tiles
+// (layer16q) -- 256 workgroups instead of 64 for the reference script's 4 096 lanes, a quarter of the MFMA chain per env step.
+template <int T, int KIND, int ENV, int STACK, bool QUAD = false>
 __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int D = ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK), Di = ENV == 2 ? 0 : 1, Do = D - Di, H = T / 2;
@@ -1169,10 +1247,12 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
     __syncthreads();
     float* const region = lds + (MODULAR ? Sm.region : S.region);
     const int N = a.n;
-    const int m = blockIdx.x * k16Group + wave * 16 + sl;
+    static_assert(!QUAD || !MODULAR, "the tile-per-workgroup form serves the plain actor");
+    const int m = QUAD ? blockIdx.x * 16 + sl : blockIdx.x * k16Group + wave * 16 + sl;
     const bool valid = m < N;
     const int i = valid ? m : N - 1;   // idle lanes shadow the last env (compute, never store)
-    const bool writer = valid && g == 0;
+    const bool writer = valid && g == 0 && (!QUAD || wave == 0);
+    [[maybe_unused]] float* const xb = lds + S.total;   // QUAD: the activation exchange buffer behind the map
     const uint32_t gid = a.env_offset + (uint32_t)i;
     const bool evaluating = a.eval_mode != 0;   // wave-uniform
     const float sigma = evaluating ? 0.f : __expf(a.a_std_log[0]);
@@ -1238,9 +1318,15 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
             f32x4 h1[T], h2[T];
             first16<T, 1>(lds + S.w0, lds + S.b0, L.KS0, lane, xr, h1);
             PIME_NO_HOIST();
-            layer16<T, 1, true>(a.img + L.w1, lds + S.b1, region, lane, tid, h1, h2);
-            PIME_NO_HOIST();
-            layer16<T, 1, true>(a.img + L.w2, lds + S.b2, region, lane, tid, h2, h1);
+            if constexpr (QUAD) {
+                layer16q<T, 1>(a.img + L.w1, lds + S.b1, region, xb, lane, tid, h1, h2);
+                PIME_NO_HOIST();
+                layer16q<T, 1>(a.img + L.w2, lds + S.b2, region, xb, lane, tid, h2, h1);
+            } else {
+                layer16<T, 1, true>(a.img + L.w1, lds + S.b1, region, lane, tid, h1, h2);
+                PIME_NO_HOIST();
+                layer16<T, 1, true>(a.img + L.w2, lds + S.b2, region, lane, tid, h2, h1);
+            }
             a_avg = head16<T>(lds + S.w3, lds[S.b3], lane, h1);
         }
         // from here on: rollout.hip's step, one env lane per (wave, lane & 15)
@@ -1302,15 +1388,26 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
     }
 }
 
-template <int KIND, int ENV, int STACK>
-static int launch_rollout16_t(const RolloutArgs& a, hipStream_t s) {
+template <int KIND, int ENV, int STACK, bool QUAD>
+static int launch_rollout16_q(const RolloutArgs& a, hipStream_t s) {
     constexpr int T = 16, D = ENV == 0 ? 3 : (ENV == 1 ? 4 : 3 * STACK);
-    const size_t lds_bytes = sizeof(float) * (size_t)(KIND == MLP_MODULAR_ACTOR ? lds16m<T>(D, 1, false).total : lds16<T>(D, false).total);
+    const size_t lds_bytes = sizeof(float) * ((size_t)(KIND == MLP_MODULAR_ACTOR ? lds16m<T>(D, 1, false).total : lds16<T>(D, false).total) +
+                                              (QUAD ? T * 64 * 4 : 0));
     static LdsLimit lds_limit;  // per instantiation
-    PIME_RAISE_LDS(lds_limit, (rollout16_kernel<T, KIND, ENV, STACK>), 160 * 1024);
-    hipLaunchKernelGGL((rollout16_kernel<T, KIND, ENV, STACK>), dim3((a.n + k16Group - 1) / k16Group), dim3(k16Threads), lds_bytes, s, a);
+    PIME_RAISE_LDS(lds_limit, (rollout16_kernel<T, KIND, ENV, STACK, QUAD>), 160 * 1024);
+    const int per_wg = QUAD ? 16 : k16Group;
+    hipLaunchKernelGGL((rollout16_kernel<T, KIND, ENV, STACK, QUAD>), dim3((a.n + per_wg - 1) / per_wg), dim3(k16Threads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
+}
+template <int KIND, int ENV, int STACK>
+static int launch_rollout16_t(const RolloutArgs& a, hipStream_t s) {
+    if constexpr (KIND == MLP_PLAIN_ACTOR) {
+        bool quad = a.n <= 4096;   // at most one tile per compute unit: split it over the workgroup's waves (as csrc/rollout.hip: tiling)
+        if (const char* e = std::getenv("PIME_ROLLOUT_NARROW")) quad = std::atoi(e) == 2;
+        if (quad) return launch_rollout16_q<KIND, ENV, STACK, true>(a, s);
+    }
+    return launch_rollout16_q<KIND, ENV, STACK, false>(a, s);
 }
 
 // width 256 (csrc/rollout.hip dispatches here); binary16 rows (PIME_STATE_MIXED16) are not served at this width

@@ -46,9 +46,10 @@ pytestmark = pytest.mark.gpu
 ])
 def test_fused_rollout_replays_through_oracle(env_name, algo, N, md, tiles, monkeypatch):
     import oracle
-    if md == 256:
-        if tiles != "wide":
-            pytest.skip("width 256 has one kernel (the streamed 16-tile family)")
+    if md == 256:   # the streamed 16-tile family: one tile per wave, or (plain actor) one tile per workgroup
+        if tiles == "wide":
+            pytest.skip("width 256 has no 32-lane tiling")
+        monkeypatch.setenv("PIME_ROLLOUT_NARROW", {"narrow": "1", "quad": "2"}[tiles])
     else:   # the library picks 16-lane tiles (one per workgroup up to 4 096 lanes) by itself; every tiling must replay
         monkeypatch.setenv("PIME_ROLLOUT_NARROW", {"wide": "0", "narrow": "1", "quad": "2"}[tiles])
     from pime_amd import gym_control
@@ -83,7 +84,8 @@ def test_fused_rollout_replays_through_oracle(env_name, algo, N, md, tiles, monk
 
 @pytest.mark.parametrize("env_name,algo,N,md", [("PH_V35", "ResidualIntegratorModularPPO", 3000, 128),
                                                ("WT_INTEGRATOR", "ResidualIntegratorModularPPO", 1024, 64),
-                                               ("WT_STACKING4", "ResidualPPO", 2048, 128)])
+                                               ("WT_STACKING4", "ResidualPPO", 2048, 128),
+                                               ("WT_STACKING10", "ResidualPPO", 1000, 256)])   # the streamed family's layer16q
 def test_quad_and_narrow_tilings_give_the_same_bits(env_name, algo, N, md, monkeypatch):
     """One 16-lane tile per workgroup (QUAD: each wave a quarter of a layer's output tiles) runs the same MFMA sequence per
     accumulator as one tile per wave (NARROW): actions, observations, rewards and done flags are bit-identical -- which is what keeps a
