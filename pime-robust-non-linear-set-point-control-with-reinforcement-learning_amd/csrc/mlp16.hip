@@ -324,6 +324,73 @@ __device__ __forceinline__ void layer16q(const float* __restrict__ gimg, const f
     for (int t = 0; t < T; ++t) out[t] = *reinterpret_cast<const f32x4*>(xb + (t * 64 + lane) * 4);
 }
 
+// QUAD form of the modular actor's 2:1 tower layers (TO = 8 output tiles at width 256: Q = 2 quads): wave w computes the two output
+// tiles [2 w, 2 w + 2) -- the .xy or .zw half of quad w >> 1 of every k-step's fragments, eight k-steps per group (16 MFMAs) -- and
+// writes them, activated, into tiles tile0 + 2 w, tile0 + 2 w + 1 of the exchange buffer; the caller barriers and reads.
+template <int TK, int TO, int ACT>
+__device__ __forceinline__ void layer16rq(const float* __restrict__ gimg, const float* __restrict__ bias, float* __restrict__ wbuf,
+                                          float* __restrict__ xb, int tile0, int lane, int tid, const f32x4 (&in)[TK]) {
+    using G = Layer16Geom<TK, TO>;
+    static_assert(G::Q * 2 == k16Waves && G::SKS % 8 == 0, "two output tiles per wave; whole groups of eight k-steps per slice");
+    constexpr int Q = G::Q, SKS = G::SKS, NS = G::NS, SLICE = G::SLICE, PER = G::PER, NG = SKS / 8;
+    const int g = lane >> 4, wave = tid >> 6, q = wave >> 1, hf = wave & 1;
+    const int wave_base = wave * 256;
+    const unsigned voff = (unsigned)tid * 16u;
+    auto dma_slice = [&](int slice) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(gimg + slice * SLICE);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        const char* sbase = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+        float* ldst = wbuf + (slice % 3) * SLICE + wave_base;
+#pragma unroll
+        for (int p = 0; p < PER; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(sbase + p * (k16Threads * 16) + voff),
+                                             (lds_void_ptr)(ldst + p * k16Threads * 4), 16, 0, 0);
+    };
+    dma_slice(0);
+    if constexpr (NS > 1) dma_slice(1);
+    f32x4 o2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o2[j] = *reinterpret_cast<const f32x4*>(bias + (2 * wave + j) * 16 + 4 * g);
+    if constexpr (NS > 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+    PIME16_BARRIER();
+    float2 wf[2][8];
+    auto load_group = [&](int slice, int gidx, float2 (&dst)[8]) {
+        const float2* wl = reinterpret_cast<const float2*>(wbuf + (slice % 3) * SLICE) + 2 * lane + hf;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) dst[kk] = wl[((gidx * 8 + kk) * Q + q) * 128];
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 2 < NS) dma_slice(s + 2);
+        load_group(s, 0, wf[(s * NG) & 1]);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int cur = (s * NG + gi) & 1;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int m = half * 4; m < half * 4 + 4; ++m) {
+                    const int ks = s * SKS + gi * 8 + m;
+                    const float b = in[ks >> 2][ks & 3];
+                    const float2 w = wf[cur][m];
+                    o2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b, o2[0], 0, 0, 0);
+                    o2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b, o2[1], 0, 0, 0);
+                }
+                if (half == 0 && gi + 1 < NG) load_group(s, gi + 1, wf[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (s + 2 < NS) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+        PIME16_BARRIER();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o2[j][r] = act16<ACT>(o2[j][r]);
+        *reinterpret_cast<f32x4*>(xb + ((tile0 + 2 * wave + j) * 64 + lane) * 4) = o2[j];
+    }
+}
+
 template <int TK, int TO = TK>
 __host__ __device__ constexpr int layer16_lds_floats() {
     return Layer16Geom<TK, TO>::NBUFW * Layer16Geom<TK, TO>::SLICE;
@@ -1229,8 +1296,8 @@ __device__ __forceinline__ float pick_col(const float (&obs)[D], int c0, int g) 
     return g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
 }
 
-// QUAD (plain actor, launches of <= 4 096 lanes): the four waves share ONE 16-lane tile, each a quad of every layer's output tiles
-// (layer16q) -- 256 workgroups instead of 64 for the reference script's 4 096 lanes, a quarter of the MFMA chain per env step.
+// QUAD (launches of <= 4 096 lanes): the four waves share ONE 16-lane tile, each a quad of every layer's output tiles (layer16q; two
+// tiles of the modular actor's tower layers: layer16rq) -- 256 workgroups instead of 64 for the reference script's 4 096 lanes, a quarter of the MFMA chain per env step.
 template <int T, int KIND, int ENV, int STACK, bool QUAD = false>
 __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1247,12 +1314,11 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
     __syncthreads();
     float* const region = lds + (MODULAR ? Sm.region : S.region);
     const int N = a.n;
-    static_assert(!QUAD || !MODULAR, "the tile-per-workgroup form serves the plain actor");
     const int m = QUAD ? blockIdx.x * 16 + sl : blockIdx.x * k16Group + wave * 16 + sl;
     const bool valid = m < N;
     const int i = valid ? m : N - 1;   // idle lanes shadow the last env (compute, never store)
     const bool writer = valid && g == 0 && (!QUAD || wave == 0);
-    [[maybe_unused]] float* const xb = lds + S.total;   // QUAD: the activation exchange buffer behind the map
+    [[maybe_unused]] float* const xb = lds + (MODULAR ? Sm.total : S.total);   // QUAD: the activation exchange buffer behind the map
     const uint32_t gid = a.env_offset + (uint32_t)i;
     const bool evaluating = a.eval_mode != 0;   // wave-uniform
     const float sigma = evaluating ? 0.f : __expf(a.a_std_log[0]);
@@ -1302,14 +1368,22 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
                 f32x4 t1[T];
                 first16<T, 1>(lds + Sm.w0o, lds + Sm.b0o, Lm.KS0o, lane, xo, t1);
                 PIME_NO_HOIST();
-                layer16r<T, H, 1, true>(a.img + Lm.w1o, lds + Sm.b1o, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[0]));
+                if constexpr (QUAD) layer16rq<T, H, 1>(a.img + Lm.w1o, lds + Sm.b1o, region, xb, 0, lane, tid, t1);
+                else layer16r<T, H, 1, true>(a.img + Lm.w1o, lds + Sm.b1o, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[0]));
                 PIME_NO_HOIST();
                 first16<T, 1>(lds + Sm.w0i, lds + Sm.b0i, Lm.KS0i, lane, xi, t1);
                 PIME_NO_HOIST();
-                layer16r<T, H, 1, true>(a.img + Lm.w1i, lds + Sm.b1i, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[H]));
+                if constexpr (QUAD) layer16rq<T, H, 1>(a.img + Lm.w1i, lds + Sm.b1i, region, xb, H, lane, tid, t1);
+                else layer16r<T, H, 1, true>(a.img + Lm.w1i, lds + Sm.b1i, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[H]));
+            }
+            if constexpr (QUAD) {   // both towers' halves are in the exchange buffer: publish, read the concatenation back
+                PIME16_BARRIER();
+#pragma unroll
+                for (int t = 0; t < T; ++t) cat[t] = *reinterpret_cast<const f32x4*>(xb + (t * 64 + lane) * 4);
             }
             PIME_NO_HOIST();
-            layer16<T, 1, true>(a.img + Lm.wn, lds + Sm.bn, region, lane, tid, cat, n0);
+            if constexpr (QUAD) layer16q<T, 1>(a.img + Lm.wn, lds + Sm.bn, region, xb, lane, tid, cat, n0);
+            else layer16<T, 1, true>(a.img + Lm.wn, lds + Sm.bn, region, lane, tid, cat, n0);
             a_avg = head16<T>(lds + Sm.w3, lds[Sm.b3], lane, n0);
         } else {
             float xr[8];
@@ -1402,11 +1476,9 @@ static int launch_rollout16_q(const RolloutArgs& a, hipStream_t s) {
 }
 template <int KIND, int ENV, int STACK>
 static int launch_rollout16_t(const RolloutArgs& a, hipStream_t s) {
-    if constexpr (KIND == MLP_PLAIN_ACTOR) {
-        bool quad = a.n <= 4096;   // at most one tile per compute unit: split it over the workgroup's waves (as csrc/rollout.hip: tiling)
-        if (const char* e = std::getenv("PIME_ROLLOUT_NARROW")) quad = std::atoi(e) == 2;
-        if (quad) return launch_rollout16_q<KIND, ENV, STACK, true>(a, s);
-    }
+    bool quad = a.n <= 4096;   // at most one tile per compute unit: split it over the workgroup's waves (as csrc/rollout.hip: tiling)
+    if (const char* e = std::getenv("PIME_ROLLOUT_NARROW")) quad = std::atoi(e) == 2;
+    if (quad) return launch_rollout16_q<KIND, ENV, STACK, true>(a, s);
     return launch_rollout16_q<KIND, ENV, STACK, false>(a, s);
 }
 
