@@ -5,10 +5,15 @@
 // (/root/reference/elegantrl/agent_residual.py:52-69: select_action -> env.step(tanh(a)+s@priorK) -> append_buffer),
 // i.e. ~8 launches x 50 steps per rollout.
 //
-// One wave owns 32 lanes (both lane halves carry the same 32 envs: the MFMA layout needs the sample on lane&31, and
-// the env arithmetic is cheap enough to do redundantly instead of shuffling).  Two waves per workgroup so that 512
-// tiles spread over all 256 CUs with one wave per SIMD: per step a wave is latency-bound on its own 3-layer MFMA chain
-// (512 MFMAs x 64 cycles), so sharing a SIMD would only stretch the episode.
+// Tilings (template parameter NARROW; chosen per launch by tiling() below).  The packed image fills LDS, so a compute unit holds ONE
+// workgroup, and every wave is latency-bound on its own serial MFMA chain plus the env arithmetic of its lanes:
+//   0  one 32-lane tile per wave, two waves per workgroup (rounds 1-2): v_mfma_f32_32x32x2_f32, 512 x 64 cycles per env step; both
+//      lane halves carry the same 32 envs (the MFMA layout needs the sample on lane & 31).  Leaves two SIMDs of every unit idle.
+//   1  one 16-lane tile per wave, four waves per workgroup: v_mfma_f32_16x16x4_f32 on the same image (policy_forward16), 512 x 32
+//      cycles; the four lane groups carry the same 16 envs.  The default above 4 096 lanes.
+//   2  one 16-lane tile per WORKGROUP, each wave a quarter of every layer's output tiles (policy_forward16q), 128 x 32 cycles + two
+//      LDS exchanges; the default up to 4 096 lanes (at most one tile per compute unit).  Bit-identical to tiling 1.
+// The redundant copies of an env do the same arithmetic in every lane group / wave (cheap enough not to shuffle); one of them stores.
 // The env arithmetic is env_device.hpp -- literally the code of ph_step_kernel / ph_reset_kernel.
 #include <cstdlib>
 #include "env_device.hpp"
