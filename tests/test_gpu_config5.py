@@ -119,13 +119,13 @@ def test_config5_mixed16_rank_slice_rollout_and_update():
     ph.close(); wt.close()
 
 
-@pytest.mark.parametrize("tiles", ["wide", "narrow"])
+@pytest.mark.parametrize("tiles", ["wide", "narrow", "quad"])
 def test_config5_stepwise_half_rollout_matches_fused(tiles, monkeypatch):
     """The launch-by-launch form (policy forward + pime_env_step_residual_h per lock-step, what a shape without a fused rollout
     takes) writes the same binary16 trajectory as the fused kernel when fed the same exploration noise.  32-lane tiles run the
     forward kernel's own MFMA chain; the default 16-lane tiles sum in another order, and a last-bit difference of a policy mean now
     and then moves a binary16 row by one ulp (1e-3 relative), which the next policy means see: looser bounds there."""
-    monkeypatch.setenv("PIME_ROLLOUT_NARROW", "1" if tiles == "narrow" else "0")
+    monkeypatch.setenv("PIME_ROLLOUT_NARROW", {"wide": "0", "narrow": "1", "quad": "2"}[tiles])
     from pime_amd import gym_control
     from pime_amd.elegantrl.run import make_buffer
     N = 1024
