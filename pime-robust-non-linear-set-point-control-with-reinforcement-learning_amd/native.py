@@ -9,7 +9,10 @@ import subprocess
 
 from ._pkg import PACKAGE_DIR
 
-LIB_PATH = os.environ.get("PIME_LIB_PATH") or os.path.join(PACKAGE_DIR, "libpime_hip.so")   # override: kernel A/B runs only
+# The product loads the in-tree library and nothing else.  PIME_LIB_PATH (another build of the same library, tools/variant.sh) is honoured
+# only when PIME_ALLOW_LIB_OVERRIDE=1 is set beside it -- the same-box kernel A/B scripts (tools/ab_*.sh) do that; on its own it is ignored.
+_override = os.environ.get("PIME_LIB_PATH") if os.environ.get("PIME_ALLOW_LIB_OVERRIDE") == "1" else None
+LIB_PATH = _override or os.path.join(PACKAGE_DIR, "libpime_hip.so")
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0

@@ -4,7 +4,7 @@ TAG=$1; CFG=$2; shift 2
 OUT=gpurun_out/${TAG}.log; rm -f $OUT
 for rep in 1 2 3; do
   for v in "$@"; do
-    PIME_LIB_PATH=$PWD/variants/$v.so timeout -k 10 200 bash tools/kstats.sh tools/grad_ab.py $CFG 2>&1 | grep "ppo_fused_kernel\|ppo16_kernel" | head -2 | sed "s/^/$v /" >> $OUT || exit 1
+    PIME_ALLOW_LIB_OVERRIDE=1 PIME_LIB_PATH=$PWD/variants/$v.so timeout -k 10 200 bash tools/kstats.sh tools/grad_ab.py $CFG 2>&1 | grep "ppo_fused_kernel\|ppo16_kernel" | head -2 | sed "s/^/$v /" >> $OUT || exit 1
   done
 done
 python3 - $OUT <<'PY'
