@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 13
+#define PIME_ABI_VERSION 14
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -363,6 +363,56 @@ int pime_rollout_offpolicy_supported(const pime_env* env, int32_t md);
 int pime_rollout_offpolicy(pime_env* env, int32_t md, const float* packed_actor, const double* priorK, float explore_noise,
                            float gamma, float reward_scale, int32_t n_steps, uint64_t noise_seed, uint32_t noise_epoch,
                            float* obs, float* ring_state, float* ring_other, int32_t slot0, int32_t slots, pime_stream stream);
+
+/* -- fused TD3 optimizer step ---------------------------------------------------------------------------------------
+ * replaces, per iteration of AgentTD3.update_net's loop (elegantrl/agent.py:314-331): get_obj_critic_raw (:361-370 -- the gather of
+ * buffer.sample_batch's rows (replay.py:344-351), act_target.get_action with clamped smoothing noise (net.py:107-110),
+ * min(cri_target.get_q1_q2), q_label, cri.get_q1_q2, SmoothL1 x 2), obj_critic.backward(), cri_optimizer.step(), the delayed
+ * soft_update(cri_target) (:116-124), obj_actor = -cri_target(state, act(state)).mean() (:323-324), obj_actor.backward(),
+ * act_optimizer.step() and the delayed soft_update(act_target): FOUR launches (csrc/td3_fused.hip) -- critic gradients
+ * (one 16-sample tile per workgroup, its four waves splitting every layer's output features), slab reduction + Adam + soft
+ * update of the critic, actor gradients (through the TARGET critic's first head, as the reference has it), the same for the actor.
+ * Nets: Actor (net.py:96-110: D -> md ReLU -> md ReLU -> md ReLU -> 1, tanh) and CriticTwin (net.py:305-332: D+1 -> md ReLU -> md
+ * ReLU, two linear heads), action_dim 1, D <= 7, md 64 | 128.  The weights are read where they live: every net is ONE flat
+ * float32 tensor in nn.Module parameter order with each tensor starting on a multiple of 4 floats (pime_td3_param_offsets;
+ * padding words zero) -- no packed images, nothing to re-pack after a step. */
+typedef struct pime_td3_net {
+    float* param;        /* [dev] float32[pime_td3_param_floats]: the online net */
+    float* target;       /* [dev] same layout: the target net (soft-updated in place) */
+    float* grad;         /* [dev] same layout, WRITTEN: this step's gradient (the reference's .grad after backward()) */
+    float* exp_avg;      /* [dev] Adam state, same layout; zero at construction */
+    float* exp_avg_sq;
+    float* step;         /* [dev] float32[2], zeroed at construction: [0] step counter (advanced on the device), [1] scratch */
+    float lr, beta1, beta2, eps;
+} pime_td3_net;
+typedef struct pime_td3_batch {
+    const float* state;      /* [dev] float32[rows, D]: replay states (ReplayBuffer.buf_state / VecReplayBuffer.buf_state) */
+    const float* other;      /* [dev] float32[rows, 3]: reward * scale, mask, action (buf_other) */
+    const int64_t* idx;      /* [dev] int64[table_rows, B]: the sampled rows of every optimizer step of an update */
+    const int64_t* nxt;      /* [dev] int64[table_rows, B]: their successors (idx + 1 in the flat ring, idx + N lanes in the vector ring) */
+    const float* noise;      /* [dev] float32[table_rows, B] standard normal draws of the smoothing noise (torch.randn_like), or NULL:
+                              * drawn in the kernel -- Philox4x32-10 keyed by noise_seed, counter (batch position, noise_epoch,
+                              * table row, stream 3), Box-Muller cosine branch in float64 */
+    int64_t* cursor;         /* [dev] int64[2] or NULL (row 0, epoch offset 0): [0] the table row of this step, advanced by the call;
+                              * [1] is added to noise_epoch (the host bumps it per update, so that a captured HIP graph draws
+                              * fresh noise in every replay) */
+    int32_t B;
+    uint64_t noise_seed;
+    uint32_t noise_epoch;
+    float policy_noise, noise_clip;   /* 0.2, 0.5 (agent.py:281, net.py:109) */
+} pime_td3_batch;
+int pime_td3_supported(int32_t D, int32_t action_dim, int32_t md);
+/* which: 0 actor, 1 critic.  offsets [8]: float offset of every parameter tensor (W, b pairs in module order) */
+int64_t pime_td3_param_floats(int32_t which, int32_t D, int32_t md);
+int pime_td3_param_offsets(int32_t which, int32_t D, int32_t md, int32_t* offsets);
+int64_t pime_td3_workspace_floats(int32_t D, int32_t md, int32_t B);
+/* soft_mode: 0 no soft target update, 1 soft update, 2 soft update when cursor[0] % update_freq == 0 (the reference's delayed update).
+ * phases: bit 0 = critic half (gradients, Adam, soft update), bit 1 = actor half; 3 = the whole step (the cursor advances with bit 1).
+ * loss [dev] float32[4] or NULL: [0] += obj_actor, [1] += obj_critic of this step (zero them per update), [2], [3] = this step's values.
+ * workspace [dev] float32[pime_td3_workspace_floats]. */
+int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_td3_net* critic, const pime_td3_batch* batch,
+                  float tau, int32_t update_freq, int32_t soft_mode, int32_t phases, float* workspace, float* loss,
+                  pime_stream stream);
 
 /* replaces: self.optimizer.step() of the single Adam over both nets (elegantrl/agent.py:565-566,656-657; no weight
  * decay, no amsgrad) when every parameter lives in ONE flat tensor.  All [dev] float32[n]; step [dev] float32[2], zeroed

@@ -78,3 +78,13 @@ class HipBackend:
                        "slower).  Supported: INTEGRATION.md 'Supported shapes'")
             return False
         return ops.FusedPPOGrad(act, cri, max_batch)
+
+    def fused_td3(self, agent, max_batch):
+        """ops.FusedTD3 for a TD3 agent's four nets, or False when their shape has no fused optimizer step."""
+        if not ops.FusedTD3.supported(agent.act, agent.cri):
+            _warn_once(("td3", type(agent.act).__name__, getattr(agent.act, "state_dim", None)),
+                       f"pime_amd: no fused TD3 step for ({type(agent.act).__name__}, {type(agent.cri).__name__}) at these shapes; "
+                       "update_net runs through torch autograd on the GPU (several times slower).  Supported: state_dim <= 7, "
+                       "width 64 / 128, action_dim 1")
+            return False
+        return ops.FusedTD3(agent.act, agent.act_target, agent.cri, agent.cri_target, max_batch, agent.learning_rate)

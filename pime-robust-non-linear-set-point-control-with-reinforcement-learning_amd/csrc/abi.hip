@@ -11,6 +11,7 @@
 #include "rollout.hpp"
 #include "rollout_eval.hpp"
 #include "rollout_offpolicy.hpp"
+#include "td3.hpp"
 
 namespace pime {
 
@@ -71,6 +72,12 @@ int launch_dw(const DwArgs&, int, hipStream_t);
 int launch_critic_scale(int, int, float* const*, const double*, int, float*, float*, int64_t*, hipStream_t);
 int launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float*, const int32_t*, float* const (*)[2], hipStream_t);
 int launch_rollout(int, int, const RolloutArgs&, hipStream_t);
+// td3_fused.hip
+int td3_grid(int);
+int64_t td3_workspace_floats(int, int, int);
+bool td3_supported(int, int, int);
+int launch_td3_grad(bool, int, const Td3GradArgs&, int, hipStream_t);
+int launch_td3_apply(const Td3ApplyArgs&, hipStream_t);
 
 }  // namespace pime
 
@@ -1141,6 +1148,83 @@ int pime_ppo_minibatch_step(const pime_ppo_net* actor, const pime_ppo_net* criti
                             float* loss_sums, const pime_adam* opt, pime_stream stream) {
     PIME_REQUIRE(opt != nullptr, "pime_ppo_minibatch_step: NULL pime_adam");
     return minibatch_impl(actor, critic, b, ratio_clip, lambda_entropy, critic_scale, moments, loss_sums, opt, stream);
+}
+
+// -- fused TD3 optimizer step (csrc/td3_fused.hip) -----------------------------------------------------------------------
+int pime_td3_supported(int32_t D, int32_t action_dim, int32_t md) { return td3_supported(D, action_dim, md) ? 1 : 0; }
+
+int64_t pime_td3_param_floats(int32_t which, int32_t D, int32_t md) {
+    if (!td3_supported(D, 1, md) || which < 0 || which > 1) {
+        set_error("pime_td3_param_floats: unsupported net (which %d, D %d, width %d)", which, D, md);
+        return -1;
+    }
+    return which == 0 ? td3_actor_off(D, md).total : td3_critic_off(D, md).total;
+}
+
+int pime_td3_param_offsets(int32_t which, int32_t D, int32_t md, int32_t* offsets) {
+    PIME_REQUIRE(offsets && td3_supported(D, 1, md) && (which == 0 || which == 1), "pime_td3_param_offsets: bad arguments");
+    if (which == 0) {
+        const Td3ActorOff o = td3_actor_off(D, md);
+        const int v[8] = {o.W1, o.b1, o.W2, o.b2, o.W3, o.b3, o.w4, o.b4};
+        for (int i = 0; i < 8; ++i) offsets[i] = v[i];
+    } else {
+        const Td3CriticOff o = td3_critic_off(D, md);
+        const int v[8] = {o.W1, o.b1, o.W2, o.b2, o.q1w, o.q1b, o.q2w, o.q2b};
+        for (int i = 0; i < 8; ++i) offsets[i] = v[i];
+    }
+    return PIME_OK;
+}
+
+int64_t pime_td3_workspace_floats(int32_t D, int32_t md, int32_t B) {
+    if (!td3_supported(D, 1, md) || B < 1) {
+        set_error("pime_td3_workspace_floats: unsupported shape (D %d, width %d, batch %d)", D, md, B);
+        return -1;
+    }
+    return td3_workspace_floats(D, md, B);
+}
+
+static int check_td3_net(const pime_td3_net* n, const char* what) {
+    PIME_REQUIRE(n && n->param && n->target && n->grad && n->exp_avg && n->exp_avg_sq && n->step, "pime_td3_step: NULL pointer in the %s's pime_td3_net", what);
+    PIME_REQUIRE(n->lr > 0.f && n->beta1 >= 0.f && n->beta1 < 1.f && n->beta2 >= 0.f && n->beta2 < 1.f && n->eps > 0.f,
+                 "pime_td3_step: bad Adam constants for the %s", what);
+    return PIME_OK;
+}
+
+int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_td3_net* critic, const pime_td3_batch* b, float tau,
+                  int32_t update_freq, int32_t soft_mode, int32_t phases, float* workspace, float* loss, pime_stream stream) {
+    PIME_REQUIRE(td3_supported(D, 1, md), "pime_td3_step: no kernel for state_dim %d width %d (D <= %d, width 64 | 128)", D, md, kTd3MaxD);
+    if (int rc = check_td3_net(actor, "actor")) return rc;
+    if (int rc = check_td3_net(critic, "critic")) return rc;
+    PIME_REQUIRE(b && b->state && b->other && b->idx && b->nxt && b->B >= 1, "pime_td3_step: bad pime_td3_batch");
+    PIME_REQUIRE(workspace != nullptr, "pime_td3_step: NULL workspace");
+    PIME_REQUIRE(soft_mode >= 0 && soft_mode <= 2 && (soft_mode != 2 || update_freq >= 1), "pime_td3_step: soft_mode %d / update_freq %d", soft_mode, update_freq);
+    PIME_REQUIRE(phases >= 1 && phases <= 3, "pime_td3_step: phases %d", phases);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = td3_grid(b->B), ngroups = (b->B + 15) / 16;
+    const Td3SlabLayout LA = td3_actor_slab(D, md), LC = td3_critic_slab(D, md);
+    float* const slab_c = workspace;
+    float* const slab_a = workspace + (size_t)grid * LC.stride;
+    Td3Batch tb{b->state, b->other, b->idx, b->nxt, b->noise, b->cursor, b->B, b->noise_seed, b->noise_epoch, b->policy_noise, b->noise_clip};
+    auto apply = [&](const pime_td3_net* n, const Td3SlabLayout& L, const float* slab, int slot, bool advance) {
+        Td3ApplyArgs a{};
+        a.L = L; a.slab = slab; a.nslabs = grid;
+        a.param = n->param; a.target = n->target; a.grad = n->grad; a.exp_avg = n->exp_avg; a.exp_avg_sq = n->exp_avg_sq; a.step = n->step;
+        a.lr = n->lr; a.b1 = n->beta1; a.b2 = n->beta2; a.eps = n->eps; a.tau = tau;
+        a.soft_mode = soft_mode; a.update_freq = update_freq > 0 ? update_freq : 1; a.cursor = b->cursor; a.advance_cursor = advance ? 1 : 0;
+        a.loss = loss; a.loss_slot = slot; a.inv_B = 1.0f / (float)b->B;
+        return launch_td3_apply(a, s);
+    };
+    if (phases & 1) {
+        Td3GradArgs g{tb, D, actor->target, critic->param, critic->target, slab_c, LC.stride, ngroups};
+        if (int rc = launch_td3_grad(true, md, g, grid, s)) return rc;
+        if (int rc = apply(critic, LC, slab_c, 1, false)) return rc;
+    }
+    if (phases & 2) {
+        Td3GradArgs g{tb, D, actor->param, critic->target, nullptr, slab_a, LA.stride, ngroups};
+        if (int rc = launch_td3_grad(false, md, g, grid, s)) return rc;
+        if (int rc = apply(actor, LA, slab_a, 0, true)) return rc;
+    }
+    return PIME_OK;
 }
 
 }  // extern "C"

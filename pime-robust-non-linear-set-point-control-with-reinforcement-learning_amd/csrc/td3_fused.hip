@@ -1,0 +1,762 @@
+// One TD3 optimizer step as FOUR launches: critic gradients, critic apply, actor gradients, actor apply.
+//
+// replaces (reference, /root/reference/elegantrl/agent.py): AgentTD3.update_net's loop body (:314-331) -- get_obj_critic_raw
+// (:361-370: minibatch gather, target actor + clamped smoothing noise (net.py:107-110), twin target heads + min, online twin
+// forward, SmoothL1 x 2), obj_critic.backward(), cri_optimizer.step(), the delayed soft update of cri_target (:116-124),
+// obj_actor = -cri_target(state, act(state)).mean() (:323-324; the reference differentiates through the TARGET critic's first head),
+// obj_actor.backward(), act_optimizer.step(), the delayed soft update of act_target -- ~150 PyTorch / rocBLAS launches per
+// optimizer step in round 3 (0.76 ms, 0.016 of the f32 matrix peak at batch 4 096).
+//
+// Shape of the problem: batch 4 096, nets of width 128 -- 0.48 MFLOP per sample, 2 GFLOP per step.  A sample tile per wave for the
+// whole net (the PPO kernels' decomposition) would occupy 128 of 1 024 SIMDs.  Here a WORKGROUP owns one 16-sample tile and its
+// four waves split every layer's OUTPUT features (v_mfma_f32_16x16x4_f32; wave w computes output tiles [PER w, PER w + PER) of
+// md / 16): batch 4 096 = 256 workgroups = every SIMD of the chip has a wave.  Consequences:
+//   * a weight element is used by exactly ONE wave of a workgroup, once: weights go global -> registers (16-byte row pieces of the
+//     nn.Linear tensors themselves: a lane's four consecutive k values of an output row are one global_load_dwordx4), a layer ahead
+//     of their use.  No packed images, no LDS staging, nothing to re-pack after an optimizer step.
+//   * the layer's activation meets in LDS ("chain layout": tile t, lane group q, sample j, 4 registers = features 16 t + 4 q + r;
+//     lane groups 72 floats apart): written as the accumulators stand (one ds_write_b128 per tile), read back by every wave as the
+//     next layer's B operands (one ds_read_b128 per tile), and read again -- the same image, conflict-free ds_read_b32 -- as BOTH
+//     operands of the weight gradients dW = dZ^T H, which contract over the tile's 16 samples (4 k-steps per 16 x 16 block).
+//   * dX = W^T dZ reads W by columns (four dword loads where the forward has one 16-byte load).
+//   * every workgroup leaves one partial gradient (slab, block-major in accumulator order); td3_apply_kernel sums the slabs in slab
+//     order (bit-reproducible), applies torch.optim.Adam to the element it has just reduced and, on delayed steps, the soft target
+//     update -- the parameters are the only copy of the weights, so that is all an optimizer step has to write.
+// The minibatch rows come from an index table [steps][B] walked by a device-side cursor (one HIP graph serves every step); the
+// smoothing noise from a table of normals (parity tests inject the reference's draws) or from Philox stream 3 in the kernel.
+#include <cstdlib>
+#include "td3.hpp"
+#include "pime_common.hpp"
+
+namespace pime {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kTd3Threads = 256, kTd3Tile = 16;
+constexpr int kQP = 72, kTP = 4 * kQP;   // chain layout: floats between lane groups / tiles (72 = 16 samples x 4 + 8: the operand reads of the weight gradients hit 32 banks)
+constexpr uint32_t STREAM_TD3_SMOOTH = 3;
+
+#define TD3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define TD3_NO_HOIST() asm volatile("" ::: "memory")
+
+__device__ __forceinline__ f32x4_t mfma16(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4_t ld4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+__device__ __forceinline__ void st4(float* p, const f32x4_t& v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+__device__ __forceinline__ f32x4_t relu4(f32x4_t v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    return v;
+}
+// d * [h > 0] (torch's threshold_backward)
+__device__ __forceinline__ f32x4_t gate4(f32x4_t d, const f32x4_t& h) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = h[r] > 0.f ? d[r] : 0.f;
+    return d;
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add16(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a row (= the tile's 16 samples), result in every lane of the row; fixed order
+__device__ __forceinline__ float row_sum16(float v) {
+    v = dpp_add16<0xb1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add16<0x4e>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add16<0x141>(v);   // row_half_mirror
+    return dpp_add16<0x140>(v);   // row_mirror
+}
+__device__ __forceinline__ f32x4_t row_sum16(f32x4_t v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = row_sum16(v[r]);
+    return v;
+}
+
+// ---- chain-layout activation images in LDS ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void chain_put(float* __restrict__ buf, int lane, int tile, const f32x4_t& v) {
+    st4(buf + tile * kTP + (lane >> 4) * kQP + (lane & 15) * 4, v);
+}
+template <int NT>
+__device__ __forceinline__ void chain_get(const float* __restrict__ buf, int lane, f32x4_t (&v)[NT]) {
+    const float* p = buf + (lane >> 4) * kQP + (lane & 15) * 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) v[t] = ld4(p + t * kTP);
+}
+// element (feature 16 t + i, sample 4 s + q) of an image, for the lane (q, i): the A / B operand of a weight-gradient k-step
+__device__ __forceinline__ float chain_elem(const float* __restrict__ buf, int lane, int t, int s) {
+    const int i = lane & 15, q = lane >> 4;
+    return buf[t * kTP + (i >> 2) * kQP + (4 * s + q) * 4 + (i & 3)];
+}
+
+// ---- weights: global -> registers --------------------------------------------------------------------------------------------------
+// forward: A operand of output tile t0 + n, k-step (kt, r) = W[16 (t0 + n) + i][16 kt + 4 q + r]: component r of one 16-byte load
+template <int NT, int PER>
+__device__ __forceinline__ void load_w(const float* __restrict__ W, int t0, int lane, f32x4_t (&w)[PER][NT]) {
+    const float* p = W + (size_t)(16 * t0 + (lane & 15)) * (NT * 16) + 4 * (lane >> 4);
+#pragma unroll
+    for (int n = 0; n < PER; ++n)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) w[n][kt] = ld4(p + n * 16 * (NT * 16) + 16 * kt);
+}
+// transposed (dX = W^T dZ): A operand of output (= input-feature) tile t0 + n, k-step (kt, r) = W[16 kt + 4 q + r][16 (t0 + n) + i]
+template <int NT, int PER>
+__device__ __forceinline__ void load_wt(const float* __restrict__ W, int t0, int lane, f32x4_t (&w)[PER][NT]) {
+    const float* p = W + (size_t)(4 * (lane >> 4)) * (NT * 16) + 16 * t0 + (lane & 15);
+#pragma unroll
+    for (int n = 0; n < PER; ++n)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[n][kt][r] = p[(size_t)(16 * kt + r) * (NT * 16) + 16 * n];
+}
+
+// out[n] = bias + W in (output tiles t0 .. t0 + PER - 1); bias == nullptr: no bias (the backward chain)
+template <int NT, int PER>
+__device__ __forceinline__ void layer(const f32x4_t (&w)[PER][NT], const float* __restrict__ bias, int t0, int lane,
+                                      const f32x4_t (&in)[NT], f32x4_t (&out)[PER]) {
+#pragma unroll
+    for (int n = 0; n < PER; ++n) {
+        if (bias) out[n] = ld4(bias + 16 * (t0 + n) + 4 * (lane >> 4));
+        else out[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int n = 0; n < PER; ++n) out[n] = mfma16(w[n][kt][r], in[kt][r], out[n]);
+}
+
+// first layer, fan-in Din <= 8: k-step 0 = input columns 0..3, k-step 1 = columns 4..7.  x0 / x1: this lane's B operands, input
+// column q / 4 + q of sample j (0 beyond Din).
+template <int PER>
+__device__ __forceinline__ void layer_first(const float* __restrict__ W, const float* __restrict__ bias, int Din, int t0, int lane,
+                                            float x0, float x1, f32x4_t (&out)[PER]) {
+    const int i = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < PER; ++n) {
+        const float* row = W + (size_t)(16 * (t0 + n) + i) * Din;
+        const float a0 = q < Din ? row[q] : 0.f;
+        const float a1 = 4 + q < Din ? row[4 + q] : 0.f;
+        out[n] = ld4(bias + 16 * (t0 + n) + 4 * q);
+        out[n] = mfma16(a0, x0, out[n]);
+        if (Din > 4) out[n] = mfma16(a1, x1, out[n]);
+    }
+}
+
+// partial head: sum over this wave's PER * 16 features of w[f] h[j][f], for the lane's sample j (same value in the four lane groups)
+template <int PER>
+__device__ __forceinline__ float head_partial(const float* __restrict__ w, int t0, int lane, const f32x4_t (&h)[PER]) {
+    float p = 0.f;
+#pragma unroll
+    for (int n = 0; n < PER; ++n) {
+        const f32x4_t wv = ld4(w + 16 * (t0 + n) + 4 * (lane >> 4));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p = fmaf(h[n][r], wv[r], p);
+    }
+    p += __shfl_xor(p, 16);
+    p += __shfl_xor(p, 32);
+    return p;
+}
+// cross-wave sums through LDS: slot = 64 floats [wave][sample]
+__device__ __forceinline__ void red_put(float* __restrict__ red, int slot, int wave, int lane, float p) {
+    if (lane < 16) red[slot * 64 + wave * 16 + lane] = p;
+}
+__device__ __forceinline__ float red_get(const float* __restrict__ red, int slot, int lane) {
+    const float* p = red + slot * 64 + (lane & 15);
+    return ((p[0] + p[16]) + p[32]) + p[48];
+}
+
+// ---- weight gradients ----------------------------------------------------------------------------------------------------------------
+// acc[n][b] = sum over the tile's samples of dZ[s][16 (t0 + n) + .] (x) H[s][16 b + .]   (both operands from chain images)
+template <int NT, int PER>
+__device__ __forceinline__ void dw_blocks(const float* __restrict__ dz, const float* __restrict__ h, int t0, int lane,
+                                          f32x4_t (&acc)[PER][NT]) {
+#pragma unroll
+    for (int n = 0; n < PER; ++n)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[n][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float av[PER], bv[NT];
+#pragma unroll
+        for (int n = 0; n < PER; ++n) av[n] = chain_elem(dz, lane, t0 + n, s);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bv[b] = chain_elem(h, lane, b, s);
+#pragma unroll
+        for (int n = 0; n < PER; ++n)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[n][b] = mfma16(av[n], bv[b], acc[n][b]);
+    }
+}
+// first-layer weight gradient: B = the tile's input rows [16 samples][16 columns, zero beyond Din] (xin)
+template <int PER>
+__device__ __forceinline__ void dw_first(const float* __restrict__ dz, const float* __restrict__ xin, int t0, int lane,
+                                         f32x4_t (&acc)[PER]) {
+#pragma unroll
+    for (int n = 0; n < PER; ++n) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float bv = xin[(4 * s + (lane >> 4)) * 16 + (lane & 15)];
+#pragma unroll
+        for (int n = 0; n < PER; ++n) acc[n] = mfma16(chain_elem(dz, lane, t0 + n, s), bv, acc[n]);
+    }
+}
+__device__ __forceinline__ void slab_put(float* __restrict__ p, f32x4_t v, bool accum) {
+    if (accum) v += ld4(p);
+    st4(p, v);
+}
+// a vector gradient (bias, head weights) of this wave's features: v = per-sample terms, summed over the tile's samples
+template <int PER>
+__device__ __forceinline__ void vec_grad(float* __restrict__ seg, int t0, int lane, const f32x4_t (&v)[PER], bool accum) {
+#pragma unroll
+    for (int n = 0; n < PER; ++n) {
+        const f32x4_t s = row_sum16(v[n]);
+        if ((lane & 15) == 0) slab_put(seg + 16 * (t0 + n) + 4 * (lane >> 4), s, accum);
+    }
+}
+
+struct Td3Lds {
+    int buf[4], xin, red, total;
+};
+__host__ __device__ constexpr int td3_buf_floats(int NT) { return NT * kTP; }
+__host__ __device__ inline Td3Lds td3_lds(int NT) {
+    Td3Lds L{};
+    int o = 0;
+    for (int k = 0; k < 4; ++k) { L.buf[k] = o; o += td3_buf_floats(NT); }
+    L.xin = o; o += 16 * 16;
+    L.red = o; o += 8 * 64;
+    L.total = o;
+    return L;
+}
+
+// this lane's smoothing-noise draw for batch position pos
+__device__ __forceinline__ float td3_noise(const Td3Batch& b, long long trow, int pos) {
+    if (b.noise) return b.noise[(size_t)trow * b.B + pos];
+    double ua, ub;
+    const uint32_t epoch = b.noise_epoch + (b.cursor ? (uint32_t)b.cursor[1] : 0u);   // cursor[1]: bumped by the host per update
+    philox_pair(b.noise_seed, (uint32_t)pos, epoch, (uint32_t)trow, STREAM_TD3_SMOOTH, ua, ub);
+    return (float)(sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586476925286766559 * ub));
+}
+
+// ======================================================================================================== critic gradients
+template <int MD>
+__global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs a) {
+    constexpr int NT = MD / 16, PER = NT / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Td3Lds F = td3_lds(NT);
+    float* const B0 = lds + F.buf[0];
+    float* const B1 = lds + F.buf[1];
+    float* const B2 = lds + F.buf[2];
+    float* const xin = lds + F.xin;
+    float* const red = lds + F.red;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = wave * PER;
+    const int D = a.D, Dc = D + 1;
+    const Td3ActorOff PA = td3_actor_off(D, MD);
+    const Td3CriticOff PC = td3_critic_off(D, MD);
+    const Td3SlabLayout SL = td3_critic_slab(D, MD);
+    const float invB = 1.0f / (float)a.b.B;
+    const long long trow = a.b.cursor ? a.b.cursor[0] : 0;
+    float* const sl = a.slab + (size_t)blockIdx.x * a.stride;
+    float loss_acc = 0.f;   // wave 0, lanes 0..15: this workgroup's loss terms
+
+#pragma unroll 1
+    for (int group = blockIdx.x; group < a.ngroups; group += gridDim.x) {
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        const int j = lane & 15, q = lane >> 4;
+        const bool accum = group != (int)blockIdx.x;
+        const int pos = group * kTd3Tile + j;
+        const bool valid = pos < a.b.B;
+        const int p = valid ? pos : a.b.B - 1;
+        const long long row = a.b.idx[(size_t)trow * a.b.B + p], nrow = a.b.nxt[(size_t)trow * a.b.B + p];
+        // first-layer B operands: input column q / 4 + q of sample j
+        const float* srow = a.b.state + (size_t)row * D;
+        const float* nsrow = a.b.state + (size_t)nrow * D;
+        const float s0 = q < D ? srow[q] : 0.f, s1 = 4 + q < D ? srow[4 + q] : 0.f;
+        const float n0 = q < D ? nsrow[q] : 0.f, n1 = 4 + q < D ? nsrow[4 + q] : 0.f;
+        const float* orow = a.b.other + (size_t)row * 3;
+        const float reward = orow[0], mask = orow[1], action = orow[2];
+        const float eps = td3_noise(a.b, trow, p);
+        TD3_BARRIER();   // the previous group is done with the LDS images
+        if (wave == 0) {   // the online critic's input rows [s, a, 0 ..] for its first-layer weight gradient
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int col = 4 * c + q;
+                xin[j * 16 + col] = col < D ? srow[col] : (col == D ? action : 0.f);
+            }
+        }
+        f32x4_t wA[PER][NT], wB[PER][NT], in[NT];
+
+        // ------------------------------------------------------------------ next_a = clamp(tanh(act_target(s')) + clamp(noise))
+        load_w<NT, PER>(a.act + PA.W2, t0, lane, wA);
+        {
+            f32x4_t h[PER];
+            layer_first<PER>(a.act + PA.W1, a.act + PA.b1, D, t0, lane, n0, n1, h);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) chain_put(B0, lane, t0 + n, relu4(h[n]));
+        }
+        load_w<NT, PER>(a.act + PA.W3, t0, lane, wB);
+        TD3_BARRIER();
+        chain_get<NT>(B0, lane, in);
+        {
+            f32x4_t h[PER];
+            layer<NT, PER>(wA, a.act + PA.b2, t0, lane, in, h);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) chain_put(B1, lane, t0 + n, relu4(h[n]));
+        }
+        load_w<NT, PER>(a.cri_target + PC.W2, t0, lane, wA);
+        TD3_BARRIER();
+        chain_get<NT>(B1, lane, in);
+        float next_a;
+        {
+            f32x4_t h[PER];
+            layer<NT, PER>(wB, a.act + PA.b3, t0, lane, in, h);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) h[n] = relu4(h[n]);
+            red_put(red, 0, wave, lane, head_partial<PER>(a.act + PA.w4, t0, lane, h));
+            TD3_BARRIER();
+            const float pre = red_get(red, 0, lane) + a.act[PA.b4];
+            const float nz = fminf(fmaxf(eps * a.b.policy_noise, -a.b.noise_clip), a.b.noise_clip);   // net.py:109
+            next_a = fminf(fmaxf(tanhf(pre) + nz, -1.0f), 1.0f);
+        }
+        // ------------------------------------------------------------------ q_label = r + mask * min(cri_target twin heads)(s', next_a)
+        load_w<NT, PER>(a.cri + PC.W2, t0, lane, wB);
+        float label;
+        {
+            const float x0 = q < D ? n0 : (q == D ? next_a : 0.f);
+            const float x1 = 4 + q < D ? n1 : (4 + q == D ? next_a : 0.f);
+            f32x4_t h[PER];
+            layer_first<PER>(a.cri_target + PC.W1, a.cri_target + PC.b1, Dc, t0, lane, x0, x1, h);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) chain_put(B0, lane, t0 + n, relu4(h[n]));
+            TD3_BARRIER();
+            chain_get<NT>(B0, lane, in);
+            layer<NT, PER>(wA, a.cri_target + PC.b2, t0, lane, in, h);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) h[n] = relu4(h[n]);
+            red_put(red, 1, wave, lane, head_partial<PER>(a.cri_target + PC.q1w, t0, lane, h));
+            red_put(red, 2, wave, lane, head_partial<PER>(a.cri_target + PC.q2w, t0, lane, h));
+            TD3_BARRIER();
+            const float tq1 = red_get(red, 1, lane) + a.cri_target[PC.q1b], tq2 = red_get(red, 2, lane) + a.cri_target[PC.q2b];
+            label = reward + mask * fminf(tq1, tq2);
+        }
+        // ------------------------------------------------------------------ online twin critic on (s, a): forward
+        f32x4_t h1[PER], h2[PER];
+        {
+            const float x0 = q < D ? s0 : (q == D ? action : 0.f);
+            const float x1 = 4 + q < D ? s1 : (4 + q == D ? action : 0.f);
+            layer_first<PER>(a.cri + PC.W1, a.cri + PC.b1, Dc, t0, lane, x0, x1, h1);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) { h1[n] = relu4(h1[n]); chain_put(B1, lane, t0 + n, h1[n]); }
+        }
+        load_wt<NT, PER>(a.cri + PC.W2, t0, lane, wA);   // for dH1 = W2^T dZ2
+        TD3_BARRIER();
+        chain_get<NT>(B1, lane, in);
+        layer<NT, PER>(wB, a.cri + PC.b2, t0, lane, in, h2);
+#pragma unroll
+        for (int n = 0; n < PER; ++n) h2[n] = relu4(h2[n]);
+        red_put(red, 3, wave, lane, head_partial<PER>(a.cri + PC.q1w, t0, lane, h2));
+        red_put(red, 4, wave, lane, head_partial<PER>(a.cri + PC.q2w, t0, lane, h2));
+        TD3_BARRIER();
+        // ------------------------------------------------------------------ SmoothL1 x 2 (beta = 1, mean) and its gradient
+        float g1 = 0.f, g2 = 0.f;
+        {
+            const float d1 = red_get(red, 3, lane) + a.cri[PC.q1b] - label, d2 = red_get(red, 4, lane) + a.cri[PC.q2b] - label;
+            const float a1 = fabsf(d1), a2 = fabsf(d2);
+            if (valid) {
+                g1 = (a1 < 1.f ? d1 : (d1 > 0.f ? 1.f : -1.f)) * invB;
+                g2 = (a2 < 1.f ? d2 : (d2 > 0.f ? 1.f : -1.f)) * invB;
+                if (wave == 0 && q == 0) loss_acc += (a1 < 1.f ? 0.5f * d1 * d1 : a1 - 0.5f) + (a2 < 1.f ? 0.5f * d2 * d2 : a2 - 0.5f);
+            }
+        }
+        // heads: weight / bias gradients, dZ2 = (g1 wq1 + g2 wq2) [h2 > 0]
+        {
+            f32x4_t v1[PER], v2[PER], dz[PER];
+#pragma unroll
+            for (int n = 0; n < PER; ++n) {
+                const f32x4_t w1 = ld4(a.cri + PC.q1w + 16 * (t0 + n) + 4 * q), w2 = ld4(a.cri + PC.q2w + 16 * (t0 + n) + 4 * q);
+                v1[n] = h2[n] * g1;
+                v2[n] = h2[n] * g2;
+                dz[n] = gate4(w1 * g1 + w2 * g2, h2[n]);
+                chain_put(B2, lane, t0 + n, dz[n]);
+            }
+            vec_grad<PER>(sl + SL.seg[4].slab_off, t0, lane, v1, accum);
+            vec_grad<PER>(sl + SL.seg[6].slab_off, t0, lane, v2, accum);
+            vec_grad<PER>(sl + SL.seg[3].slab_off, t0, lane, dz, accum);   // net_sa.2 bias
+            if (wave == 0) {
+                const float b1 = row_sum16(g1), b2 = row_sum16(g2);
+                if (lane == 0) {
+                    float* p1 = sl + SL.seg[5].slab_off;
+                    float* p2 = sl + SL.seg[7].slab_off;
+                    p1[0] = accum ? p1[0] + b1 : b1;
+                    p2[0] = accum ? p2[0] + b2 : b2;
+                }
+            }
+        }
+        TD3_BARRIER();   // dZ2 published
+        {   // net_sa.2 weight gradient
+            f32x4_t acc[PER][NT];
+            dw_blocks<NT, PER>(B2, B1, t0, lane, acc);
+            float* seg = sl + SL.seg[2].slab_off;
+#pragma unroll
+            for (int n = 0; n < PER; ++n)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) slab_put(seg + (((t0 + n) * NT + b) * 64 + lane) * 4, acc[n][b], accum);
+        }
+        TD3_NO_HOIST();
+        chain_get<NT>(B2, lane, in);
+        {
+            f32x4_t d1[PER];
+            layer<NT, PER>(wA, nullptr, t0, lane, in, d1);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) { d1[n] = gate4(d1[n], h1[n]); chain_put(B0, lane, t0 + n, d1[n]); }
+            vec_grad<PER>(sl + SL.seg[1].slab_off, t0, lane, d1, accum);   // net_sa.0 bias
+        }
+        TD3_BARRIER();   // dZ1 published
+        {
+            f32x4_t acc[PER];
+            dw_first<PER>(B0, xin, t0, lane, acc);
+            float* seg = sl + SL.seg[0].slab_off;
+#pragma unroll
+            for (int n = 0; n < PER; ++n) slab_put(seg + ((t0 + n) * 64 + lane) * 4, acc[n], accum);
+        }
+    }
+    if (wave == 0) {
+        const float t = row_sum16(loss_acc);
+        if (tid == 0) st4(sl + SL.scalar_off, f32x4_t{t, 0.f, 0.f, 0.f});
+    }
+}
+
+// ======================================================================================================== actor gradients
+// obj_actor = -mean(cri_target.q1(s, tanh(act(s))))  (agent.py:323-324), differentiated down to the actor's parameters
+template <int MD>
+__global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a) {
+    constexpr int NT = MD / 16, PER = NT / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Td3Lds F = td3_lds(NT);
+    float* const B0 = lds + F.buf[0];
+    float* const B1 = lds + F.buf[1];
+    float* const B2 = lds + F.buf[2];
+    float* const B3 = lds + F.buf[3];
+    float* const xin = lds + F.xin;
+    float* const red = lds + F.red;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = wave * PER;
+    const int D = a.D, Dc = D + 1;
+    const Td3ActorOff PA = td3_actor_off(D, MD);
+    const Td3CriticOff PC = td3_critic_off(D, MD);
+    const Td3SlabLayout SL = td3_actor_slab(D, MD);
+    const float invB = 1.0f / (float)a.b.B;
+    const long long trow = a.b.cursor ? a.b.cursor[0] : 0;
+    float* const sl = a.slab + (size_t)blockIdx.x * a.stride;
+    float q_acc = 0.f;
+
+#pragma unroll 1
+    for (int group = blockIdx.x; group < a.ngroups; group += gridDim.x) {
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        const int j = lane & 15, q = lane >> 4;
+        const bool accum = group != (int)blockIdx.x;
+        const int pos = group * kTd3Tile + j;
+        const bool valid = pos < a.b.B;
+        const int p = valid ? pos : a.b.B - 1;
+        const long long row = a.b.idx[(size_t)trow * a.b.B + p];
+        const float* srow = a.b.state + (size_t)row * D;
+        const float s0 = q < D ? srow[q] : 0.f, s1 = 4 + q < D ? srow[4 + q] : 0.f;
+        TD3_BARRIER();
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int col = 4 * c + q;
+                xin[j * 16 + col] = col < D ? srow[col] : 0.f;
+            }
+        }
+        f32x4_t wA[PER][NT], wB[PER][NT], in[NT];
+        f32x4_t a1[PER], a2[PER], a3[PER], c1[PER], c2[PER];
+
+        // ------------------------------------------------------------------ action = tanh(act(s))
+        load_w<NT, PER>(a.act + PA.W2, t0, lane, wA);
+        layer_first<PER>(a.act + PA.W1, a.act + PA.b1, D, t0, lane, s0, s1, a1);
+#pragma unroll
+        for (int n = 0; n < PER; ++n) { a1[n] = relu4(a1[n]); chain_put(B0, lane, t0 + n, a1[n]); }
+        load_w<NT, PER>(a.act + PA.W3, t0, lane, wB);
+        TD3_BARRIER();
+        chain_get<NT>(B0, lane, in);
+        layer<NT, PER>(wA, a.act + PA.b2, t0, lane, in, a2);
+#pragma unroll
+        for (int n = 0; n < PER; ++n) { a2[n] = relu4(a2[n]); chain_put(B1, lane, t0 + n, a2[n]); }
+        load_w<NT, PER>(a.cri + PC.W2, t0, lane, wA);
+        TD3_BARRIER();
+        chain_get<NT>(B1, lane, in);
+        layer<NT, PER>(wB, a.act + PA.b3, t0, lane, in, a3);
+#pragma unroll
+        for (int n = 0; n < PER; ++n) a3[n] = relu4(a3[n]);
+        red_put(red, 0, wave, lane, head_partial<PER>(a.act + PA.w4, t0, lane, a3));
+        TD3_BARRIER();
+        const float act = tanhf(red_get(red, 0, lane) + a.act[PA.b4]);
+        // ------------------------------------------------------------------ q1 = cri_target.q1(s, action)
+        {
+            const float x0 = q < D ? s0 : (q == D ? act : 0.f);
+            const float x1 = 4 + q < D ? s1 : (4 + q == D ? act : 0.f);
+            layer_first<PER>(a.cri + PC.W1, a.cri + PC.b1, Dc, t0, lane, x0, x1, c1);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) { c1[n] = relu4(c1[n]); chain_put(B2, lane, t0 + n, c1[n]); }
+        }
+        load_wt<NT, PER>(a.cri + PC.W2, t0, lane, wB);   // dC1 = W2^T dZc2
+        TD3_BARRIER();
+        chain_get<NT>(B2, lane, in);
+        layer<NT, PER>(wA, a.cri + PC.b2, t0, lane, in, c2);
+#pragma unroll
+        for (int n = 0; n < PER; ++n) c2[n] = relu4(c2[n]);
+        red_put(red, 1, wave, lane, head_partial<PER>(a.cri + PC.q1w, t0, lane, c2));   // (the value itself only feeds the logged objective)
+        // ------------------------------------------------------------------ backward through the critic to the action
+        const float g = valid ? -invB : 0.f;   // d(-mean q1) / d q1
+#pragma unroll
+        for (int n = 0; n < PER; ++n) {
+            const f32x4_t wq = ld4(a.cri + PC.q1w + 16 * (t0 + n) + 4 * q);
+            chain_put(B3, lane, t0 + n, gate4(wq * g, c2[n]));
+        }
+        load_wt<NT, PER>(a.act + PA.W3, t0, lane, wA);   // dA2 = W3^T dZ3
+        TD3_BARRIER();
+        if (valid && wave == 0 && q == 0) q_acc += red_get(red, 1, lane) + a.cri[PC.q1b];
+        chain_get<NT>(B3, lane, in);
+        float dpre;
+        {
+            f32x4_t d[PER];
+            layer<NT, PER>(wB, nullptr, t0, lane, in, d);
+            float pa = 0.f;   // d obj / d action = sum_f W1[f][D] dZc1[f]
+#pragma unroll
+            for (int n = 0; n < PER; ++n) {
+                d[n] = gate4(d[n], c1[n]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pa = fmaf(d[n][r], a.cri[PC.W1 + (size_t)(16 * (t0 + n) + 4 * q + r) * Dc + D], pa);
+            }
+            pa += __shfl_xor(pa, 16);
+            pa += __shfl_xor(pa, 32);
+            red_put(red, 2, wave, lane, pa);
+            TD3_BARRIER();
+            dpre = red_get(red, 2, lane) * (1.0f - act * act);   // tanh'
+        }
+        // ------------------------------------------------------------------ actor backward + weight gradients
+        {
+            f32x4_t v[PER], dz[PER];
+#pragma unroll
+            for (int n = 0; n < PER; ++n) {
+                const f32x4_t w4 = ld4(a.act + PA.w4 + 16 * (t0 + n) + 4 * q);
+                v[n] = a3[n] * dpre;
+                dz[n] = gate4(w4 * dpre, a3[n]);
+                chain_put(B2, lane, t0 + n, dz[n]);
+            }
+            vec_grad<PER>(sl + SL.seg[6].slab_off, t0, lane, v, accum);    // net.6 weight
+            vec_grad<PER>(sl + SL.seg[5].slab_off, t0, lane, dz, accum);   // net.4 bias
+            if (wave == 0) {
+                const float bg = row_sum16(dpre);
+                if (lane == 0) {
+                    float* pb = sl + SL.seg[7].slab_off;
+                    pb[0] = accum ? pb[0] + bg : bg;
+                }
+            }
+        }
+        load_wt<NT, PER>(a.act + PA.W2, t0, lane, wB);   // dA1 = W2^T dZ2
+        TD3_BARRIER();   // dZ3 published
+        {
+            f32x4_t acc[PER][NT];
+            dw_blocks<NT, PER>(B2, B1, t0, lane, acc);   // net.4: dZ3^T A2
+            float* seg = sl + SL.seg[4].slab_off;
+#pragma unroll
+            for (int n = 0; n < PER; ++n)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) slab_put(seg + (((t0 + n) * NT + b) * 64 + lane) * 4, acc[n][b], accum);
+        }
+        TD3_NO_HOIST();
+        chain_get<NT>(B2, lane, in);
+        {
+            f32x4_t d[PER];
+            layer<NT, PER>(wA, nullptr, t0, lane, in, d);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) { d[n] = gate4(d[n], a2[n]); chain_put(B3, lane, t0 + n, d[n]); }
+            vec_grad<PER>(sl + SL.seg[3].slab_off, t0, lane, d, accum);    // net.2 bias
+        }
+        TD3_BARRIER();   // dZ2 published
+        {
+            f32x4_t acc[PER][NT];
+            dw_blocks<NT, PER>(B3, B0, t0, lane, acc);   // net.2: dZ2^T A1
+            float* seg = sl + SL.seg[2].slab_off;
+#pragma unroll
+            for (int n = 0; n < PER; ++n)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) slab_put(seg + (((t0 + n) * NT + b) * 64 + lane) * 4, acc[n][b], accum);
+        }
+        TD3_NO_HOIST();
+        chain_get<NT>(B3, lane, in);
+        {
+            f32x4_t d[PER];
+            layer<NT, PER>(wB, nullptr, t0, lane, in, d);
+#pragma unroll
+            for (int n = 0; n < PER; ++n) { d[n] = gate4(d[n], a1[n]); chain_put(B1, lane, t0 + n, d[n]); }
+            vec_grad<PER>(sl + SL.seg[1].slab_off, t0, lane, d, accum);    // net.0 bias
+        }
+        TD3_BARRIER();   // dZ1 published
+        {
+            f32x4_t acc[PER];
+            dw_first<PER>(B1, xin, t0, lane, acc);
+            float* seg = sl + SL.seg[0].slab_off;
+#pragma unroll
+            for (int n = 0; n < PER; ++n) slab_put(seg + ((t0 + n) * 64 + lane) * 4, acc[n], accum);
+        }
+    }
+    if (wave == 0) {
+        const float t = row_sum16(q_acc);
+        if (tid == 0) st4(sl + SL.scalar_off, f32x4_t{t, 0.f, 0.f, 0.f});
+    }
+}
+
+// ======================================================================================================== slab reduction + Adam + soft update
+// Workgroup = 64 consecutive 16-byte words of the slab layout; wave w sums slabs w, w + 4, ...; the partial sums meet in LDS and are
+// combined in wave order (bit-reproducible); wave 0 then owns four gradient elements per lane: writes them, applies torch.optim.Adam
+// (defaults: no weight decay, no amsgrad) to their parameters and, on a delayed step, target = tau * param + (1 - tau) * target
+// (agent.py:116-124, the reference's operand order).
+__global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) {
+    __shared__ float4 part[4][64];
+    __shared__ float adam_sh[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwords = a.L.stride / 4;
+    const int unit = blockIdx.x * 64 + lane;
+    if (wave == 1) {   // Adam's bias corrections, off wave 0's critical path; every workgroup reads the OLD step count
+        const float tn = a.step[0] + 1.0f;
+        const double t = (double)tn;
+        const float ss = a.lr / (float)(1.0 - pow((double)a.b1, t));
+        const float bs = (float)sqrt(1.0 - pow((double)a.b2, t));
+        if (lane == 0) { adam_sh[0] = tn; adam_sh[1] = ss; adam_sh[2] = bs; }
+    }
+    bool soft = a.soft_mode == 1;
+    if (a.soft_mode == 2) soft = (a.cursor ? a.cursor[0] : 0) % a.update_freq == 0;
+    // which elements this lane finishes
+    long long flat[4] = {-1, -1, -1, -1};
+    bool scalar_word = false;
+    if (unit < nwords) {
+        const int off = unit * 4;
+        if (off >= a.L.scalar_off) scalar_word = true;
+        else {
+            int si = 0;
+            while (si + 1 < a.L.nseg && off >= a.L.seg[si + 1].slab_off) ++si;
+            const Td3Seg sg = a.L.seg[si];
+            const int u = (off - sg.slab_off) / 4;
+            if (u < sg.n4) {
+                if (sg.tb > 0) {
+                    const int blk = u >> 6, ln = u & 63;
+                    const int row = (blk / sg.tb) * 16 + 4 * (ln >> 4), col = (blk % sg.tb) * 16 + (ln & 15);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (col < sg.ncols) flat[k] = sg.flat_off + (long long)(row + k) * sg.ldw + col;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (u * 4 + k < sg.n) flat[k] = sg.flat_off + u * 4 + k;
+                }
+            }
+        }
+    }
+    // optimizer state of those elements, requested before the slab loads
+    float pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f}, pp[4] = {0.f, 0.f, 0.f, 0.f}, pt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (flat[k] >= 0) {
+                pm[k] = a.exp_avg[flat[k]]; pv[k] = a.exp_avg_sq[flat[k]]; pp[k] = a.param[flat[k]];
+                if (soft) pt[k] = a.target[flat[k]];
+            }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (unit < nwords) {
+        const float* base = a.slab + (size_t)unit * 4;
+        const size_t stride = (size_t)a.L.stride;
+        int s = wave;
+        for (; s + 12 < a.nslabs; s += 16) {   // four loads in flight
+            const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
+            const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(s + 4) * stride);
+            const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(s + 8) * stride);
+            const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(s + 12) * stride);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        }
+        for (; s < a.nslabs; s += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    const float t_new = adam_sh[0], step_size = adam_sh[1], bc2_sqrt = adam_sh[2];
+    if (wave == 0 && unit < nwords) {
+        float4 t = part[0][lane];
+        for (int w = 1; w < 4; ++w) { const float4 v = part[w][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        const float gv[4] = {t.x, t.y, t.z, t.w};
+        if (scalar_word) {
+            if (a.loss) {
+                const float val = (a.loss_slot == 0 ? -gv[0] : gv[0]) * a.inv_B;
+                a.loss[a.loss_slot] += val;
+                a.loss[2 + a.loss_slot] = val;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (flat[k] < 0) continue;
+                const long long e = flat[k];
+                a.grad[e] = gv[k];
+                const float mi = pm[k] + (gv[k] - pm[k]) * (1.0f - a.b1);
+                const float vi = pv[k] * a.b2 + gv[k] * gv[k] * (1.0f - a.b2);
+                a.exp_avg[e] = mi;
+                a.exp_avg_sq[e] = vi;
+                const float pn = pp[k] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + a.eps));
+                a.param[e] = pn;
+                if (soft) a.target[e] = pn * a.tau + pt[k] * (1.0f - a.tau);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int* arrivals = reinterpret_cast<unsigned int*>(a.step + 1);
+        if (atomicAdd(arrivals, 1u) == gridDim.x - 1) {   // every workgroup has read the old step count and the cursor
+            *arrivals = 0;
+            a.step[0] = t_new;
+            if (a.advance_cursor && a.cursor) a.cursor[0] += 1;
+        }
+    }
+}
+
+// ======================================================================================================== host side
+int td3_grid(int B) {
+    const int ngroups = (B + kTd3Tile - 1) / kTd3Tile;
+    return ngroups < kTd3MaxSlabs ? ngroups : kTd3MaxSlabs;
+}
+int64_t td3_workspace_floats(int D, int md, int B) {
+    const int64_t g = td3_grid(B);
+    return g * (td3_actor_slab(D, md).stride + td3_critic_slab(D, md).stride);
+}
+bool td3_supported(int D, int A, int md) { return A == 1 && D >= 1 && D <= kTd3MaxD && (md == 64 || md == 128); }
+
+template <int MD>
+static int launch_grad(bool critic, const Td3GradArgs& a, int grid, hipStream_t s) {
+    const size_t lds_bytes = sizeof(float) * (size_t)td3_lds(MD / 16).total;
+    if (critic) hipLaunchKernelGGL((td3_critic_kernel<MD>), dim3(grid), dim3(kTd3Threads), lds_bytes, s, a);
+    else hipLaunchKernelGGL((td3_actor_kernel<MD>), dim3(grid), dim3(kTd3Threads), lds_bytes, s, a);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+int launch_td3_grad(bool critic, int md, const Td3GradArgs& a, int grid, hipStream_t s) {
+    if (md == 128) return launch_grad<128>(critic, a, grid, s);
+    if (md == 64) return launch_grad<64>(critic, a, grid, s);
+    set_error("no fused TD3 instantiation for width %d", md);
+    return PIME_ERR_ARG;
+}
+int launch_td3_apply(const Td3ApplyArgs& a, hipStream_t s) {
+    const int nwords = a.L.stride / 4;
+    hipLaunchKernelGGL(td3_apply_kernel, dim3((nwords + 63) / 64), dim3(kTd3Threads), 0, s, a);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+}  // namespace pime

@@ -656,9 +656,11 @@ class AgentTD3(AgentBase):
     One-instance env + flat ring buffer: the reference's loop, op for op (pinned against the reference's weights by
     tests/test_td3_golden_cpu.py).  Vectorised env (`env.num_envs`) + `VecReplayBuffer`: all lanes step in lock-step through
     the HIP env kernel, transitions stay in HBM, and `update_net` runs target_step / num_envs * repeat_times optimizer steps
-    (the reference's "one gradient step per env step" counted per LOCK-STEP, not per lane), each replayed from HIP graphs
-    after the first eager ones.  Nets, losses and Adam are PyTorch-ROCm, as BASELINE.json's north_star prescribes for the
-    off-policy update."""
+    (the reference's "one gradient step per env step" counted per LOCK-STEP, not per lane).  On the GPU an optimizer step is
+    four hand-written launches (`pime_td3_step`, csrc/td3_fused.hip: critic gradients, slab reduction + Adam + delayed soft
+    update, actor gradients through the target critic, the same for the actor), a whole update_net one HIP graph; shapes the
+    kernels do not serve (state_dim > 7, widths other than 64 / 128, data parallel) and CPU tensors run the same arithmetic as
+    PyTorch modules (`_one_update`)."""
 
     def __init__(self, backend=None, device=None):
         super().__init__(backend, device)
@@ -671,6 +673,10 @@ class AgentTD3(AgentBase):
         # forward is 16 workgroups on three serial 256-MFMA chains (~25 us each), slower than rocBLAS's small GEMMs -- 165 vs 157 ms
         # per bench step.  PIME_TD3_FUSED_TARGETS=1 switches it on (parity: tests/test_gpu_td3.py).
         self.use_fused_targets = os.environ.get("PIME_TD3_FUSED_TARGETS", "0") == "1"
+        self.use_fused_update = os.environ.get("PIME_TD3_FUSED", "1") == "1"   # the optimizer step on the hand-written kernels
+        self.draw_hook = None      # tests: callable(n_steps, batch) -> (idx, nxt, noise) tables of a whole update (injected draws)
+        self.launch_timer = None   # bench.py: callable(name, fn) timing one update's launches with HIP events
+        self._fused_td3 = None
         self._graphs = None
         self._obs = None
         self._packed_act = None
@@ -695,11 +701,26 @@ class AgentTD3(AgentBase):
         self._graphs = None
         self._packed_act = None
         self._tpacks = None
+        self._fused_td3 = None   # its Adam moments belong to the optimizers just replaced
 
     def weights_changed(self):
         super().weights_changed()
         self._tpacks = None   # the target nets' packed images are stale (checkpoint load, rebuilt optimizer)
-        self._graphs = None
+        self._graphs = None   # (the fused step reads the parameters where they live: nothing of it goes stale)
+
+    def _fused_step(self, batch_size):
+        """ops.FusedTD3 serving the current nets, or None -> the PyTorch modules (_one_update)."""
+        if not self.use_fused_update or self.device.type != "cuda" or self.dp is not None or not hasattr(self.backend, "fused_td3"):
+            return None
+        f = self._fused_td3
+        if f is False:
+            return None
+        if f is None or not f.wraps(self):
+            f = self._fused_td3 = self.backend.fused_td3(self, batch_size)
+            if f is False:
+                return None
+        f.ensure_batch(batch_size)
+        return f
 
     def _target_packs(self):
         """(actor_target, q1 head, q2 head of cri_target) as packed images of the hand-written forward kernel, or None -> the torch
@@ -855,6 +876,9 @@ class AgentTD3(AgentBase):
         dev = self.device
         vec = isinstance(buffer, VecReplayBuffer)
         n_steps = int(target_step * repeat_times) if not vec else max(1, int(target_step // buffer.num_envs * repeat_times))
+        fused = self._fused_step(batch_size) if n_steps else None
+        if fused is not None:
+            return self._update_fused(fused, buffer, n_steps, batch_size, int(target_step if not vec else n_steps))
         sums = torch.zeros(2, device=dev)
         obj_actor = obj_critic = torch.zeros((), device=dev)
         graphs = self._graphs if (vec and self.use_hip_graphs and dev.type == "cuda") else None
@@ -883,6 +907,76 @@ class AgentTD3(AgentBase):
             logger.record("train/actor_loss", mean[0])
             logger.record("train/critic_loss", mean[1])
         return float(obj_actor), float(obj_critic) / 2
+
+    def _update_fused(self, f, buffer, n_steps, batch_size, n_updates):
+        """update_net on the fused step: the sampled rows of ALL n_steps optimizer steps are drawn at once into an index table that
+        the kernels walk with a device-side cursor (so every step is the same launch sequence), the smoothing noise is drawn inside
+        the critic kernel (Philox stream 3; `draw_hook` injects tables instead), and from the second call on the whole update --
+        n_steps x 4 launches -- is ONE HIP graph.  The only host synchronisation is the read of the four loss words at the end."""
+        dev = self.device
+        vec = isinstance(buffer, VecReplayBuffer)
+        st = getattr(f, "tables", None)
+        if st is None or st["shape"] != (n_steps, batch_size):
+            i64 = dict(dtype=torch.int64, device=dev)
+            st = f.tables = {"shape": (n_steps, batch_size), "idx": torch.zeros((n_steps, batch_size), **i64),
+                             "nxt": torch.zeros((n_steps, batch_size), **i64), "noise": None, "graph": None, "key": None, "warm": False}
+        idx, nxt = st["idx"], st["nxt"]
+        if self.draw_hook is not None:
+            h_idx, h_nxt, h_noise = self.draw_hook(n_steps, batch_size)
+            idx.copy_(torch.as_tensor(h_idx).to(dev)); nxt.copy_(torch.as_tensor(h_nxt).to(dev))
+            if st["noise"] is None:
+                st["noise"] = torch.zeros((n_steps, batch_size), dtype=torch.float32, device=dev)
+            st["noise"].copy_(torch.as_tensor(h_noise).to(dev).reshape(n_steps, batch_size))
+        elif vec:   # VecReplayBuffer.sample_indices for the whole table: uniform over the rows that have a successor
+            assert buffer.stored_slots >= 2, "need two stored steps before sampling"
+            N = buffer.num_envs
+            u = torch.randint(2 ** 62, (n_steps, batch_size), device=dev) % buffer._bounds[0]   # bounds live on the device (replay.py)
+            lane = u % N
+            slot = (u // N + buffer._bounds[1]) % buffer.slots                   # slots in age order start at the oldest
+            torch.add(slot * N, lane, out=idx)
+            torch.add(((slot + 1) % buffer.slots) * N, lane, out=nxt)            # successor: same lane, next slot
+        else:       # ReplayBuffer.sample_batch (replay.py:344-351): rows [0, now_len - 1), successor = the next row
+            torch.randint(buffer.now_len - 1, (n_steps, batch_size), device=dev, out=idx)
+            torch.add(idx, 1, out=nxt)
+        noise = st["noise"] if self.draw_hook is not None else None
+        if not hasattr(self, "_smooth_seed"):
+            self._smooth_seed = (int(torch.initial_seed()) ^ 0x5DEECE66D) & (2 ** 63 - 1)   # smoothing noise follows torch's seed
+        f.loss.zero_()
+        f.cursor[0] = 0
+        f.cursor[1] += 1   # the noise epoch: a captured graph draws fresh noise in every replay
+
+        def run():
+            for _ in range(n_steps):
+                f.step(buffer.buf_state, buffer.buf_other, idx, nxt, noise, self.soft_update_tau, self.update_freq, self.policy_noise,
+                       noise_seed=self._smooth_seed)
+
+        key = (buffer.buf_state.data_ptr(), buffer.buf_other.data_ptr(), noise is None, self.soft_update_tau, self.update_freq,
+               self.policy_noise)
+        if self.use_hip_graphs and st["warm"] and (st["graph"] is None or st["key"] != key):
+            try:
+                torch.cuda.synchronize(dev)
+                g = torch.cuda.CUDAGraph()
+                with _no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    run()
+                st["graph"], st["key"] = g, key
+                f.cursor[0] = 0   # (a capture executes nothing, but keep the state explicit)
+            except RuntimeError as exc:
+                print(f"| HIP graph capture of the TD3 update failed ({exc}); continuing with eager launches")
+                self.use_hip_graphs = False
+                torch.cuda.synchronize(dev)
+                st["graph"] = None
+        go = st["graph"].replay if (self.use_hip_graphs and st["graph"] is not None and st["key"] == key) else run
+        if self.launch_timer is not None:
+            self.launch_timer("td3_update", go)
+        else:
+            go()
+        st["warm"] = True
+        self._n_updates += n_updates
+        tot = f.loss.tolist()   # the update's only host synchronisation
+        logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
+        logger.record("train/actor_loss", tot[0] / n_steps)
+        logger.record("train/critic_loss", tot[1] / n_steps)
+        return tot[2], tot[3] / 2
 
     def _capture_updates(self, buffer, batch_size, key):
         out = {"key": key}

@@ -16,7 +16,7 @@ LIB_PATH = _override or os.path.join(PACKAGE_DIR, "libpime_hip.so")
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
-ABI_VERSION = 13
+ABI_VERSION = 14
 ENV_PH, ENV_WT = 0, 1
 STATE_F64, STATE_MIXED, STATE_MIXED16 = 0, 1, 2
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
@@ -55,6 +55,18 @@ class Adam(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("step", C.c_void_p), ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float), ("image_map", C.c_void_p)]
+
+
+class Td3Net(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("target", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p),
+                ("exp_avg_sq", C.c_void_p), ("step", C.c_void_p), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float)]
+
+
+class Td3Batch(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("other", C.c_void_p), ("idx", C.c_void_p), ("nxt", C.c_void_p), ("noise", C.c_void_p),
+                ("cursor", C.c_void_p), ("B", C.c_int32), ("noise_seed", C.c_uint64), ("noise_epoch", C.c_uint32),
+                ("policy_noise", C.c_float), ("noise_clip", C.c_float)]
 
 
 class EnvCfg(C.Structure):
@@ -128,6 +140,11 @@ _SIGNATURES = {
     "pime_ppo_minibatch_step": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "pime_ppo_image_map": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "pime_adam_step_images": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "pime_td3_supported": (C.c_int, [_i32, _i32, _i32]),
+    "pime_td3_param_floats": (C.c_int64, [_i32, _i32, _i32]),
+    "pime_td3_param_offsets": (C.c_int, [_i32, _i32, _i32, _vp]),
+    "pime_td3_workspace_floats": (C.c_int64, [_i32, _i32, _i32]),
+    "pime_td3_step": (C.c_int, [_i32, _i32, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -355,3 +355,122 @@ class FlatAdam:
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count, "lr": self.lr}
+
+
+_TD3_ACTOR_PARAMS = ["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias", "net.6.weight", "net.6.bias"]
+_TD3_CRITIC_PARAMS = ["net_sa.0.weight", "net_sa.0.bias", "net_sa.2.weight", "net_sa.2.bias", "net_q1.weight", "net_q1.bias",
+                      "net_q2.weight", "net_q2.bias"]
+
+
+class FusedTD3:
+    """One TD3 optimizer step -- critic objective, its gradients, Adam, delayed soft update, actor objective through the target
+    critic, its gradients, Adam, delayed soft update (elegantrl/agent.py:314-331 of the reference) -- as four HIP launches
+    (csrc/td3_fused.hip, `pime_td3_step`).
+
+    The four nets (actor, actor target, critic, critic target) are re-homed into ONE flat float32 tensor each, in the order and at
+    the 16-byte-aligned offsets the kernels read them at (`pime_td3_param_offsets`); every nn.Parameter becomes a view into its
+    net's flat tensor and every online parameter's .grad a view into the flat gradient the step writes.  The kernels read the
+    nn.Linear tensors themselves: there are no packed copies to keep in step with the weights."""
+
+    def __init__(self, act, act_target, cri, cri_target, max_batch, lr, betas=(0.9, 0.999), eps=1e-8):
+        dev = next(cri.parameters()).device
+        _need_cuda(next(cri.parameters()))
+        L = native.lib()
+        self.device = dev
+        self.D, self.md = int(act.state_dim), int(act.net[0].out_features)
+        if not self.supported(act, cri):
+            raise native.PimeError(f"fused TD3 step unsupported for state_dim {self.D} width {self.md}: {native.last_error()}")
+        self.max_batch = int(max_batch)
+        self.nets = (act, act_target, cri, cri_target)
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def rehome(module, names, which):
+            n = L.pime_td3_param_floats(which, self.D, self.md)
+            offs = (C.c_int32 * 8)()
+            native.check(L.pime_td3_param_offsets(which, self.D, self.md, offs), "pime_td3_param_offsets")
+            flat = torch.zeros(n, **f32)
+            sd = dict(module.named_parameters())
+            with torch.no_grad():
+                for name, off in zip(names, offs):
+                    p = sd[name]
+                    assert p.dtype == torch.float32
+                    flat[off:off + p.numel()].copy_(p.detach().reshape(-1))
+                    p.data = flat[off:off + p.numel()].view_as(p)
+            return flat, list(offs)
+
+        self.act_flat, self.act_off = rehome(act, _TD3_ACTOR_PARAMS, 0)
+        self.act_t_flat, _ = rehome(act_target, _TD3_ACTOR_PARAMS, 0)
+        self.cri_flat, self.cri_off = rehome(cri, _TD3_CRITIC_PARAMS, 1)
+        self.cri_t_flat, _ = rehome(cri_target, _TD3_CRITIC_PARAMS, 1)
+        self.act_grad, self.cri_grad = torch.zeros_like(self.act_flat), torch.zeros_like(self.cri_flat)
+        for module, names, offs, g in ((act, _TD3_ACTOR_PARAMS, self.act_off, self.act_grad),
+                                      (cri, _TD3_CRITIC_PARAMS, self.cri_off, self.cri_grad)):
+            sd = dict(module.named_parameters())
+            for name, off in zip(names, offs):
+                p = sd[name]
+                p.grad = g[off:off + p.numel()].view_as(p)
+        self.state = {k: torch.zeros_like(t) for k, t in (("act_m", self.act_flat), ("act_v", self.act_flat),
+                                                          ("cri_m", self.cri_flat), ("cri_v", self.cri_flat))}
+        self.act_step, self.cri_step = torch.zeros(2, **f32), torch.zeros(2, **f32)
+        self.workspace = None
+        self.ensure_batch(self.max_batch)
+        self.loss = torch.zeros(4, **f32)          # [0] sum of obj_actor, [1] sum of obj_critic, [2], [3] the last step's
+        self.cursor = torch.zeros(2, dtype=torch.int64, device=dev)   # [0] table row of the next step, [1] noise epoch offset
+        self._structs()
+
+    def ensure_batch(self, batch):
+        """Workspace (one partial-gradient slab per workgroup) for minibatches of up to `batch` rows; the optimizer state stays."""
+        if self.workspace is None or batch > self.max_batch:
+            self.max_batch = max(int(batch), self.max_batch)
+            n_ws = native.lib().pime_td3_workspace_floats(self.D, self.md, self.max_batch)
+            if n_ws <= 0:
+                raise native.PimeError(f"fused TD3 step: {native.last_error()}")
+            self.workspace = torch.empty(n_ws, dtype=torch.float32, device=self.device)
+
+    @staticmethod
+    def supported(act, cri):
+        try:
+            if type(act).__name__ != "Actor" or type(cri).__name__ != "CriticTwin":
+                return False
+            md = act.net[0].out_features
+            if cri.net_sa[0].out_features != md or cri.net_sa[0].in_features != act.state_dim + 1 or len(act.net) != 7:
+                return False
+            return bool(native.lib().pime_td3_supported(int(act.state_dim), int(getattr(act, "action_dim", 1)), int(md))) \
+                and next(cri.parameters()).is_cuda
+        except Exception:
+            return False
+
+    def wraps(self, agent):
+        return (agent.act, agent.act_target, agent.cri, agent.cri_target) == self.nets and \
+            agent.act.net[0].weight.data_ptr() == self.act_flat.data_ptr()
+
+    def _structs(self):
+        s = self.state
+        self._actor = native.Td3Net(param=self.act_flat.data_ptr(), target=self.act_t_flat.data_ptr(), grad=self.act_grad.data_ptr(),
+                                    exp_avg=s["act_m"].data_ptr(), exp_avg_sq=s["act_v"].data_ptr(), step=self.act_step.data_ptr(),
+                                    lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
+        self._critic = native.Td3Net(param=self.cri_flat.data_ptr(), target=self.cri_t_flat.data_ptr(), grad=self.cri_grad.data_ptr(),
+                                     exp_avg=s["cri_m"].data_ptr(), exp_avg_sq=s["cri_v"].data_ptr(), step=self.cri_step.data_ptr(),
+                                     lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
+
+    def step(self, buf_state, buf_other, idx, nxt, noise, tau, update_freq, policy_noise, noise_clip=0.5, noise_seed=0,
+             noise_epoch=0, soft_mode=2, phases=3, use_cursor=True):
+        """One optimizer step on table row cursor[0] of idx / nxt (int64 [rows, B]) and noise (float32 [rows, B] or None: Philox in
+        the kernel); advances the cursor.  use_cursor=False: idx / nxt / noise are single rows [B] and soft_mode must be 0 or 1."""
+        _need_cuda(buf_state, buf_other, idx, nxt)
+        B = idx.shape[-1]
+        assert B <= self.max_batch and idx.dtype == nxt.dtype == torch.int64 and idx.is_contiguous() and nxt.is_contiguous()
+        assert buf_state.dtype == buf_other.dtype == torch.float32 and buf_state.is_contiguous() and buf_other.is_contiguous()
+        assert buf_state.shape[1] == self.D and buf_other.shape[1] == 3
+        assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape == idx.shape)
+        assert use_cursor or soft_mode in (0, 1)
+        batch = native.Td3Batch(state=buf_state.data_ptr(), other=buf_other.data_ptr(), idx=idx.data_ptr(), nxt=nxt.data_ptr(),
+                                noise=noise.data_ptr() if noise is not None else None,
+                                cursor=self.cursor.data_ptr() if use_cursor else None, B=B, noise_seed=int(noise_seed),
+                                noise_epoch=int(noise_epoch), policy_noise=float(policy_noise), noise_clip=float(noise_clip))
+        with torch.cuda.device(self.device):
+            native.check(native.lib().pime_td3_step(self.D, self.md, C.byref(self._actor), C.byref(self._critic), C.byref(batch),
+                                                    C.c_float(tau), int(update_freq), int(soft_mode), int(phases),
+                                                    native.ptr(self.workspace), native.ptr(self.loss), _stream(buf_state)),
+                         "pime_td3_step")

@@ -657,6 +657,93 @@ def golden_td3_update():
     save("td3_update.npz", **out)
 
 
+def golden_td3_update_multi():
+    """AgentTD3.update_net at the batch size of BASELINE config 2 (4 096 = 256 workgroups of the fused HIP step), width 128, with
+    the reference's own first-step gradients (VERDICT r03 task 1; what `ppo_update_multi` is for PPO).
+
+    Reference AgentTD3 (elegantrl/agent.py:276-376), net_dim 128, state_dim 4, on a flat ring of 6 000 random transitions;
+    update_net(target_step 2, batch 4 096, repeat 2) = 4 optimizer steps (steps 0 and 2 with the delayed soft updates).  Recorded:
+    the sampled rows (torch.randint) and the smoothing-noise draws (torch.randn_like) of every step; the critic's .grad after the
+    first obj_critic.backward() and the actor's after the first obj_actor.backward() (agent.py:317,326); all four nets after the
+    first step and after the last; the per-step objectives the reference appends (agent.py:315,324) and the returned pair."""
+    from elegantrl.agent import AgentTD3
+    from elegantrl.replay import ReplayBuffer
+    out = {}
+    torch.manual_seed(31)
+    agent = AgentTD3()
+    agent.init(128, 4, 1)
+    with torch.no_grad():   # targets that differ from the online nets, heads away from their tiny initial scale
+        for net in (agent.act_target, agent.cri_target):
+            for p_ in net.parameters():
+                p_.add_(torch.randn_like(p_) * 0.02)
+        agent.act.net[-1].weight.normal_(0, 0.1)
+        agent.act_target.net[-1].weight.normal_(0, 0.1)
+    rng = np.random.RandomState(9)
+    n = 6000
+    buf = ReplayBuffer(max_len=n + 8, state_dim=4, action_dim=1, if_on_policy=False, if_per=False, if_gpu=True)
+    state = (rng.rand(n, 4) * np.array([10., 10., 10., 50.]) - np.array([0., 0., 0., 25.])).astype(np.float32)
+    other = np.stack([-rng.rand(n) * 5, np.where(rng.rand(n) < 0.02, 0.0, 0.99), np.tanh(rng.randn(n))], axis=1).astype(np.float32)
+    buf.extend_buffer(torch.as_tensor(state), torch.as_tensor(other))
+    for tag, net in (("act0", agent.act), ("cri0", agent.cri), ("act_target0", agent.act_target), ("cri_target0", agent.cri_target)):
+        out.update(_sd_to_np(f"td3m:{tag}", net.state_dict()))
+    idx_log, noise_log, steps = [], [], {"cri": 0, "act": 0}
+    orig_randint, orig_randn_like = torch.randint, torch.randn_like
+    orig_cri_step, orig_act_step = agent.cri_optimizer.step, agent.act_optimizer.step
+
+    def rec_randint(*a, **k):
+        v = orig_randint(*a, **k)
+        idx_log.append(v.numpy().astype(np.int32))
+        return v
+
+    def rec_randn_like(t, **k):
+        v = orig_randn_like(t, **k)
+        noise_log.append(v.numpy().reshape(-1).copy())
+        return v
+
+    def rec_cri_step(*a, **k):
+        if steps["cri"] == 0:
+            for name, p_ in agent.cri.named_parameters():
+                out[f"td3m:grad1:cri.{name}"] = p_.grad.detach().numpy().copy()
+        steps["cri"] += 1
+        return orig_cri_step(*a, **k)
+
+    def rec_act_step(*a, **k):
+        if steps["act"] == 0:
+            for name, p_ in agent.act.named_parameters():
+                out[f"td3m:grad1:act.{name}"] = p_.grad.detach().numpy().copy()
+        r = orig_act_step(*a, **k)
+        steps["act"] += 1
+        return r
+
+    orig_soft = agent.soft_update
+    snaps = []
+
+    def rec_soft(tar, cur, tau):
+        r = orig_soft(tar, cur, tau)
+        if tar is agent.act_target and not snaps:   # end of step 0 (the last statement of a delayed step, agent.py:331)
+            for tag, net in (("act_step1", agent.act), ("cri_step1", agent.cri), ("act_target_step1", agent.act_target),
+                             ("cri_target_step1", agent.cri_target)):
+                out.update(_sd_to_np(f"td3m:{tag}", net.state_dict()))
+            snaps.append(1)
+        return r
+    torch.randint, torch.randn_like = rec_randint, rec_randn_like
+    agent.cri_optimizer.step, agent.act_optimizer.step, agent.soft_update = rec_cri_step, rec_act_step, rec_soft
+    torch.manual_seed(78)
+    try:
+        obj_a, obj_c = agent.update_net(buf, 2, 4096, 2)
+    finally:
+        torch.randint, torch.randn_like = orig_randint, orig_randn_like
+    assert steps == {"cri": 4, "act": 4} and len(idx_log) == 4 and len(noise_log) == 4 and snaps
+    for tag, net in (("act1", agent.act), ("cri1", agent.cri), ("act_target1", agent.act_target), ("cri_target1", agent.cri_target)):
+        out.update(_sd_to_np(f"td3m:{tag}", net.state_dict()))
+    out["td3m:state"], out["td3m:other"] = state, other
+    out["td3m:indices"], out["td3m:noise"] = np.array(idx_log), np.array(noise_log, dtype=np.float32)
+    out["td3m:obj"] = np.array([obj_a, obj_c])
+    out["td3m:hyper"] = np.array([128, 2, 4096, 2, agent.learning_rate, agent.soft_update_tau, agent.explore_noise, agent.policy_noise,
+                                  agent.update_freq])
+    save("td3_update_multi.npz", **out)
+
+
 def main():
     only = set(sys.argv[1:])
     jobs = dict(ph_table=golden_ph_table, ph_zoh=golden_ph_zoh, ph_rollouts=golden_ph_rollouts,
@@ -665,7 +752,7 @@ def main():
                 gae=golden_gae, nets=golden_nets, ppo_update=golden_ppo_update_and_explore,
                 ppo_update_wide=golden_ppo_update_wide, ppo_update_mod256=golden_ppo_update_mod256,
                 ppo_update_multi=golden_ppo_update_multi,
-                td3_update=golden_td3_update)
+                td3_update=golden_td3_update, td3_update_multi=golden_td3_update_multi)
     for name, fn in jobs.items():
         if only and name not in only:
             continue

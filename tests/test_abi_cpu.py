@@ -48,7 +48,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     """sizeof / offsetof of every ABI struct as gcc sees include/pime_hip.h against the ctypes mirrors in native.py."""
     import subprocess
     import pime_amd.native as nt
-    structs = {"pime_env_cfg": nt.EnvCfg, "pime_ph_chem": nt.PhChem, "pime_ppo_net": nt.PpoNet, "pime_ppo_batch": nt.PpoBatch}
+    structs = {"pime_env_cfg": nt.EnvCfg, "pime_ph_chem": nt.PhChem, "pime_ppo_net": nt.PpoNet, "pime_ppo_batch": nt.PpoBatch,
+               "pime_adam": nt.Adam, "pime_td3_net": nt.Td3Net, "pime_td3_batch": nt.Td3Batch}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pime_hip.h"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

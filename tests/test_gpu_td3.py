@@ -32,29 +32,47 @@ def test_td3_nets_reproduce_reference_outputs_on_gpu():
         np.testing.assert_allclose(det(x4).cpu().numpy(), g["actor4:forward"], rtol=1e-5, atol=1e-5)
 
 
-def test_td3_update_matches_reference_on_gpu():
-    """The reference's update_net golden through the GPU modules: the sampled rows and the smoothing noise come from torch's
-    CPU generator in the golden and from the device generator here, so rows / noise are injected instead of seeded."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_td3_update_matches_reference_on_gpu(fused):
+    """The reference's update_net golden (weights of all four nets after 6 optimizer steps, 1e-5) through AgentTD3.update_net on the
+    GPU: `fused` = the hand-written optimizer step (pime_td3_step: four launches per step), else the PyTorch modules it replaces.
+    The sampled rows and the smoothing noise come from torch's CPU generator in the golden and from the device here, so the
+    generator's draws (randint, then randn_like, per step -- agent.py:363-365) are replayed: as tables through `draw_hook` on the
+    fused path, by patching torch.randint / torch.randn_like on the module path."""
+    from pime_amd import ops
     from pime_amd.elegantrl.agent import AgentTD3
     from pime_amd.elegantrl.replay import ReplayBuffer
     g = load_golden("td3_update.npz")
     net_dim, target_step, batch, repeat = (int(v) for v in g["td3:hyper"][:4])
     ag = AgentTD3(device=DEV)
+    ag.use_fused_update = fused
     ag.init(net_dim, 4, 1)
     for net, tag in ((ag.act, "act0"), (ag.cri, "cri0"), (ag.act_target, "act0"), (ag.cri_target, "cri0")):
         net.load_state_dict({k[len("td3:" + tag) + 1:]: torch.from_numpy(g[k].copy()).to(DEV) for k in g.files
                              if k.startswith(f"td3:{tag}.")})
     buf = ReplayBuffer(len(g["td3:state"]) + 8, 4, 1, if_on_policy=False, device=DEV)
     buf.extend_buffer(g["td3:state"], g["td3:other"])
-    # replay the CPU generator's draws: sample_batch's randint, then get_action's randn_like, per update step
     cpu_gen = torch.Generator().manual_seed(77)
-    orig_randint, orig_randn_like = torch.randint, torch.randn_like
-    torch.randint = lambda high, size, device=None, **k: orig_randint(high, size, generator=cpu_gen).to(DEV)
-    torch.randn_like = lambda t, **k: torch.randn(t.shape, generator=cpu_gen).to(DEV)
-    try:
+    if fused:
+        def hook(n_steps, B):
+            idx, eps = [], []
+            for _ in range(n_steps):
+                idx.append(torch.randint(len(g["td3:state"]) - 1, (B,), generator=cpu_gen))
+                eps.append(torch.randn((B, 1), generator=cpu_gen)[:, 0])
+            idx = torch.stack(idx)
+            return idx, idx + 1, torch.stack(eps)
+        ag.draw_hook = hook
         obj_a, obj_c = ag.update_net(buf, target_step, batch, repeat)
-    finally:
-        torch.randint, torch.randn_like = orig_randint, orig_randn_like
+        assert isinstance(ag._fused_td3, ops.FusedTD3), "the update did not run on the fused step"
+    else:
+        orig_randint, orig_randn_like = torch.randint, torch.randn_like
+        torch.randint = lambda high, size, device=None, **k: orig_randint(high, size, generator=cpu_gen).to(DEV)
+        torch.randn_like = lambda t, **k: torch.randn(t.shape, generator=cpu_gen).to(DEV)
+        try:
+            obj_a, obj_c = ag.update_net(buf, target_step, batch, repeat)
+        finally:
+            torch.randint, torch.randn_like = orig_randint, orig_randn_like
+        assert ag._fused_td3 is None
     for tag, net in (("act1", ag.act), ("cri1", ag.cri), ("act_target1", ag.act_target), ("cri_target1", ag.cri_target)):
         for k, v in net.state_dict().items():
             np.testing.assert_allclose(v.cpu().numpy(), g[f"td3:{tag}.{k}"], rtol=0, atol=1e-5, err_msg=f"{tag}.{k}")
@@ -82,16 +100,19 @@ def test_residual_td3_on_the_hip_env_with_graph_replay():
     w0 = torch.cat([p.detach().reshape(-1) for p in ag.act.parameters()]).clone()
     oa, oc = ag.update_net(buf, 60 * N, 512, 1)                   # 60 optimizer steps: 2 eager, capture, 58 replays
     torch.cuda.synchronize()
-    assert ag._graphs and True in ag._graphs and False in ag._graphs, "the TD3 update was not captured into HIP graphs"
+    assert ag._fused_td3 is not None and ag._fused_td3 is not False, "the update must run on the fused TD3 step"
     assert np.isfinite(oa) and np.isfinite(oc)
     w1 = torch.cat([p.detach().reshape(-1) for p in ag.act.parameters()])
     assert torch.isfinite(w1).all() and not torch.equal(w0, w1)
     # a few more rounds: the residual must not destroy the prior controller's return (sanity of the composed agent)
-    graphs = ag._graphs
-    for _ in range(6):
+    graph = None
+    for k in range(6):
         ag.explore_env(env, buf, 50 * N, 1.0, 0.99)
         ag.update_net(buf, 50 * N, 512, 1)
-    assert ag._graphs is graphs, "the two update graphs must survive from one update_net call to the next (device-side sampler bounds)"
+        if k == 1:   # (k = 0 is the first call with 50 optimizer steps: eager; the second one captures)
+            graph = ag._fused_td3.tables["graph"]
+            assert graph is not None, "the second update_net call of a shape must capture the whole update into ONE HIP graph"
+    assert ag._fused_td3.tables["graph"] is graph, "the update graph must survive from one update_net call to the next (device-side sampler bounds)"
     r1 = get_episode_return_vec(env, ag.eval_policy).mean()
     assert np.isfinite(r1) and r1 > 2.0 * r0, f"return collapsed: prior {r0:.1f} -> {r1:.1f}"   # returns are negative
     env.close()
@@ -150,7 +171,7 @@ def test_config2_residual_td3_4096_lanes_replays_through_oracle():
     np.testing.assert_allclose(env.get_field("a1"), ref.get("a1"), rtol=1e-7)
     oa, oc = ag.update_net(buf, steps * N, 4096, 1)
     torch.cuda.synchronize()
-    assert np.isfinite(oa) and np.isfinite(oc) and ag._graphs and True in ag._graphs
+    assert np.isfinite(oa) and np.isfinite(oc) and ag._fused_td3
     env.close()
 
 

@@ -274,3 +274,64 @@ def test_nets_forward():
     sd = _sd(g, "ppo3")
     mean = oracle.plain_actor_mean(g["x3"], sd).astype(np.float64)
     np.testing.assert_allclose(np.tanh(mean), g["ppo3:forward"], rtol=2e-5, atol=2e-5)
+
+
+# ---- TD3 optimizer step (oracle/td3.py) against the reference's own update_net (elegantrl/agent.py:276-376) ------------------------
+def _td3_sd(g, prefix):
+    return {k[len(prefix) + 1:]: g[k] for k in g.files if k.startswith(prefix + ".")}
+
+
+def test_td3_oracle_matches_reference_weights_after_six_steps():
+    """td3_update.npz: the reference draws sample_batch's rows and the smoothing noise from torch's CPU generator seeded 77, in the
+    order randint, randn_like per step; the same draws are replayed here.  float64 restatement vs the reference's float32 run:
+    2e-6 on every weight of the four nets after 6 optimizer steps (three delayed soft updates)."""
+    import torch
+    from oracle import td3
+    g = load_golden("td3_update.npz")
+    net_dim, target_step, batch, repeat = (int(v) for v in g["td3:hyper"][:4])
+    o = td3.Td3(_td3_sd(g, "td3:act0"), _td3_sd(g, "td3:act0"), _td3_sd(g, "td3:cri0"), _td3_sd(g, "td3:cri0"),
+                lr=float(g["td3:hyper"][4]), tau=float(g["td3:hyper"][5]), policy_noise=float(g["td3:hyper"][7]),
+                update_freq=int(g["td3:hyper"][8]))
+    state, other = g["td3:state"], g["td3:other"]
+    gen = torch.Generator().manual_seed(77)
+    obj = None
+    for i in range(target_step * repeat):
+        idx = torch.randint(len(state) - 1, (batch,), generator=gen).numpy()
+        eps = torch.randn((batch, 1), generator=gen).numpy()[:, 0]
+        obj = o.step(i, state, other, idx, idx + 1, eps)
+    for tag, net in (("act1", o.act), ("cri1", o.cri), ("act_target1", o.act_t), ("cri_target1", o.cri_t)):
+        want = _td3_sd(g, f"td3:{tag}")
+        for k in want:
+            np.testing.assert_allclose(net[k], want[k], rtol=0, atol=2e-6, err_msg=f"{tag}.{k}")
+    np.testing.assert_allclose([obj[0], obj[1] / 2], g["td3:obj"], rtol=1e-5, atol=1e-6)
+
+
+def test_td3_oracle_matches_reference_gradients_at_batch_4096():
+    """td3_update_multi.npz: width 128, batch 4 096, the reference's recorded rows and noise.  First-step .grad of every critic and
+    actor parameter within 2e-6 of its tensor's largest entry (float64 vs the reference's float32 autograd), weights of all four nets
+    after step 1 and after step 4 within 2e-6."""
+    from oracle import td3
+    g = load_golden("td3_update_multi.npz")
+    o = td3.Td3(_td3_sd(g, "td3m:act0"), _td3_sd(g, "td3m:act_target0"), _td3_sd(g, "td3m:cri0"), _td3_sd(g, "td3m:cri_target0"),
+                lr=float(g["td3m:hyper"][4]), tau=float(g["td3m:hyper"][5]), policy_noise=float(g["td3m:hyper"][7]),
+                update_freq=int(g["td3m:hyper"][8]))
+    state, other, idx, noise = g["td3m:state"], g["td3m:other"], g["td3m:indices"].astype(np.int64), g["td3m:noise"]
+    assert idx.shape == (4, 4096) and noise.shape == (4, 4096)
+    obj = None
+    for i in range(4):
+        obj = o.step(i, state, other, idx[i], idx[i] + 1, noise[i])
+        if i == 0:
+            for net_tag, grads in (("cri", obj[2]), ("act", obj[3])):
+                for k, got in grads.items():
+                    want = g[f"td3m:grad1:{net_tag}.{k}"]
+                    np.testing.assert_allclose(got.reshape(want.shape), want, rtol=0, atol=2e-6 * max(np.abs(want).max(), 1e-3),
+                                               err_msg=f"grad {net_tag}.{k}")
+            for tag, net in (("act_step1", o.act), ("cri_step1", o.cri), ("act_target_step1", o.act_t), ("cri_target_step1", o.cri_t)):
+                want = _td3_sd(g, f"td3m:{tag}")
+                for k in want:
+                    np.testing.assert_allclose(net[k], want[k], rtol=0, atol=2e-6, err_msg=f"{tag}.{k}")
+    for tag, net in (("act1", o.act), ("cri1", o.cri), ("act_target1", o.act_t), ("cri_target1", o.cri_t)):
+        want = _td3_sd(g, f"td3m:{tag}")
+        for k in want:
+            np.testing.assert_allclose(net[k], want[k], rtol=0, atol=2e-6, err_msg=f"{tag}.{k}")
+    np.testing.assert_allclose([obj[0], obj[1] / 2], g["td3m:obj"], rtol=1e-5, atol=1e-6)
