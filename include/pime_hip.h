@@ -112,6 +112,15 @@ int pime_env_cfg_default(int32_t kind, pime_env_cfg* cfg);
 /* replaces: gym.make(id) -> env constructor (ph.py:353-407, nonlinear_watertank.py:830-888). synchronous. */
 pime_env* pime_env_create(const pime_env_cfg* cfg);
 void pime_env_destroy(pime_env* env);
+/* Stream capture and device frees.  hipFree under an open stream capture aborts the process, and Python finalises handles whenever
+ * its garbage collector pleases.  Bracket every capture (torch.cuda.graph, hipStreamBeginCapture) with pime_capture_begin / _end:
+ * while the depth is non-zero pime_env_destroy and
+ * pime_oneshot_destroy park their device memory instead of freeing it; pime_capture_end (at depth 0), pime_env_create and the
+ * destroy calls outside a capture drain the queue.  pime_deferred_releases: pointers parked right now. */
+void pime_capture_begin(void);
+void pime_capture_end(void);
+void pime_capture_leave(void);   /* pime_capture_end without the drain (a finaliser inside a capture the library was not told about) */
+int pime_deferred_releases(void);
 int32_t pime_env_obs_dim(const pime_env* env);
 int32_t pime_env_num_envs(const pime_env* env);
 /* number of float64 draws one reset consumes per lane: pH 4 (qww_V, qc_V, x0, r), WT 6 (a1, a2, Kp, h1, h2, r) */

@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -22,6 +23,48 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- deferred device frees (pime_common.hpp) ---------------------------------------------------------------------------------
+namespace {
+struct Release { void* p; int device; ReleaseKind kind; };
+std::mutex g_release_mu;
+std::vector<Release> g_release_queue;
+std::atomic<int> g_capture_depth{0};
+void release_now(const Release& r, bool synchronize_first) {
+    (void)hipSetDevice(r.device);
+    if (synchronize_first) (void)hipDeviceSynchronize();
+    if (r.kind == RELEASE_IPC_CLOSE) (void)hipIpcCloseMemHandle(r.p);
+    else (void)hipFree(r.p);
+}
+}  // namespace
+
+bool capture_active() { return g_capture_depth.load(std::memory_order_acquire) > 0; }
+void release_device(void* p, int device, ReleaseKind kind, bool synchronize_first) {
+    if (!p) return;
+    if (capture_active()) {
+        std::lock_guard<std::mutex> lk(g_release_mu);
+        g_release_queue.push_back(Release{p, device, kind});
+        return;
+    }
+    release_now(Release{p, device, kind}, synchronize_first);
+}
+int drain_releases() {
+    if (capture_active()) return 0;
+    std::vector<Release> q;
+    {
+        std::lock_guard<std::mutex> lk(g_release_mu);
+        q.swap(g_release_queue);
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (size_t i = 0; i < q.size(); ++i) release_now(q[i], i == 0 || q[i].device != q[i - 1].device);   // one synchronise per device run
+    if (!q.empty() && prev >= 0) (void)hipSetDevice(prev);
+    return (int)q.size();
+}
+int queued_releases() {
+    std::lock_guard<std::mutex> lk(g_release_mu);
+    return (int)g_release_queue.size();
 }
 
 // launchers defined in env_kernels.hip / gae_scan.hip / mlp_mfma.hip
@@ -360,6 +403,7 @@ int pime_env_cfg_default(int32_t kind, pime_env_cfg* c) {
 }
 
 pime_env* pime_env_create(const pime_env_cfg* cfg) {
+    (void)drain_releases();   // slabs parked by handles destroyed under a stream capture
     if (check_cfg(cfg) != PIME_OK) return nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -451,13 +495,24 @@ pime_env* pime_env_create(const pime_env_cfg* cfg) {
 
 void pime_env_destroy(pime_env* e) {
     if (!e) return;
-    if (e->slab) {
-        (void)hipSetDevice(e->cfg.device_id);
-        (void)hipDeviceSynchronize();
-        (void)hipFree(e->slab);
-    }
+    // under a stream capture (pime_capture_begin, or the runtime says so) the slab is parked and freed by the next entry point
+    // outside the capture; otherwise: wait for the launches that use it, free it, and whatever an earlier capture left queued
+    release_device(e->slab, e->cfg.device_id, RELEASE_FREE, /*synchronize_first=*/true);
     delete e;
+    (void)drain_releases();
 }
+
+void pime_capture_begin(void) { g_capture_depth.fetch_add(1, std::memory_order_acq_rel); }
+void pime_capture_end(void) {
+    if (g_capture_depth.fetch_sub(1, std::memory_order_acq_rel) <= 1) {
+        g_capture_depth.store(0, std::memory_order_release);
+        (void)drain_releases();
+    }
+}
+void pime_capture_leave(void) {   // as pime_capture_end without the drain: for finalisers that run inside a capture nobody announced
+    if (g_capture_depth.fetch_sub(1, std::memory_order_acq_rel) <= 1) g_capture_depth.store(0, std::memory_order_release);
+}
+int pime_deferred_releases(void) { return queued_releases(); }
 
 int32_t pime_env_obs_dim(const pime_env* e) { return e ? e->obs_dim : 0; }
 int32_t pime_env_num_envs(const pime_env* e) { return e ? e->cfg.n_envs : 0; }

@@ -221,12 +221,13 @@ int pime_oneshot_status(pime_oneshot* h) {
 
 void pime_oneshot_destroy(pime_oneshot* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    // (parked while a stream capture is open: pime_common.hpp release_device)
     for (int r = 0; r < h->world; ++r)
-        if (r != h->rank && h->peer[r]) (void)hipIpcCloseMemHandle(h->peer[r]);
-    if (h->region) (void)hipFree(h->region);
-    if (h->local) (void)hipFree(h->local);
+        if (r != h->rank && h->peer[r]) release_device(h->peer[r], h->device, RELEASE_IPC_CLOSE, false);
+    release_device(h->region, h->device, RELEASE_FREE, true);
+    release_device(h->local, h->device, RELEASE_FREE, false);
     delete h;
+    (void)drain_releases();
 }
 
 }  // extern "C"

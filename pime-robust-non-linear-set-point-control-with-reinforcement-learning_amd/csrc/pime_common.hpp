@@ -30,6 +30,18 @@ void set_error(const char* fmt, ...);
         }                                \
     } while (0)
 
+// ---- frees that must not run under stream capture ---------------------------------------------------------------------------
+// hipFree / hipDeviceSynchronize / hipIpcCloseMemHandle called while a stream capture is open on the calling thread abort the
+// process (seen once: a garbage-collected env handle finalised inside torch.cuda.graph, gpurun_out/r03b_pytest.log).  The library
+// keeps a capture depth (pime_capture_begin / pime_capture_end, set by the Python capture wrapper around EVERY torch.cuda.graph of
+// this package; the Python finalisers also ask torch whether the current stream is capturing); while it is non-zero, release_device
+// parks the pointer in a queue that the next entry point outside a capture drains.
+enum ReleaseKind { RELEASE_FREE = 0, RELEASE_IPC_CLOSE = 1 };
+bool capture_active();
+void release_device(void* p, int device, ReleaseKind kind, bool synchronize_first);   // now, or queued while a capture is open
+int drain_releases();                                                                // frees what is queued (no-op under capture); returns how many
+int queued_releases();
+
 // hipFuncSetAttribute acts on the current device: one bit per device ordinal records where a kernel's dynamic-LDS limit has
 // been raised, so that a process driving several GPUs raises it on each (one static LdsLimit per kernel instantiation).
 struct LdsLimit {

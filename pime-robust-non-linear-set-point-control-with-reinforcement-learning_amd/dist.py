@@ -83,8 +83,15 @@ class OneShotAllReduce:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.pime_oneshot_destroy(self._h)
+            from . import native
+            native.destroy_handle(self._lib.pime_oneshot_destroy, self._h)   # parked, not freed, while a stream capture is open
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class DataParallel:

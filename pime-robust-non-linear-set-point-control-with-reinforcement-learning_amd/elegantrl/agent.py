@@ -12,8 +12,6 @@ What differs from the reference, by design:
   * under torch.distributed every optimizer step all-reduces ONE flat gradient buffer, and the buffer-global
     advantage normalisation (agent.py:707) all-reduces three moments.
 """
-import contextlib
-import gc
 import os
 
 import numpy as np
@@ -26,19 +24,14 @@ from .net import Actor, ActorPPO, CriticAdv, CriticTwin
 from .replay import TrajectoryBuffer, VecReplayBuffer
 
 
-@contextlib.contextmanager
 def _no_gc():
-    """No cyclic garbage collection while a HIP graph is being captured: a collection that happens to run inside the capture
-    can finalise an unrelated object that owns device resources (an env handle of an earlier run: pime_env_destroy -> hipFree),
-    and a hipFree under stream capture aborts the process (seen once in tests/test_gpu_td3.py, "Garbage-collecting" in the
-    fatal error's stack)."""
-    was = gc.isenabled()
-    gc.disable()
-    try:
-        yield
-    finally:
-        if was:
-            gc.enable()
+    """Every HIP-graph capture of the agents runs inside native.capture_guard: no cyclic garbage collection while the capture is
+    open, and the library parks -- instead of hipFree-ing -- any device memory a handle releases meanwhile (a hipFree under stream
+    capture aborts the process: seen once in tests/test_gpu_td3.py, "Garbage-collecting" in the fatal error's stack, when a cyclic
+    collection finalised an earlier env handle inside torch.cuda.graph).  The guard also covers refcount-driven finalisation,
+    which disabling the collector alone does not."""
+    from .. import native
+    return native.capture_guard()
 
 
 class AgentBase:

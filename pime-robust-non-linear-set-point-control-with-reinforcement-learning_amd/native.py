@@ -96,6 +96,10 @@ _SIGNATURES = {
     "pime_env_cfg_default": (C.c_int, [_i32, C.POINTER(EnvCfg)]),
     "pime_env_create": (_vp, [C.POINTER(EnvCfg)]),
     "pime_env_destroy": (None, [_vp]),
+    "pime_capture_begin": (None, []),
+    "pime_capture_end": (None, []),
+    "pime_capture_leave": (None, []),
+    "pime_deferred_releases": (C.c_int, []),
     "pime_env_obs_dim": (_i32, [_vp]),
     "pime_env_num_envs": (_i32, [_vp]),
     "pime_env_reset_draw_width": (_i32, [_vp]),
@@ -176,6 +180,45 @@ def lib():
             raise PimeError(f"libpime_hip.so ABI {handle.pime_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
         _lib = handle
     return _lib
+
+
+class capture_guard:
+    """Context manager around EVERY stream capture (torch.cuda.graph) of this package: no cyclic garbage collection inside (a
+    collection can finalise an unrelated object that owns device memory), and the library parks any device memory a handle releases
+    meanwhile instead of calling hipFree under the capture, which aborts the process (include/pime_hip.h: pime_capture_begin)."""
+
+    def __enter__(self):
+        import gc
+        self._gc = gc.isenabled()
+        gc.disable()
+        lib().pime_capture_begin()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        lib().pime_capture_end()
+        if self._gc:
+            gc.enable()
+        return False
+
+
+def destroy_handle(destroy, handle):
+    """The one finaliser path of every Python object that owns library-side device memory (env handles, one-shot all-reduce
+    regions): outside a capture `destroy(handle)` frees at once; inside one -- announced by capture_guard, or seen by torch on the
+    current stream -- the library parks the memory and frees it at its next entry point outside the capture."""
+    import torch
+    unannounced = False
+    try:
+        unannounced = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    except Exception:   # interpreter shutdown
+        pass
+    if unannounced:
+        lib().pime_capture_begin()
+    try:
+        destroy(handle)
+    finally:
+        if unannounced:
+            lib().pime_capture_leave()
 
 
 def last_error():

@@ -154,13 +154,11 @@ class VecControlEnv:
     # -- lifetime ------------------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.pime_env_destroy(self._h)
+            native.destroy_handle(self._lib.pime_env_destroy, self._h)   # parked, not freed, while a stream capture is open
             self._h = None
 
     def __del__(self):
         try:
-            if torch.cuda.is_current_stream_capturing():
-                return   # a hipFree under stream capture would abort the process: leak the slab until exit instead
             self.close()
         except Exception:  # interpreter shutdown
             pass
