@@ -82,7 +82,7 @@ class KernelTimer:
         return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.pairs.items()}
 
 
-def pmc_traffic_bytes(kernel_prefixes):
+def pmc_traffic_bytes(kernel_prefixes, pattern="r*_pmc_hbm_traffic.json"):
     """(HBM bytes per launch, source file) from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     bench (profiles/r<round>_<tag>_pmc_hbm_traffic.json, produced by tools/pmc_traffic.sh: separate passes, FETCH_SIZE doubled
     as MI355X_MICROARCH.md prescribes for gfx950; PIME_PMC_TRAFFIC=<file> names another one).  PMC counters cannot be read
@@ -91,7 +91,7 @@ def pmc_traffic_bytes(kernel_prefixes):
     import glob
     path = os.environ.get("PIME_PMC_TRAFFIC")
     if not path:
-        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
         path = found[-1] if found else None
     if not path or not os.path.exists(path):
         return None, None
@@ -408,7 +408,8 @@ def bench_water_tank_td3(args, device, json_fd):
     """BASELINE config 2 as BASELINE.json words it: water-tank Integrator env, 4096 vectorised instances, residual TD3
     (AgentResidualTD3: composed from the reference's TD3 pieces).  One step = 200 lock-steps of all lanes
     (one episode each: 819 200 transitions into the device ring) + 200 TD3 optimizer steps (one per lock-step, the reference's
-    schedule counted per lock-step), batch 4096, net_dim 128; update replayed from HIP graphs, nets in PyTorch-ROCm."""
+    schedule counted per lock-step), batch 4096, net_dim 128; every optimizer step four hand-written launches (pime_td3_step), an
+    update one HIP graph."""
     from pime_amd import gym_control
     from pime_amd.elegantrl.agent_residual import AgentResidualTD3
     from pime_amd.elegantrl.run import make_buffer
@@ -431,30 +432,51 @@ def bench_water_tank_td3(args, device, json_fd):
     total = sum(step() for _ in range(args.steps))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # roofline of the update, which is 97 % of the step: one TD3 optimizer step on PyTorch-ROCm (autograd + rocBLAS + elementwise
-    # kernels, ~150 launches replayed from a HIP graph) against the f32 matrix peak.  Algorithmic flops per sample (net_dim 128,
-    # D = 4): actor 2 * 33 664, twin critic 2 * 17 408; target actor + target critic forwards, critic forward + backward (3x),
-    # actor objective: actor forward + backward (3x) and target-critic forward + input-gradient backward (2x)
+    # roofline of the update (92 % of the step): ONE TD3 optimizer step = four hand-written launches (td3_critic_kernel,
+    # td3_apply_kernel, td3_actor_kernel, td3_apply_kernel; csrc/td3_fused.hip), the 200 steps of an update replayed as one HIP
+    # graph; HIP events around that replay on the stream it runs on.  Algorithmic flops per sample (net_dim 128, D = 4): actor
+    # 2 * 33 664, twin critic 2 * 17 408; critic launch: target actor + target critic forwards, critic forward + backward (3x);
+    # actor launch: actor forward + backward (3x), target-critic forward + input-gradient backward (2x)
+    timer = KernelTimer()
+    timer.enabled = True
+    agent.launch_timer = timer.bracket
+    agent.update_net(buf, lanes * T, batch, 1)
+    timer.pairs.clear()
     agent.update_net(buf, lanes * T, batch, 1)
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    agent.update_net(buf, lanes * T, batch, 1)
-    torch.cuda.synchronize()
-    upd_ms = (time.perf_counter() - t1) * 1e3 / T
+    agent.launch_timer = None
+    fused = bool(getattr(agent, "_fused_td3", None))
+    if fused:
+        n_upd, ms_upd = timer.summary()["td3_update"]
+        upd_ms = ms_upd / T
+    else:   # PIME_TD3_FUSED=0: the PyTorch modules (~150 launches per step), wall clock
+        t1 = time.perf_counter()
+        agent.update_net(buf, lanes * T, batch, 1)
+        torch.cuda.synchronize()
+        upd_ms = (time.perf_counter() - t1) * 1e3 / T
     fa, fc = 2 * 33664, 2 * 17408
-    flops = (fa + fc + 3 * fc + 3 * fa + 2 * fc) * batch
+    flops_c, flops_a = (fa + fc + 3 * fc) * batch, (3 * fa + 2 * fc) * batch
+    flops = flops_c + flops_a
     td3_tf = flops / (upd_ms * 1e-3) / 1e12
-    roofline = {"kernel": "one TD3 optimizer step (AgentTD3.update_net on PyTorch-ROCm: ~150 autograd / rocBLAS / elementwise "
-                          "launches per step, HIP-graph replay)", "bound": "mfma", "achieved": td3_tf, "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": td3_tf / F32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": upd_ms,
+    traffic, traffic_src = pmc_traffic_bytes(["td3_"], "r*_td3_hbm_traffic_pmc.json") if fused else (None, None)
+    roofline = {"kernel": ("td3_step = td3_critic_kernel<128> + td3_apply_kernel + td3_actor_kernel<128> + td3_apply_kernel (one "
+                           "optimizer step at batch 4096: gather, target nets, twin-critic and actor gradients, slab reduction, Adam, "
+                           "delayed soft updates; per-kernel split in profiles/)") if fused else
+                          "one TD3 optimizer step on PyTorch-ROCm (PIME_TD3_FUSED=0: ~150 autograd / rocBLAS / elementwise launches)",
+                "bound": "mfma", "achieved": td3_tf, "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": td3_tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_source": traffic_src, "avg_launch_ms": upd_ms, "launches_per_step": 4 * T if fused else None,
                 "algorithmic_flops_per_launch": flops,
-                "note": "batch 4096 = 16 workgroup-sized sample groups: launch-latency bound by construction (profiles/"
-                        "r03_*_td3_kernel_stats.csv); the exploration is ONE launch per explore call (pime_rollout_offpolicy)"}
+                "algorithmic_flops_split": {"td3_critic_kernel": flops_c, "td3_actor_kernel": flops_a},
+                "note": "avg_launch_ms is one optimizer step (four launches), timed with HIP events around the one-graph replay of an "
+                        "update's 200 steps; batch 4096 = 256 workgroups of one 16-sample tile, the four waves of a workgroup "
+                        "splitting every layer's output features (v_mfma_f32_16x16x4_f32); the exploration is ONE launch per "
+                        "explore call (pime_rollout_offpolicy)"}
     out = {"metric": "env-steps/sec (rollout+update), water-tank env, 4096 parallel envs, residual TD3", "value": total / dt,
            "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "water tank Integrator-v2 (reward 'distance'), 4096 lanes x 200 lock-steps, AgentResidualTD3 "
-                                  "net_dim 128, 200 optimizer steps of batch 4096 per step (HIP-graph replay)"},
+                                  "net_dim 128, 200 optimizer steps of batch 4096 per step (one HIP graph per update)"},
            "roofline": roofline}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 

@@ -214,18 +214,48 @@ __device__ __forceinline__ void vec_grad(float* __restrict__ seg, int t0, int la
     }
 }
 
+// The SMALL tensors of a net -- first-layer weights, biases, heads: everything but the md x md matrices -- are read by every wave at
+// the moment a layer starts; from global memory each such read is an exposed L2 round trip on the workgroup's critical path (a dozen
+// per kernel).  They are copied into LDS once per workgroup, behind the minibatch gather: the flat tensors minus the big matrices,
+// in the same order (td3.hpp), so that a small-image offset is the flat offset minus the matrices in front of it.
+struct Td3SmallActor { int W1, b1, b2, b3, w4, b4, total; };
+struct Td3SmallCritic { int W1, b1, b2, q1w, q1b, q2w, q2b, total; };
+__host__ __device__ inline Td3SmallActor td3_small_actor(int D, int md) {
+    const Td3ActorOff P = td3_actor_off(D, md);
+    const int mm = md * md;
+    return Td3SmallActor{P.W1, P.b1, P.b2 - mm, P.b3 - 2 * mm, P.w4 - 2 * mm, P.b4 - 2 * mm, P.total - 2 * mm};
+}
+__host__ __device__ inline Td3SmallCritic td3_small_critic(int D, int md) {
+    const Td3CriticOff P = td3_critic_off(D, md);
+    const int mm = md * md;
+    return Td3SmallCritic{P.W1, P.b1, P.b2 - mm, P.q1w - mm, P.q1b - mm, P.q2w - mm, P.q2b - mm, P.total - mm};
+}
+
 struct Td3Lds {
-    int buf[4], xin, red, total;
+    int buf[4], xin, red, small[3], total;
 };
 __host__ __device__ constexpr int td3_buf_floats(int NT) { return NT * kTP; }
-__host__ __device__ inline Td3Lds td3_lds(int NT) {
+__host__ __device__ inline Td3Lds td3_lds(int NT, int D) {
     Td3Lds L{};
     int o = 0;
     for (int k = 0; k < 4; ++k) { L.buf[k] = o; o += td3_buf_floats(NT); }
     L.xin = o; o += 16 * 16;
     L.red = o; o += 8 * 64;
+    const int md = NT * 16, sa = td3_small_actor(D, md).total, sc = td3_small_critic(D, md).total;
+    L.small[0] = o; o += sa;                 // the launch's actor (critic launch: the target actor)
+    L.small[1] = o; o += sc;                 // the launch's critic (critic launch: the online critic; actor launch: the target critic)
+    L.small[2] = o; o += sc;                 // critic launch only: the target critic
     L.total = o;
     return L;
+}
+
+// up to 256 16-byte words of a flat tensor, this thread's share: loaded here, written to LDS by small_store (the caller puts other
+// loads in between, so that one memory round trip covers them all)
+__device__ __forceinline__ f32x4_t small_load(const float* __restrict__ src, int n4, int tid) {
+    return tid < n4 ? ld4(src + 4 * tid) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void small_store(float* __restrict__ dst, int n4, int tid, const f32x4_t& v) {
+    if (tid < n4) st4(dst + 4 * tid, v);
 }
 
 // this lane's smoothing-noise draw for batch position pos
@@ -242,7 +272,8 @@ template <int MD>
 __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs a) {
     constexpr int NT = MD / 16, PER = NT / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const Td3Lds F = td3_lds(NT);
+    const int D = a.D, Dc = D + 1;
+    const Td3Lds F = td3_lds(NT, D);
     float* const B0 = lds + F.buf[0];
     float* const B1 = lds + F.buf[1];
     float* const B2 = lds + F.buf[2];
@@ -250,9 +281,13 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
     float* const red = lds + F.red;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = wave * PER;
-    const int D = a.D, Dc = D + 1;
     const Td3ActorOff PA = td3_actor_off(D, MD);
     const Td3CriticOff PC = td3_critic_off(D, MD);
+    const Td3SmallActor SA = td3_small_actor(D, MD);
+    const Td3SmallCritic SC = td3_small_critic(D, MD);
+    const float* const at = lds + F.small[0];   // target actor, small tensors
+    const float* const cr = lds + F.small[1];   // online critic
+    const float* const ct = lds + F.small[2];   // target critic
     const Td3SlabLayout SL = td3_critic_slab(D, MD);
     const float invB = 1.0f / (float)a.b.B;
     const long long trow = a.b.cursor ? a.b.cursor[0] : 0;
@@ -269,6 +304,16 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         const bool valid = pos < a.b.B;
         const int p = valid ? pos : a.b.B - 1;
         const long long row = a.b.idx[(size_t)trow * a.b.B + p], nrow = a.b.nxt[(size_t)trow * a.b.B + p];
+        // the nets' small tensors ride behind the index loads (first group only): seven 16-byte loads per thread, one round trip
+        const bool stage = !accum;
+        const int nA0 = (PA.W2 - PA.W1) / 4, nA1 = MD / 4, nA2 = (PA.total - PA.b3) / 4, nC0 = (PC.W2 - PC.W1) / 4, nC1 = (PC.total - PC.b2) / 4;
+        f32x4_t sv[9];
+        if (stage) {
+            sv[0] = small_load(a.act + PA.W1, nA0, tid); sv[1] = small_load(a.act + PA.b2, nA1, tid); sv[2] = small_load(a.act + PA.b3, nA2, tid);
+            sv[3] = small_load(a.cri + PC.W1, nC0, tid); sv[4] = small_load(a.cri + PC.b2, nC1, tid);
+            sv[5] = small_load(a.cri_target + PC.W1, nC0, tid); sv[6] = small_load(a.cri_target + PC.b2, nC1, tid);
+            sv[7] = small_load(a.cri + PC.W1 + 1024, nC0 - 256, tid); sv[8] = small_load(a.cri_target + PC.W1 + 1024, nC0 - 256, tid);   // D = 7 only
+        }
         // first-layer B operands: input column q / 4 + q of sample j
         const float* srow = a.b.state + (size_t)row * D;
         const float* nsrow = a.b.state + (size_t)nrow * D;
@@ -277,7 +322,16 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         const float* orow = a.b.other + (size_t)row * 3;
         const float reward = orow[0], mask = orow[1], action = orow[2];
         const float eps = td3_noise(a.b, trow, p);
-        TD3_BARRIER();   // the previous group is done with the LDS images
+        if (stage) {
+            float* const w = lds + F.small[0];
+            small_store(w + SA.W1, nA0, tid, sv[0]); small_store(w + SA.b2, nA1, tid, sv[1]); small_store(w + SA.b3, nA2, tid, sv[2]);
+            float* const c = lds + F.small[1];
+            small_store(c + SC.W1, nC0, tid, sv[3]); small_store(c + SC.b2, nC1, tid, sv[4]);
+            float* const t = lds + F.small[2];
+            small_store(t + SC.W1, nC0, tid, sv[5]); small_store(t + SC.b2, nC1, tid, sv[6]);
+            small_store(c + SC.W1 + 1024, nC0 - 256, tid, sv[7]); small_store(t + SC.W1 + 1024, nC0 - 256, tid, sv[8]);
+        }
+        TD3_BARRIER();   // the previous group is done with the LDS images; the small tensors are in
         if (wave == 0) {   // the online critic's input rows [s, a, 0 ..] for its first-layer weight gradient
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -291,7 +345,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         load_w<NT, PER>(a.act + PA.W2, t0, lane, wA);
         {
             f32x4_t h[PER];
-            layer_first<PER>(a.act + PA.W1, a.act + PA.b1, D, t0, lane, n0, n1, h);
+            layer_first<PER>(at + SA.W1, at + SA.b1, D, t0, lane, n0, n1, h);
 #pragma unroll
             for (int n = 0; n < PER; ++n) chain_put(B0, lane, t0 + n, relu4(h[n]));
         }
@@ -300,7 +354,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         chain_get<NT>(B0, lane, in);
         {
             f32x4_t h[PER];
-            layer<NT, PER>(wA, a.act + PA.b2, t0, lane, in, h);
+            layer<NT, PER>(wA, at + SA.b2, t0, lane, in, h);
 #pragma unroll
             for (int n = 0; n < PER; ++n) chain_put(B1, lane, t0 + n, relu4(h[n]));
         }
@@ -310,12 +364,12 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         float next_a;
         {
             f32x4_t h[PER];
-            layer<NT, PER>(wB, a.act + PA.b3, t0, lane, in, h);
+            layer<NT, PER>(wB, at + SA.b3, t0, lane, in, h);
 #pragma unroll
             for (int n = 0; n < PER; ++n) h[n] = relu4(h[n]);
-            red_put(red, 0, wave, lane, head_partial<PER>(a.act + PA.w4, t0, lane, h));
+            red_put(red, 0, wave, lane, head_partial<PER>(at + SA.w4, t0, lane, h));
             TD3_BARRIER();
-            const float pre = red_get(red, 0, lane) + a.act[PA.b4];
+            const float pre = red_get(red, 0, lane) + at[SA.b4];
             const float nz = fminf(fmaxf(eps * a.b.policy_noise, -a.b.noise_clip), a.b.noise_clip);   // net.py:109
             next_a = fminf(fmaxf(tanhf(pre) + nz, -1.0f), 1.0f);
         }
@@ -326,18 +380,18 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
             const float x0 = q < D ? n0 : (q == D ? next_a : 0.f);
             const float x1 = 4 + q < D ? n1 : (4 + q == D ? next_a : 0.f);
             f32x4_t h[PER];
-            layer_first<PER>(a.cri_target + PC.W1, a.cri_target + PC.b1, Dc, t0, lane, x0, x1, h);
+            layer_first<PER>(ct + SC.W1, ct + SC.b1, Dc, t0, lane, x0, x1, h);
 #pragma unroll
             for (int n = 0; n < PER; ++n) chain_put(B0, lane, t0 + n, relu4(h[n]));
             TD3_BARRIER();
             chain_get<NT>(B0, lane, in);
-            layer<NT, PER>(wA, a.cri_target + PC.b2, t0, lane, in, h);
+            layer<NT, PER>(wA, ct + SC.b2, t0, lane, in, h);
 #pragma unroll
             for (int n = 0; n < PER; ++n) h[n] = relu4(h[n]);
-            red_put(red, 1, wave, lane, head_partial<PER>(a.cri_target + PC.q1w, t0, lane, h));
-            red_put(red, 2, wave, lane, head_partial<PER>(a.cri_target + PC.q2w, t0, lane, h));
+            red_put(red, 1, wave, lane, head_partial<PER>(ct + SC.q1w, t0, lane, h));
+            red_put(red, 2, wave, lane, head_partial<PER>(ct + SC.q2w, t0, lane, h));
             TD3_BARRIER();
-            const float tq1 = red_get(red, 1, lane) + a.cri_target[PC.q1b], tq2 = red_get(red, 2, lane) + a.cri_target[PC.q2b];
+            const float tq1 = red_get(red, 1, lane) + ct[SC.q1b], tq2 = red_get(red, 2, lane) + ct[SC.q2b];
             label = reward + mask * fminf(tq1, tq2);
         }
         // ------------------------------------------------------------------ online twin critic on (s, a): forward
@@ -345,23 +399,23 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         {
             const float x0 = q < D ? s0 : (q == D ? action : 0.f);
             const float x1 = 4 + q < D ? s1 : (4 + q == D ? action : 0.f);
-            layer_first<PER>(a.cri + PC.W1, a.cri + PC.b1, Dc, t0, lane, x0, x1, h1);
+            layer_first<PER>(cr + SC.W1, cr + SC.b1, Dc, t0, lane, x0, x1, h1);
 #pragma unroll
             for (int n = 0; n < PER; ++n) { h1[n] = relu4(h1[n]); chain_put(B1, lane, t0 + n, h1[n]); }
         }
         load_wt<NT, PER>(a.cri + PC.W2, t0, lane, wA);   // for dH1 = W2^T dZ2
         TD3_BARRIER();
         chain_get<NT>(B1, lane, in);
-        layer<NT, PER>(wB, a.cri + PC.b2, t0, lane, in, h2);
+        layer<NT, PER>(wB, cr + SC.b2, t0, lane, in, h2);
 #pragma unroll
         for (int n = 0; n < PER; ++n) h2[n] = relu4(h2[n]);
-        red_put(red, 3, wave, lane, head_partial<PER>(a.cri + PC.q1w, t0, lane, h2));
-        red_put(red, 4, wave, lane, head_partial<PER>(a.cri + PC.q2w, t0, lane, h2));
+        red_put(red, 3, wave, lane, head_partial<PER>(cr + SC.q1w, t0, lane, h2));
+        red_put(red, 4, wave, lane, head_partial<PER>(cr + SC.q2w, t0, lane, h2));
         TD3_BARRIER();
         // ------------------------------------------------------------------ SmoothL1 x 2 (beta = 1, mean) and its gradient
         float g1 = 0.f, g2 = 0.f;
         {
-            const float d1 = red_get(red, 3, lane) + a.cri[PC.q1b] - label, d2 = red_get(red, 4, lane) + a.cri[PC.q2b] - label;
+            const float d1 = red_get(red, 3, lane) + cr[SC.q1b] - label, d2 = red_get(red, 4, lane) + cr[SC.q2b] - label;
             const float a1 = fabsf(d1), a2 = fabsf(d2);
             if (valid) {
                 g1 = (a1 < 1.f ? d1 : (d1 > 0.f ? 1.f : -1.f)) * invB;
@@ -374,7 +428,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
             f32x4_t v1[PER], v2[PER], dz[PER];
 #pragma unroll
             for (int n = 0; n < PER; ++n) {
-                const f32x4_t w1 = ld4(a.cri + PC.q1w + 16 * (t0 + n) + 4 * q), w2 = ld4(a.cri + PC.q2w + 16 * (t0 + n) + 4 * q);
+                const f32x4_t w1 = ld4(cr + SC.q1w + 16 * (t0 + n) + 4 * q), w2 = ld4(cr + SC.q2w + 16 * (t0 + n) + 4 * q);
                 v1[n] = h2[n] * g1;
                 v2[n] = h2[n] * g2;
                 dz[n] = gate4(w1 * g1 + w2 * g2, h2[n]);
@@ -433,7 +487,8 @@ template <int MD>
 __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a) {
     constexpr int NT = MD / 16, PER = NT / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const Td3Lds F = td3_lds(NT);
+    const int D = a.D, Dc = D + 1;
+    const Td3Lds F = td3_lds(NT, D);
     float* const B0 = lds + F.buf[0];
     float* const B1 = lds + F.buf[1];
     float* const B2 = lds + F.buf[2];
@@ -442,9 +497,12 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
     float* const red = lds + F.red;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = wave * PER;
-    const int D = a.D, Dc = D + 1;
     const Td3ActorOff PA = td3_actor_off(D, MD);
     const Td3CriticOff PC = td3_critic_off(D, MD);
+    const Td3SmallActor SA = td3_small_actor(D, MD);
+    const Td3SmallCritic SC = td3_small_critic(D, MD);
+    const float* const ac = lds + F.small[0];   // online actor, small tensors
+    const float* const ct = lds + F.small[1];   // target critic
     const Td3SlabLayout SL = td3_actor_slab(D, MD);
     const float invB = 1.0f / (float)a.b.B;
     const long long trow = a.b.cursor ? a.b.cursor[0] : 0;
@@ -461,9 +519,24 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
         const bool valid = pos < a.b.B;
         const int p = valid ? pos : a.b.B - 1;
         const long long row = a.b.idx[(size_t)trow * a.b.B + p];
+        const bool stage = !accum;   // the small tensors ride behind the index load (first group only)
+        const int nA0 = (PA.W2 - PA.W1) / 4, nA1 = MD / 4, nA2 = (PA.total - PA.b3) / 4, nC0 = (PC.W2 - PC.W1) / 4, nC1 = (PC.total - PC.b2) / 4;
+        f32x4_t sv[6];
+        if (stage) {
+            sv[0] = small_load(a.act + PA.W1, nA0, tid); sv[1] = small_load(a.act + PA.b2, nA1, tid); sv[2] = small_load(a.act + PA.b3, nA2, tid);
+            sv[3] = small_load(a.cri + PC.W1, nC0, tid); sv[4] = small_load(a.cri + PC.b2, nC1, tid);
+            sv[5] = small_load(a.cri + PC.W1 + 1024, nC0 - 256, tid);   // D = 7 only
+        }
         const float* srow = a.b.state + (size_t)row * D;
         const float s0 = q < D ? srow[q] : 0.f, s1 = 4 + q < D ? srow[4 + q] : 0.f;
-        TD3_BARRIER();
+        if (stage) {
+            float* const w = lds + F.small[0];
+            small_store(w + SA.W1, nA0, tid, sv[0]); small_store(w + SA.b2, nA1, tid, sv[1]); small_store(w + SA.b3, nA2, tid, sv[2]);
+            float* const c = lds + F.small[1];
+            small_store(c + SC.W1, nC0, tid, sv[3]); small_store(c + SC.b2, nC1, tid, sv[4]);
+            small_store(c + SC.W1 + 1024, nC0 - 256, tid, sv[5]);
+        }
+        TD3_BARRIER();   // the previous group is done with the LDS images; the small tensors are in
         if (wave == 0) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -476,49 +549,49 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
 
         // ------------------------------------------------------------------ action = tanh(act(s))
         load_w<NT, PER>(a.act + PA.W2, t0, lane, wA);
-        layer_first<PER>(a.act + PA.W1, a.act + PA.b1, D, t0, lane, s0, s1, a1);
+        layer_first<PER>(ac + SA.W1, ac + SA.b1, D, t0, lane, s0, s1, a1);
 #pragma unroll
         for (int n = 0; n < PER; ++n) { a1[n] = relu4(a1[n]); chain_put(B0, lane, t0 + n, a1[n]); }
         load_w<NT, PER>(a.act + PA.W3, t0, lane, wB);
         TD3_BARRIER();
         chain_get<NT>(B0, lane, in);
-        layer<NT, PER>(wA, a.act + PA.b2, t0, lane, in, a2);
+        layer<NT, PER>(wA, ac + SA.b2, t0, lane, in, a2);
 #pragma unroll
         for (int n = 0; n < PER; ++n) { a2[n] = relu4(a2[n]); chain_put(B1, lane, t0 + n, a2[n]); }
         load_w<NT, PER>(a.cri + PC.W2, t0, lane, wA);
         TD3_BARRIER();
         chain_get<NT>(B1, lane, in);
-        layer<NT, PER>(wB, a.act + PA.b3, t0, lane, in, a3);
+        layer<NT, PER>(wB, ac + SA.b3, t0, lane, in, a3);
 #pragma unroll
         for (int n = 0; n < PER; ++n) a3[n] = relu4(a3[n]);
-        red_put(red, 0, wave, lane, head_partial<PER>(a.act + PA.w4, t0, lane, a3));
+        red_put(red, 0, wave, lane, head_partial<PER>(ac + SA.w4, t0, lane, a3));
         TD3_BARRIER();
-        const float act = tanhf(red_get(red, 0, lane) + a.act[PA.b4]);
+        const float act = tanhf(red_get(red, 0, lane) + ac[SA.b4]);
         // ------------------------------------------------------------------ q1 = cri_target.q1(s, action)
         {
             const float x0 = q < D ? s0 : (q == D ? act : 0.f);
             const float x1 = 4 + q < D ? s1 : (4 + q == D ? act : 0.f);
-            layer_first<PER>(a.cri + PC.W1, a.cri + PC.b1, Dc, t0, lane, x0, x1, c1);
+            layer_first<PER>(ct + SC.W1, ct + SC.b1, Dc, t0, lane, x0, x1, c1);
 #pragma unroll
             for (int n = 0; n < PER; ++n) { c1[n] = relu4(c1[n]); chain_put(B2, lane, t0 + n, c1[n]); }
         }
         load_wt<NT, PER>(a.cri + PC.W2, t0, lane, wB);   // dC1 = W2^T dZc2
         TD3_BARRIER();
         chain_get<NT>(B2, lane, in);
-        layer<NT, PER>(wA, a.cri + PC.b2, t0, lane, in, c2);
+        layer<NT, PER>(wA, ct + SC.b2, t0, lane, in, c2);
 #pragma unroll
         for (int n = 0; n < PER; ++n) c2[n] = relu4(c2[n]);
-        red_put(red, 1, wave, lane, head_partial<PER>(a.cri + PC.q1w, t0, lane, c2));   // (the value itself only feeds the logged objective)
+        red_put(red, 1, wave, lane, head_partial<PER>(ct + SC.q1w, t0, lane, c2));   // (the value itself only feeds the logged objective)
         // ------------------------------------------------------------------ backward through the critic to the action
         const float g = valid ? -invB : 0.f;   // d(-mean q1) / d q1
 #pragma unroll
         for (int n = 0; n < PER; ++n) {
-            const f32x4_t wq = ld4(a.cri + PC.q1w + 16 * (t0 + n) + 4 * q);
+            const f32x4_t wq = ld4(ct + SC.q1w + 16 * (t0 + n) + 4 * q);
             chain_put(B3, lane, t0 + n, gate4(wq * g, c2[n]));
         }
         load_wt<NT, PER>(a.act + PA.W3, t0, lane, wA);   // dA2 = W3^T dZ3
         TD3_BARRIER();
-        if (valid && wave == 0 && q == 0) q_acc += red_get(red, 1, lane) + a.cri[PC.q1b];
+        if (valid && wave == 0 && q == 0) q_acc += red_get(red, 1, lane) + ct[SC.q1b];
         chain_get<NT>(B3, lane, in);
         float dpre;
         {
@@ -529,7 +602,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
             for (int n = 0; n < PER; ++n) {
                 d[n] = gate4(d[n], c1[n]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pa = fmaf(d[n][r], a.cri[PC.W1 + (size_t)(16 * (t0 + n) + 4 * q + r) * Dc + D], pa);
+                for (int r = 0; r < 4; ++r) pa = fmaf(d[n][r], ct[SC.W1 + (16 * (t0 + n) + 4 * q + r) * Dc + D], pa);
             }
             pa += __shfl_xor(pa, 16);
             pa += __shfl_xor(pa, 32);
@@ -542,7 +615,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
             f32x4_t v[PER], dz[PER];
 #pragma unroll
             for (int n = 0; n < PER; ++n) {
-                const f32x4_t w4 = ld4(a.act + PA.w4 + 16 * (t0 + n) + 4 * q);
+                const f32x4_t w4 = ld4(ac + SA.w4 + 16 * (t0 + n) + 4 * q);
                 v[n] = a3[n] * dpre;
                 dz[n] = gate4(w4 * dpre, a3[n]);
                 chain_put(B2, lane, t0 + n, dz[n]);
@@ -671,16 +744,23 @@ __global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) 
     if (unit < nwords) {
         const float* base = a.slab + (size_t)unit * 4;
         const size_t stride = (size_t)a.L.stride;
+        // A wave's slabs were written by other compute units a kernel ago: every load is an Infinity-Cache / HBM round trip, so
+        // the loop is bound by how many are in flight -- sixteen per lane (four dependent batches for 256 slabs; with four in flight
+        // the kernel took 11.5 us of a 78 us optimizer step).  Summed in slab order w, w + 4, ...: bit-reproducible.
         int s = wave;
-        for (; s + 12 < a.nslabs; s += 16) {   // four loads in flight
-            const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
-            const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(s + 4) * stride);
-            const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(s + 8) * stride);
-            const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(s + 12) * stride);
-            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        for (; s + 60 < a.nslabs; s += 64) {
+            float4 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const float4*>(base + (size_t)(s + 4 * k) * stride);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+        }
+        for (; s + 12 < a.nslabs; s += 16) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(base + (size_t)(s + 4 * k) * stride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
         }
         for (; s < a.nslabs; s += 4) {
             const float4 v = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
@@ -740,7 +820,7 @@ bool td3_supported(int D, int A, int md) { return A == 1 && D >= 1 && D <= kTd3M
 
 template <int MD>
 static int launch_grad(bool critic, const Td3GradArgs& a, int grid, hipStream_t s) {
-    const size_t lds_bytes = sizeof(float) * (size_t)td3_lds(MD / 16).total;
+    const size_t lds_bytes = sizeof(float) * (size_t)td3_lds(MD / 16, a.D).total;
     if (critic) hipLaunchKernelGGL((td3_critic_kernel<MD>), dim3(grid), dim3(kTd3Threads), lds_bytes, s, a);
     else hipLaunchKernelGGL((td3_actor_kernel<MD>), dim3(grid), dim3(kTd3Threads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());

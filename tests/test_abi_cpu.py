@@ -104,3 +104,14 @@ def test_no_cpu_fallback():
     nt.check(nt.lib().pime_env_cfg_default(nt.ENV_WT, C.byref(cfg)))
     assert not nt.lib().pime_env_create(C.byref(cfg))
     assert "no HIP device" in nt.last_error() or "fallback" in nt.last_error()
+
+
+def test_capture_flag_entry_points_work_without_a_gpu():
+    """pime_capture_begin / _end / _leave only move a counter and drain an (empty) queue: callable on a host without a device."""
+    import pime_amd.native as nt
+    L = nt.lib()
+    assert L.pime_deferred_releases() == 0
+    L.pime_capture_begin(); L.pime_capture_begin(); L.pime_capture_leave(); L.pime_capture_end()
+    with nt.capture_guard():
+        assert L.pime_deferred_releases() == 0
+    assert L.pime_deferred_releases() == 0
