@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 14
+#define PIME_ABI_VERSION 15
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -251,6 +251,12 @@ typedef struct pime_ppo_batch {
     int64_t* index_row;           /* [dev] int64[1] or NULL.  Not NULL: `indices` is a table int64[rows, B], this call uses
                                    * row index_row[0] and then advances it by one -- the minibatches of a whole update can be
                                    * drawn by one torch.randint and a captured HIP graph replayed per optimizer step */
+    float* dp_moments;            /* [dev] float32[4] or NULL.  Not NULL (data-parallel callers): the critic's gradient is left
+                                   * UNSCALED and dp_moments[0..2] = sum r_sum[indices], sum of squares, B are written -- the caller
+                                   * all-reduces them with the gradients (they sit behind the flat gradient buffer) and
+                                   * pime_adam_step_dp applies 1 / (std over the UNION minibatch + 1e-5), which is what agent.py:652
+                                   * means when the minibatch is spread over several ranks.  Slab nets only (PIME_ERR_ARG if the
+                                   * critic takes the split pipeline) */
 } pime_ppo_batch;
 /* the call OVERWRITES the gradient tensors (and g_a_std_log) instead of adding to them: saves the caller's zeroing launch */
 #define PIME_PPO_OVERWRITE_GRADS 1
@@ -294,6 +300,9 @@ typedef struct pime_adam {
     const int32_t* image_map;   /* [dev] int32[2 n] from pime_ppo_image_map, or NULL.  Not NULL: the launch that updates a
                                  * parameter also writes its new value into the nets' img_fwd / img_bwd, so that NO
                                  * pime_ppo_repack is needed after the step (one launch less per optimizer step) */
+    const float* dp_moments;    /* pime_adam_step_dp: [dev] float32[4], the rank-AVERAGED words pime_ppo_batch.dp_moments wrote */
+    int64_t critic_offset;      /* pime_adam_step_dp: flat elements [critic_offset, n) are the critic's */
+    int32_t dp_world;           /* pime_adam_step_dp: ranks the all-reduce averaged over */
 } pime_adam;
 /* For every element j of the flat parameter tensor: image_map[2j] = its position in its net's img_fwd, image_map[2j+1] = its
  * position in img_bwd, each with the net in bits 28..29 (0 critic, 1 actor; -1: not in that image, e.g. hidden-layer biases in the
@@ -434,6 +443,13 @@ int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * packed images, so no pime_ppo_repack follows.  For data-parallel callers, whose all-reduce sits between pime_ppo_minibatch_grad
  * and the optimizer step (single-GPU callers get the same from pime_ppo_minibatch_step in one launch less). */
 int pime_adam_step_images(const pime_adam* opt, const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream);
+
+/* The optimizer step of a data-parallel rank, behind the all-reduce (AVG) of [flat gradients | dp_moments]: the critic's elements
+ * grad[critic_offset .. n) are first multiplied by 1 / (std + 1e-5), std = torch's unbiased std of the dp_world * B targets of the
+ * UNION minibatch, recovered from the averaged moments (agent.py:652: `obj_critic / (r_sum.std() + 1e-5)`; actor and critic
+ * parameters are disjoint and the united loss is linear in that factor, so scaling the averaged critic gradient is exact), written
+ * back into grad, then torch.optim.Adam as pime_adam_step.  image_map may be NULL (then pime_ppo_repack follows). */
+int pime_adam_step_dp(const pime_adam* opt, const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream);
 
 /* -- one-shot all-reduce of the flat gradient buffer over peer-mapped memory ---------------------------------------------
  * replaces: nothing in the reference (one process; elegantrl/run.py:232-247 is an unused mp.Pipe) -- it is the hand-written

@@ -101,7 +101,7 @@ int64_t fused_stash_floats(int, int, int);
 bool fused_fits(int, int, int, int);
 int launch_repack(const PackArgs&, const PackArgs&, float*, float*, float*, float*, hipStream_t);
 int launch_grad_reduce(const PpoArgs&, const PpoArgs&, int, int, int, int, bool, bool, bool, bool, int, int, float* const*,
-                       float* const*, float*, float*, double*, float*, int, int64_t*, const ReduceAdam*, hipStream_t);
+                       float* const*, float*, float*, double*, float*, int, int64_t*, const ReduceAdam*, float*, hipStream_t);
 int fused_grid(int);
 // mlp16.hip: the streamed 16x16x4 family (width 256; widths 64 / 128 under PIME_MLP16=1)
 bool family16(int, int);
@@ -113,7 +113,8 @@ int launch_ppo16(int, int, const PpoArgs&, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
 int launch_dw(const DwArgs&, int, hipStream_t);
 int launch_critic_scale(int, int, float* const*, const double*, int, float*, float*, int64_t*, hipStream_t);
-int launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float*, const int32_t*, float* const (*)[2], hipStream_t);
+int launch_adam(float*, float*, float*, float*, long long, float, float, float, float, float*, const int32_t*, float* const (*)[2],
+                const float*, long long, int, hipStream_t);
 int launch_rollout(int, int, const RolloutArgs&, hipStream_t);
 // td3_fused.hip
 int td3_grid(int);
@@ -890,7 +891,8 @@ int pime_rollout_offpolicy(pime_env* e, int32_t md, const float* packed_actor, c
 int pime_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, float* step, pime_stream stream) {
     PIME_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && n >= 1, "pime_adam_step: bad arguments");
-    return launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, nullptr, nullptr, static_cast<hipStream_t>(stream));
+    return launch_adam(param, const_cast<float*>(grad), exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, nullptr, nullptr, nullptr, 0, 1,
+                       static_cast<hipStream_t>(stream));
 }
 
 static int check_net(const pime_ppo_net* n, bool actor) {
@@ -1038,7 +1040,23 @@ int pime_adam_step_images(const pime_adam* opt, const pime_ppo_net* actor, const
     float* const img[2][2] = {{const_cast<float*>(critic->img_fwd), const_cast<float*>(critic->img_bwd)},
                               {const_cast<float*>(actor->img_fwd), const_cast<float*>(actor->img_bwd)}};
     return launch_adam(opt->param, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n, opt->lr, opt->beta1, opt->beta2, opt->eps,
-                       opt->step, opt->image_map, img, static_cast<hipStream_t>(stream));
+                       opt->step, opt->image_map, img, nullptr, 0, 1, static_cast<hipStream_t>(stream));
+}
+
+int pime_adam_step_dp(const pime_adam* opt, const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream) {
+    PIME_REQUIRE(opt && opt->param && opt->grad && opt->exp_avg && opt->exp_avg_sq && opt->step && opt->n >= 1, "pime_adam_step_dp: bad pime_adam");
+    PIME_REQUIRE(opt->dp_moments && opt->dp_world >= 1 && opt->critic_offset >= 0 && opt->critic_offset <= opt->n,
+                 "pime_adam_step_dp: dp_moments / dp_world / critic_offset");
+    float* img[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    if (opt->image_map) {
+        if (int rc = check_net(actor, true)) return rc;
+        if (int rc = check_net(critic, false)) return rc;
+        img[0][0] = const_cast<float*>(critic->img_fwd); img[0][1] = const_cast<float*>(critic->img_bwd);
+        img[1][0] = const_cast<float*>(actor->img_fwd); img[1][1] = const_cast<float*>(actor->img_bwd);
+    }
+    return launch_adam(opt->param, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n, opt->lr, opt->beta1, opt->beta2, opt->eps,
+                       opt->step, opt->image_map, img, opt->dp_moments, (long long)opt->critic_offset, opt->dp_world,
+                       static_cast<hipStream_t>(stream));
 }
 
 static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b, float ratio_clip,
@@ -1067,6 +1085,8 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
         else mode[k] = (force_split || !fused_fits(n->kind, n->D, n->Di, n->md)) ? SPLIT : FUSED;
     }
     const bool any_split = mode[0] == SPLIT || mode[1] == SPLIT, any_slab = mode[0] != SPLIT || mode[1] != SPLIT;
+    PIME_REQUIRE(!(b->dp_moments && mode[0] == SPLIT), "pime_ppo_minibatch_grad: dp_moments needs the critic on a slab kernel (it takes the split pipeline here)");
+    PIME_REQUIRE(!(b->dp_moments && opt), "pime_ppo_minibatch_step: dp_moments with a fused optimizer step (the all-reduce has to come first)");
     ReduceAdam adam{};
     if (opt) {
         PIME_REQUIRE(!any_split, "pime_ppo_minibatch_step: the optimizer step is fused into the slab reduction, which these nets "
@@ -1183,7 +1203,7 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
                                         mode[0] == F16, mode[1] == F16, mode[0] != SPLIT, mode[1] != SPLIT, nslabs[0], nslabs[1],
                                         critic->grads, actor->grads, actor->g_a_std_log, critic_scale, moments, loss_sums + 3,
                                         b->flags & PIME_PPO_OVERWRITE_GRADS, mode[0] != SPLIT ? b->index_row : nullptr,
-                                        opt ? &adam : nullptr, s))
+                                        opt ? &adam : nullptr, b->dp_moments, s))
             return rc;
     }
     if (mode[0] == SPLIT)   // scales the split critic's gradients, advances the index-table row

@@ -1094,6 +1094,7 @@ struct ReduceArgs {
     int stride[2];
     float* scale_out;
     double* moments_out;
+    float* dp_moments;   // not NULL (data parallel): the critic's gradient stays unscaled; [0..2] = sum r, sum r^2, B of this rank's minibatch
 };
 
 __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
@@ -1146,8 +1147,9 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
         const double var = a.B > 1 ? fmax((m2 - m1 * m1 / B) / (B - 1.0), 0.0) : 0.0;
         const float scale = (float)(1.0 / ((double)(float)sqrt(var) + 1e-5));
         if (lane == 0) {
-            scale_sh = scale;
+            scale_sh = a.dp_moments ? 1.0f : scale;   // data parallel: the scale of the UNION minibatch is applied behind the all-reduce
             if (blockIdx.x == 0) {
+                if (a.dp_moments) { a.dp_moments[0] = (float)m1; a.dp_moments[1] = (float)m2; a.dp_moments[2] = (float)a.B; a.dp_moments[3] = 0.f; }
                 a.scale_out[0] = scale; a.moments_out[0] = m1; a.moments_out[1] = m2; a.scale_sum[0] += scale;
                 // loss_sums[4] += (this call's SmoothL1 sum) * scale: the logged united loss is the mean of the per-step
                 // values actor + critic * scale (agent.py:652), not mean(critic) * mean(scale).  scale_sum = loss_sums + 3.
@@ -1293,7 +1295,7 @@ int fused_grid(int B) {
 int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,
                        bool f16_c, bool f16_a, bool use_c, bool use_a, int nslabs_c, int nslabs_a, float* const* grads_c, float* const* grads_a, float* g_std, float* scale_out,
                        double* moments_out, float* scale_sum, int overwrite, int64_t* index_row, const ReduceAdam* adam,
-                       hipStream_t s) {
+                       float* dp_moments, hipStream_t s) {
     ReduceArgs r{};
     if (adam) r.adam = *adam;
     int poff[13], psize[12], chunks = 0;
@@ -1340,6 +1342,7 @@ int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, 
     r.slab[0] = critic.slab; r.slab[1] = actor.slab;
     r.stride[0] = critic.slab_stride; r.stride[1] = actor.slab_stride;
     r.scale_out = scale_out; r.moments_out = moments_out; r.scale_sum = scale_sum; r.overwrite = overwrite; r.index_row = index_row;
+    r.dp_moments = dp_moments;
     hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3(chunks), dim3(512), 0, s, r);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;

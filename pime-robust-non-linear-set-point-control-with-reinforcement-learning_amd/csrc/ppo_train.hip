@@ -454,23 +454,41 @@ struct AdamImages {   // optional: keep the packed images current (pime_adam_ste
     const int32_t* map;   // [2 n], see pime_ppo_image_map; NULL: parameters only
     float* img[2][2];     // [0 critic, 1 actor][0 forward, 1 transposed]
 };
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// Data parallel (pime_adam_step_dp): the critic's gradient arrives unscaled and rank-averaged, with the averaged target moments
+// behind it; every workgroup recovers 1 / (std of the union minibatch + 1e-5) from them and applies it to the critic's elements.
+struct AdamDp {
+    const float* moments;   // NULL: plain step.  [0] mean over ranks of sum r, [1] of sum r^2, [2] B
+    long long critic_off;
+    int world;
+};
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                            float* __restrict__ step, AdamImages im) {
+                            float* __restrict__ step, AdamImages im, AdamDp dp) {
     // the bias corrections (two float64 pow behind a dependent load of the step count) once per workgroup, not once per thread:
     // they are ~10x the work of an element's update
-    __shared__ float consts[3];
+    __shared__ float consts[4];
     if (threadIdx.x == 0) {
         const float tn = step[0] + 1.0f;
         const double t = (double)tn;
         consts[0] = tn;
         consts[1] = lr / (float)(1.0 - pow((double)b1, t));
         consts[2] = (float)sqrt(1.0 - pow((double)b2, t));
+        consts[3] = 1.0f;
+        if (dp.moments) {   // torch's unbiased std over the union of the ranks' minibatches (ppo_grad_reduce_kernel's formula)
+            const double G = (double)dp.world, N = G * (double)dp.moments[2];
+            const double m1 = G * (double)dp.moments[0], m2 = G * (double)dp.moments[1];
+            const double var = N > 1.0 ? fmax((m2 - m1 * m1 / N) / (N - 1.0), 0.0) : 0.0;
+            consts[3] = (float)(1.0 / ((double)(float)sqrt(var) + 1e-5));
+        }
     }
     __syncthreads();
-    const float t_new = consts[0], step_size = consts[1], bc2_sqrt = consts[2];
+    const float t_new = consts[0], step_size = consts[1], bc2_sqrt = consts[2], cscale = consts[3];
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i];
+        float gi = g[i];
+        if (dp.moments && i >= dp.critic_off) {
+            gi *= cscale;
+            g[i] = gi;   // .grad holds the gradient of the united loss
+        }
         const float mi = m[i] + (gi - m[i]) * (1.0f - b1);       // exp_avg.lerp_(grad, 1 - beta1)
         const float vi = v[i] * b2 + gi * gi * (1.0f - b2);      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
         m[i] = mi;
@@ -494,8 +512,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
-int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
-                float* step, const int32_t* map, float* const (*img)[2], hipStream_t s) {
+int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                float* step, const int32_t* map, float* const (*img)[2], const float* dp_moments, long long critic_off, int world,
+                hipStream_t s) {
     AdamImages im{};
     if (map) {
         im.map = map;
@@ -505,7 +524,8 @@ int launch_adam(float* p, const float* g, float* m, float* v, long long n, float
     const int block = 256;
     long long grid = (n + block - 1) / block;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(block), 0, s, p, g, m, v, n, lr, b1, b2, eps, step, im);
+    const AdamDp dp{dp_moments, critic_off, world};
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(block), 0, s, p, g, m, v, n, lr, b1, b2, eps, step, im, dp);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }

@@ -136,11 +136,14 @@ class DataParallel:
             t.div_(self.world)
         return t
 
-    def average_gradients(self, params):
-        """Flatten every gradient into ONE buffer, all-reduce it once, scatter the mean back."""
+    def average_gradients(self, params, extra=None):
+        """Flatten every gradient into ONE buffer, all-reduce it once, scatter the mean back.  extra: a small float vector that
+        rides behind the gradients in the same collective (the minibatch's target moments); its rank mean is returned."""
         grads = [p.grad for p in params if p.grad is not None]
         if not grads:
-            return
+            return None
+        if extra is not None:
+            grads = grads + [extra.to(device=grads[0].device, dtype=grads[0].dtype)]
         n = sum(g.numel() for g in grads)
         if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
             self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
@@ -151,6 +154,7 @@ class DataParallel:
         for g in grads:
             g.copy_(self._flat[off:off + g.numel()].view_as(g))
             off += g.numel()
+        return grads[-1] if extra is not None else None
 
     def barrier(self):
         td.barrier()

@@ -360,11 +360,30 @@ class AgentPPO(AgentBase):
             obj_actor = -surrogate.mean() + obj_entropy * self.lambda_entropy
             value = self.cri(state).squeeze(1)
             obj_critic = self.criterion(value, r_sum)
-            obj_united = obj_actor + obj_critic / (r_sum.std() + 1e-5)             # :652
-            self.optimizer.zero_grad(set_to_none=False)
-            obj_united.backward()
-            if self.dp is not None:
-                self.dp.average_gradients(params)                                  # one flat all-reduce per step
+            if self.dp is None:
+                obj_united = obj_actor + obj_critic / (r_sum.std() + 1e-5)         # :652
+                self.optimizer.zero_grad(set_to_none=False)
+                obj_united.backward()
+            else:
+                # Data parallel: the minibatch of :652 is the UNION of the ranks' minibatches.  Actor and critic parameters are
+                # disjoint and the united loss is linear in the critic's factor, so: back-propagate actor + UNSCALED critic, let
+                # the one flat all-reduce of the step also carry (sum r, sum r^2, count), then scale the averaged critic gradient
+                # by 1 / (std of the union + 1e-5) -- the same weights as one rank stepping on the concatenated minibatch.
+                self.optimizer.zero_grad(set_to_none=False)
+                (obj_actor + obj_critic).backward()
+                r64 = r_sum.detach().double()
+                mom = self.dp.average_gradients(params, extra=torch.stack([r64.sum(), (r64 * r64).sum(),
+                                                                           torch.tensor(float(r64.numel()), dtype=torch.float64)]).float())
+                G = float(self.dp.world)
+                n_tot, s1, s2 = G * mom[2].double(), G * mom[0].double(), G * mom[1].double()
+                var = ((s2 - s1 * s1 / n_tot) / (n_tot - 1.0)).clamp_min(0.0)
+                scale = (1.0 / (var.sqrt().float() + 1e-5))
+                obj_united = obj_actor + obj_critic * scale                        # (logged: this rank's terms, the union's scale)
+                cri_params = {id(p) for p in self.cri.parameters()}
+                with torch.no_grad():
+                    for p in params:
+                        if id(p) in cri_params and p.grad is not None:
+                            p.grad.mul_(scale)
             self.optimizer.step()
             sums += torch.stack([obj_united.detach(), obj_actor.detach(), obj_critic.detach(), obj_entropy.detach()])
         self.weights_changed()
@@ -454,10 +473,19 @@ class AgentPPO(AgentBase):
         fuse_adam = (self.dp is None and self.launch_timer is None and isinstance(self.optimizer, FlatAdam)
                      and getattr(fused, "adam_fusable", True))
 
+        # Data parallel: the critic's gradient leaves the kernels UNSCALED with the minibatch's target moments behind it; the one
+        # all-reduce of an optimizer step carries both, and the Adam launch applies 1 / (std of the UNION minibatch + 1e-5)
+        # (agent.py:652 on the minibatch the ranks hold together).  Nets whose critic takes the split pipeline (a modular actor
+        # on a stacked observation) keep the rank-local scale.
+        dp_union = self.dp is not None and isinstance(self.optimizer, FlatAdam) and getattr(fused, "dp_union_ok", True)
+
         def grads():   # overwrite: no zeroing launch; the running sum of the critic scale lands in loss_sums[3]
             fused(buf_state, action, st.logprob, st.adv, st.r_sum, st.table if use_table else st.idx, self.ratio_clip,
                   self.lambda_entropy, st.scale, overwrite=True, index_row=st.row if use_table else None,
-                  adam=self.optimizer if fuse_adam else None)
+                  adam=self.optimizer if fuse_adam else None, defer_critic_scale=dp_union)
+
+        def all_reduce():
+            self.dp.all_reduce_mean(fused.flat_grad_dp if dp_union else fused.flat_grad)
 
         # With the image map the launch that applies Adam writes every new parameter value into the packed images as well (the
         # fused step on one GPU, pime_adam_step_images behind the all-reduce under data parallelism): no re-pack launch.
@@ -465,12 +493,26 @@ class AgentPPO(AgentBase):
 
         def apply():
             if not fuse_adam:
-                if images_follow:
+                if dp_union:
+                    self.optimizer.step(images=fused if images_follow else None, dp=(fused, self.dp.world))
+                elif images_follow:
                     self.optimizer.step(images=fused)
                 else:
                     self.optimizer.step()
             if not images_follow:
                 fused.repack()
+
+        if dp_union and not getattr(fused, "dp_union_probed", False):   # does the library defer the scale for these nets?
+            from ..native import PimeError
+            fused.dp_union_probed = True
+            snap = [t.clone() for t in (fused.loss_sums, st.row)]
+            try:
+                grads()
+            except PimeError as exc:
+                print(f"| critic scale over the union minibatch unavailable for these nets ({exc}); using the rank-local scale")
+                fused.dp_union_ok, dp_union = False, False
+            for dst, src in zip((fused.loss_sums, st.row), snap):
+                dst.copy_(src)
 
         if fuse_adam and not getattr(fused, "adam_probed", False):   # does the library fuse the step for these nets?
             from ..native import PimeError
@@ -502,8 +544,8 @@ class AgentPPO(AgentBase):
         # build that refuses collectives under capture) the agent falls back to the two-graph sequence for good.
         in_graph_dp = self.dp is not None and self.use_graph_collective and getattr(self.dp, "graph_capturable", False)
         one_graph = self.use_single_graph and (self.dp is None or in_graph_dp) and use_table and self.launch_timer is None
-        if st.mode != (use_table, one_graph, fuse_adam):   # the captured graphs bake in the index source and the step form
-            st.mode, st.graph_a, st.graph_b, st.graph_full = (use_table, one_graph, fuse_adam), None, None, None
+        if st.mode != (use_table, one_graph, fuse_adam, dp_union):   # the captured graphs bake in the index source and the step form
+            st.mode, st.graph_a, st.graph_b, st.graph_full = (use_table, one_graph, fuse_adam, dp_union), None, None, None
             st.graph_update, st.graph_update_steps = None, None
         last = None
         # With the index table every optimizer step is the same launch sequence (the row cursor lives on the device), so once
@@ -520,7 +562,7 @@ class AgentPPO(AgentBase):
                             st.last.copy_(fused.loss_sums)
                         grads()
                         if self.dp is not None:
-                            self.dp.all_reduce_mean(fused.flat_grad)
+                            all_reduce()
                         apply()
                 st.graph_update = capture(whole_update)
             except RuntimeError as exc:
@@ -543,7 +585,7 @@ class AgentPPO(AgentBase):
                     if one_graph and self.dp is not None:
                         refused = None
                         try:
-                            st.graph_full = capture(grads, lambda: self.dp.all_reduce_mean(fused.flat_grad), apply)
+                            st.graph_full = capture(grads, all_reduce, apply)
                         except RuntimeError as exc:
                             refused = exc
                         # the ranks must use the SAME launch form from here on (a rank replaying the collective from its graph
@@ -553,7 +595,7 @@ class AgentPPO(AgentBase):
                             print(f"| all-reduce inside the HIP graph refused on a rank ({refused}); every rank uses the "
                                   "two-graph step sequence")
                             self.use_graph_collective, one_graph = False, False
-                            st.mode = (use_table, one_graph, fuse_adam)
+                            st.mode = (use_table, one_graph, fuse_adam, dp_union)
                             st.graph_full = None
                             torch.cuda.synchronize(dev)
                             st.graph_a, st.graph_b = capture(grads), capture(apply)
@@ -575,7 +617,7 @@ class AgentPPO(AgentBase):
             else:
                 run()
             if self.dp is not None:
-                self.dp.all_reduce_mean(fused.flat_grad)
+                all_reduce()
             if st.graph_b is not None:
                 st.graph_b.replay()
             else:

@@ -16,7 +16,7 @@ LIB_PATH = _override or os.path.join(PACKAGE_DIR, "libpime_hip.so")
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
-ABI_VERSION = 14
+ABI_VERSION = 15
 ENV_PH, ENV_WT = 0, 1
 STATE_F64, STATE_MIXED, STATE_MIXED16 = 0, 1, 2
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
@@ -45,7 +45,8 @@ class PpoNet(C.Structure):
 
 class PpoBatch(C.Structure):
     _fields_ = [("state", C.c_void_p), ("action", C.c_void_p), ("logprob", C.c_void_p), ("adv", C.c_void_p),
-                ("r_sum", C.c_void_p), ("indices", C.c_void_p), ("B", C.c_int32), ("flags", C.c_int32), ("index_row", C.c_void_p)]
+                ("r_sum", C.c_void_p), ("indices", C.c_void_p), ("B", C.c_int32), ("flags", C.c_int32), ("index_row", C.c_void_p),
+                ("dp_moments", C.c_void_p)]
 
 
 PPO_OVERWRITE_GRADS = 1
@@ -54,7 +55,8 @@ PPO_OVERWRITE_GRADS = 1
 class Adam(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("step", C.c_void_p), ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("eps", C.c_float), ("image_map", C.c_void_p)]
+                ("eps", C.c_float), ("image_map", C.c_void_p), ("dp_moments", C.c_void_p), ("critic_offset", C.c_int64),
+                ("dp_world", C.c_int32)]
 
 
 class Td3Net(C.Structure):
@@ -144,6 +146,7 @@ _SIGNATURES = {
     "pime_ppo_minibatch_step": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "pime_ppo_image_map": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "pime_adam_step_images": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "pime_adam_step_dp": (C.c_int, [_vp, _vp, _vp, _vp]),
     "pime_td3_supported": (C.c_int, [_i32, _i32, _i32]),
     "pime_td3_param_floats": (C.c_int64, [_i32, _i32, _i32]),
     "pime_td3_param_offsets": (C.c_int, [_i32, _i32, _i32, _vp]),

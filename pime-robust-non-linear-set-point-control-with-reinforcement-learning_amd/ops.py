@@ -127,7 +127,13 @@ class FusedPPOGrad:
         params = [p for p in list(act.parameters()) + list(cri.parameters()) if p.requires_grad]
         self.params = params
         total = sum(p.numel() for p in params)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        # four more words behind the gradients: under data parallelism the minibatch's target moments (sum r_sum, sum r_sum^2, B)
+        # ride in the SAME all-reduce as the gradients (flat_grad_dp), so that the critic scale of agent.py:652 is that of the
+        # union minibatch (pime_adam_step_dp)
+        self.flat_grad_dp = torch.zeros(total + 4, dtype=torch.float32, device=self.device)
+        self.flat_grad = self.flat_grad_dp[:total]
+        self.dp_moments = self.flat_grad_dp[total:]
+        self.critic_offset = sum(p.numel() for p in act.parameters() if p.requires_grad)   # flat order: actor, then critic
         off = 0
         for p in params:
             p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
@@ -279,7 +285,7 @@ class FusedPPOGrad:
         self.flat_grad.zero_()
 
     def __call__(self, state, action, logprob, adv, r_sum, indices, ratio_clip, lambda_entropy, critic_scale,
-                 overwrite=False, index_row=None, adam=None):
+                 overwrite=False, index_row=None, adam=None, defer_critic_scale=False):
         """Accumulates (overwrite=True: writes) d(obj_united)/d(theta) of the minibatch `indices` into the .grad views;
         loss_sums[3] accumulates the critic scale of every call.  index_row (int64 [1] on the device): `indices` is then a
         table [rows, B]; the call uses row index_row[0] and advances it (so a captured graph can be replayed per step).  All tensors float32
@@ -293,7 +299,9 @@ class FusedPPOGrad:
         batch = native.PpoBatch(state=state.data_ptr(), action=action.data_ptr(), logprob=logprob.data_ptr(),
                                 adv=adv.data_ptr(), r_sum=r_sum.data_ptr(), indices=indices.data_ptr(), B=B,
                                 flags=native.PPO_OVERWRITE_GRADS if overwrite else 0,
-                                index_row=index_row.data_ptr() if index_row is not None else None)
+                                index_row=index_row.data_ptr() if index_row is not None else None,
+                                # data parallel: critic gradient left unscaled, target moments written behind the flat gradients
+                                dp_moments=self.dp_moments.data_ptr() if defer_critic_scale else None)
         with torch.cuda.device(self.device):
             if adam is not None:   # gradients AND the Adam step, fused into the slab reduction (pime_ppo_minibatch_step)
                 assert adam.param is self.flat_param and adam.grad is self.flat_grad
@@ -328,10 +336,27 @@ class FlatAdam:
         self.step_count = torch.zeros(2, dtype=torch.float32, device=param.device)   # [0] step, [1] arrival counter (scratch)
         self.param_groups = [{"params": [param], "lr": self.lr}]
 
-    def step(self, images=None):
+    def step(self, images=None, dp=None):
         """images: the FusedPPOGrad whose packed images should follow the step (its image map): the launch then also writes
-        every new parameter value into them (pime_adam_step_images) and the caller skips repack()."""
+        every new parameter value into them (pime_adam_step_images) and the caller skips repack().
+        dp = (FusedPPOGrad, world): the step of a data-parallel rank behind the all-reduce of fused.flat_grad_dp -- the critic's
+        gradient is first scaled by 1 / (std of the union minibatch's targets + 1e-5) (pime_adam_step_dp)."""
         imap = images.image_map() if images is not None else None
+        if dp is not None:
+            fused, world = dp
+            assert fused.flat_param is self.param and fused.flat_grad.data_ptr() == self.grad.data_ptr()
+            if fused._structs is None:
+                fused._build_structs()
+            actor, critic, _ = fused._structs
+            opt = native.Adam(param=self.param.data_ptr(), grad=self.grad.data_ptr(), exp_avg=self.exp_avg.data_ptr(),
+                              exp_avg_sq=self.exp_avg_sq.data_ptr(), step=self.step_count.data_ptr(), n=self.param.numel(),
+                              lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                              image_map=imap.data_ptr() if imap is not None else None,
+                              dp_moments=fused.dp_moments.data_ptr(), critic_offset=int(fused.critic_offset), dp_world=int(world))
+            with torch.cuda.device(self.param.device):
+                native.check(native.lib().pime_adam_step_dp(C.byref(opt), C.byref(actor), C.byref(critic), _stream(self.param)),
+                             "pime_adam_step_dp")
+            return
         if imap is not None:
             assert images.flat_param is self.param
             if images._structs is None:

@@ -142,3 +142,95 @@ def test_two_rank_train_loop_exits_together(tmp_path):
     assert r[0]["length"] == r[1]["length"] == 0
     run = os.path.join(tmp_path, "run")
     assert os.path.exists(os.path.join(run, "actor.pth")) and os.path.exists(os.path.join(run, "init", "critic.pth"))
+
+
+# ---- the critic scale of agent.py:652 on the UNION minibatch -------------------------------------------------------------------------
+def _fill(buf, gen):
+    """Synthetic trajectory rows (no env needed: the update only sees the buffer)."""
+    T, n = buf.horizon, buf.num_envs
+    buf.state[:T + 1] = torch.randn(T + 1, n, 3, generator=gen) * torch.tensor([2.0, 2.0, 5.0]) + torch.tensor([7.0, 7.0, 0.0])
+    buf.reward[:T] = -torch.rand(T, n, generator=gen) * 4
+    buf.mask[:T] = torch.where(torch.rand(T, n, generator=gen) < 0.05, 0.0, 0.99)
+    buf.noise[:T] = torch.randn(T, n, 1, generator=gen)
+    buf.action[:T] = torch.randn(T, n, 1, generator=gen) * 0.6
+    buf.length = T
+
+
+def _union_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from oracle.cpu_stack import OracleBackend
+    from pime_amd import dist as pdist
+    from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
+    from pime_amd.elegantrl.replay import TrajectoryBuffer
+    dp = pdist.init_from_env(backend="gloo", device="cpu")
+    T, n, B, n_steps = 20, 16, 64, 3
+
+    def make_agent():
+        torch.manual_seed(42)                      # the same initial weights everywhere
+        ag = AgentResidualIntegratorModularPPO(backend=OracleBackend(), device="cpu")
+        ag.lambda_gae_adv = 0.99
+        ag.init(32, 3, 1, 1)
+        ag.init_residual({"init_K": np.array([[-0.02], [0.02], [0.035]])})
+        with torch.no_grad():
+            ag.act.net[-1].weight.normal_(0, 0.05)
+        return ag
+
+    agent = make_agent()
+    agent.dp = dp
+    buf = TrajectoryBuffer(T, n, 3, 1, "cpu")
+    _fill(buf, torch.Generator().manual_seed(500 + rank))          # every rank holds different lanes ...
+    idx = torch.randint(T * n, (n_steps, B), generator=torch.Generator().manual_seed(900 + rank))   # ... and draws its own rows
+    agent.index_hook = lambda step, buf_len, batch: idx[step]
+    agent.update_net(buf, T * n, B, n_steps * B / (T * n))
+    flat = torch.cat([p.detach().reshape(-1) for p in list(agent.act.parameters()) + list(agent.cri.parameters())])
+    # rank 0 gathers everybody's rows and repeats the update ALONE on the union buffer with the concatenated minibatches
+    rows = {k: getattr(buf, k)[:T + (1 if k == "state" else 0)].clone() for k in ("state", "reward", "mask", "noise", "action")}
+    gathered = {}
+    for k, v in rows.items():
+        parts = [torch.zeros_like(v) for _ in range(world)]
+        torch.distributed.all_gather(parts, v.contiguous())
+        gathered[k] = torch.cat(parts, dim=1)                       # lanes of rank r at [r n, (r + 1) n)
+    all_idx = [torch.zeros_like(idx) for _ in range(world)]
+    torch.distributed.all_gather(all_idx, idx)
+    out = {"flat": flat}
+    if rank == 0:
+        solo = make_agent()
+        big = TrajectoryBuffer(T, n * world, 3, 1, "cpu")
+        for k, v in gathered.items():
+            getattr(big, k)[:v.shape[0]] = v
+        big.length = T
+        N = n * world
+
+        def union_rows(step, buf_len, batch):       # local flat row t n + l of rank r = union row t N + r n + l
+            parts = []
+            for r in range(world):
+                t, l = all_idx[r][step] // n, all_idx[r][step] % n
+                parts.append(t * N + r * n + l)
+            return torch.cat(parts)
+        solo.index_hook = union_rows
+        solo.update_net(big, T * N, B * world, n_steps * B * world / (T * N))
+        out["solo"] = torch.cat([p.detach().reshape(-1) for p in list(solo.act.parameters()) + list(solo.cri.parameters())])
+    torch.save(out, os.path.join(out_dir, f"union_rank{rank}.pt"))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_data_parallel_update_equals_one_rank_on_the_union_minibatch(tmp_path, world):
+    """/root/reference/elegantrl/agent.py:652 divides the critic loss by the std of the MINIBATCH's targets; on G ranks the
+    minibatch is the union of the ranks' minibatches.  Every rank back-propagates the unscaled critic loss, the one flat all-reduce
+    of the step carries (sum r, sum r^2, count) behind the gradients, and the scale of the union is applied to the averaged critic
+    gradient: after three optimizer steps the replicas are bit-identical AND equal (2e-6) to ONE rank updating on the concatenated
+    buffer with the concatenated minibatches (advantage normalisation over the union included)."""
+    import oracle
+    oracle.build()
+    port = _free_port()
+    mp.spawn(_union_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"union_rank{k}.pt"), weights_only=True) for k in range(world)]
+    for k in range(1, world):
+        assert torch.equal(r[0]["flat"], r[k]["flat"]), "replicas diverged"
+    np.testing.assert_allclose(r[0]["flat"].numpy(), r[0]["solo"].numpy(), rtol=0, atol=2e-6)
