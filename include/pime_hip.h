@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 15
+#define PIME_ABI_VERSION 16
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -400,7 +400,8 @@ typedef struct pime_td3_net {
     float* grad;         /* [dev] same layout, WRITTEN: this step's gradient (the reference's .grad after backward()) */
     float* exp_avg;      /* [dev] Adam state, same layout; zero at construction */
     float* exp_avg_sq;
-    float* step;         /* [dev] float32[2], zeroed at construction: [0] step counter (advanced on the device), [1] scratch */
+    const float* step;   /* [dev] float32[1]: optimizer steps applied BEFORE table row 0; a call is Adam step number step[0] + row + 1.
+                          * The CALLER adds the number of steps behind an update (one stream-ordered add per update_net) */
     float lr, beta1, beta2, eps;
 } pime_td3_net;
 typedef struct pime_td3_batch {
@@ -410,10 +411,11 @@ typedef struct pime_td3_batch {
     const int64_t* nxt;      /* [dev] int64[table_rows, B]: their successors (idx + 1 in the flat ring, idx + N lanes in the vector ring) */
     const float* noise;      /* [dev] float32[table_rows, B] standard normal draws of the smoothing noise (torch.randn_like), or NULL:
                               * drawn in the kernel -- Philox4x32-10 keyed by noise_seed, counter (batch position, noise_epoch,
-                              * table row, stream 3), Box-Muller cosine branch in float64 */
-    int64_t* cursor;         /* [dev] int64[2] or NULL (row 0, epoch offset 0): [0] the table row of this step, advanced by the call;
-                              * [1] is added to noise_epoch (the host bumps it per update, so that a captured HIP graph draws
-                              * fresh noise in every replay) */
+                              * table row, stream 3), Box-Muller cosine branch in float32 */
+    int64_t row;             /* the table row of THIS optimizer step.  A launch argument, not device state: every node of a captured
+                              * update graph carries its own row, so no launch has to advance a shared cursor */
+    const int64_t* epoch;    /* [dev] int64[1] or NULL: added to noise_epoch (the host bumps it once per update, so that a captured
+                              * HIP graph draws fresh noise in every replay) */
     int32_t B;
     uint64_t noise_seed;
     uint32_t noise_epoch;
@@ -426,6 +428,8 @@ int pime_td3_param_offsets(int32_t which, int32_t D, int32_t md, int32_t* offset
 int64_t pime_td3_workspace_floats(int32_t D, int32_t md, int32_t B);
 /* soft_mode: 0 no soft target update, 1 soft update, 2 soft update when cursor[0] % update_freq == 0 (the reference's delayed update).
  * phases: bit 0 = critic half (gradients, Adam, soft update), bit 1 = actor half; 3 = the whole step (the cursor advances with bit 1).
+ *         The actor half reads the minibatch's state rows as the critic half of the SAME table row left them in the workspace: run
+ *         bit 1 alone only behind a bit-0 call on that row.
  * loss [dev] float32[4] or NULL: [0] += obj_actor, [1] += obj_critic of this step (zero them per update), [2], [3] = this step's values.
  * workspace [dev] float32[pime_td3_workspace_floats]. */
 int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_td3_net* critic, const pime_td3_batch* batch,

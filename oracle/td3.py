@@ -144,7 +144,9 @@ class Td3:
 
 def smoothing_noise(seed, epoch, row, B):
     """float32[B]: the draws the fused step makes when no noise table is given -- Philox4x32-10 keyed by `seed`, counter (batch
-    position, epoch, table row, stream 3), Box-Muller cosine branch in float64, rounded once (csrc/td3_fused.hip: td3_noise)."""
+    position, epoch, table row, stream 3), Box-Muller cosine branch (csrc/td3_fused.hip: td3_noise evaluates log / sqrt / cos with the
+    float32 hardware transcendentals; this float64 evaluation of the same uniforms agrees to ~1e-6 relative, far inside the gradient
+    tolerance of the test that uses it)."""
     from .binding import philox_uniform_pair
     out = np.empty(B, dtype=np.float32)
     for p in range(B):

@@ -1273,31 +1273,49 @@ int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_t
     PIME_REQUIRE(b && b->state && b->other && b->idx && b->nxt && b->B >= 1, "pime_td3_step: bad pime_td3_batch");
     PIME_REQUIRE(workspace != nullptr, "pime_td3_step: NULL workspace");
     PIME_REQUIRE(soft_mode >= 0 && soft_mode <= 2 && (soft_mode != 2 || update_freq >= 1), "pime_td3_step: soft_mode %d / update_freq %d", soft_mode, update_freq);
+    PIME_REQUIRE(b->row >= 0, "pime_td3_step: table row %lld", (long long)b->row);
+    const int soft = soft_mode == 1 || (soft_mode == 2 && b->row % update_freq == 0);
     PIME_REQUIRE(phases >= 1 && phases <= 3, "pime_td3_step: phases %d", phases);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = td3_grid(b->B), ngroups = (b->B + 15) / 16;
     const Td3SlabLayout LA = td3_actor_slab(D, md), LC = td3_critic_slab(D, md);
     float* const slab_c = workspace;
     float* const slab_a = workspace + (size_t)grid * LC.stride;
-    Td3Batch tb{b->state, b->other, b->idx, b->nxt, b->noise, b->cursor, b->B, b->noise_seed, b->noise_epoch, b->policy_noise, b->noise_clip};
-    auto apply = [&](const pime_td3_net* n, const Td3SlabLayout& L, const float* slab, int slot, bool advance) {
+    float* const xg = slab_a + (size_t)grid * LA.stride;   // [B][8] gathered rows: written by the critic launch, read by the actor launch
+    Td3Batch tb{b->state, b->other, b->idx, b->nxt, b->noise, (long long)b->row, b->epoch, b->B, b->noise_seed, b->noise_epoch, b->policy_noise, b->noise_clip};
+    auto apply = [&](const pime_td3_net* n, const Td3SlabLayout& L, const float* slab, int slot) {
         Td3ApplyArgs a{};
         a.L = L; a.slab = slab; a.nslabs = grid;
         a.param = n->param; a.target = n->target; a.grad = n->grad; a.exp_avg = n->exp_avg; a.exp_avg_sq = n->exp_avg_sq; a.step = n->step;
         a.lr = n->lr; a.b1 = n->beta1; a.b2 = n->beta2; a.eps = n->eps; a.tau = tau;
-        a.soft_mode = soft_mode; a.update_freq = update_freq > 0 ? update_freq : 1; a.cursor = b->cursor; a.advance_cursor = advance ? 1 : 0;
+        a.row = (long long)b->row; a.soft = soft;
         a.loss = loss; a.loss_slot = slot; a.inv_B = 1.0f / (float)b->B;
         return launch_td3_apply(a, s);
     };
+    static const bool tracing = std::getenv("PIME_TD3_TRACE") != nullptr;   // tuning aid: phase marks of workgroup 0 (synchronises)
+    static long long* trace_dev = nullptr;
+    if (tracing && !trace_dev) PIME_HIP_TRY(hipMalloc(&trace_dev, 64 * sizeof(long long)));
+    if (tracing) PIME_HIP_TRY(hipMemsetAsync(trace_dev, 0, 64 * sizeof(long long), s));
     if (phases & 1) {
-        Td3GradArgs g{tb, D, actor->target, critic->param, critic->target, slab_c, LC.stride, ngroups};
+        Td3GradArgs g{tb, D, actor->target, critic->param, critic->target, slab_c, xg, LC.stride, ngroups, tracing ? trace_dev : nullptr};
         if (int rc = launch_td3_grad(true, md, g, grid, s)) return rc;
-        if (int rc = apply(critic, LC, slab_c, 1, false)) return rc;
+        if (int rc = apply(critic, LC, slab_c, 1)) return rc;
     }
     if (phases & 2) {
-        Td3GradArgs g{tb, D, actor->param, critic->target, nullptr, slab_a, LA.stride, ngroups};
+        Td3GradArgs g{tb, D, actor->param, critic->target, nullptr, slab_a, xg, LA.stride, ngroups, tracing ? trace_dev + 32 : nullptr};
         if (int rc = launch_td3_grad(false, md, g, grid, s)) return rc;
-        if (int rc = apply(actor, LA, slab_a, 0, true)) return rc;
+        if (int rc = apply(actor, LA, slab_a, 0)) return rc;
+    }
+    if (tracing) {
+        long long t[64];
+        PIME_HIP_TRY(hipStreamSynchronize(s));
+        PIME_HIP_TRY(hipMemcpy(t, trace_dev, sizeof(t), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 2; ++k) {
+            std::fprintf(stderr, "[pime td3 trace] %s:", k ? "actor " : "critic");
+            for (int i = 1; i < 32; ++i)
+                if (t[32 * k + i]) std::fprintf(stderr, " m%d=%.2f", i, (double)(t[32 * k + i] - t[32 * k]) * 0.01);
+            std::fprintf(stderr, "\n");
+        }
     }
     return PIME_OK;
 }

@@ -76,7 +76,8 @@ struct Td3Batch {
     const int64_t* idx;        // [table rows][B] sampled rows; the successor state of row idx is row nxt
     const int64_t* nxt;
     const float* noise;        // [table rows][B] standard normal draws of the target policy smoothing, or NULL: Philox in the kernel
-    const int64_t* cursor;     // NULL (table row 0), or [0] the device-side row cursor (advanced by the actor's apply launch), [1] noise epoch offset
+    long long row;             // table row of this optimizer step (a launch argument: every node of a captured update graph carries its own)
+    const int64_t* epoch;      // NULL, or [dev] int64[1] added to noise_epoch (bumped by the host per update: fresh noise in every graph replay)
     int B;
     uint64_t noise_seed;       // noise == NULL: Philox key; counter (batch position, noise_epoch, table row, stream 3)
     uint32_t noise_epoch;
@@ -89,7 +90,9 @@ struct Td3GradArgs {
     const float *act, *cri;    // critic launch: TARGET actor, ONLINE critic;  actor launch: ONLINE actor, TARGET critic
     const float* cri_target;   // critic launch only: the target critic
     float* slab;               // [grid][stride]
+    float* xg;                 // [B][8]: the minibatch's state rows (+ action), gathered by the critic launch, read back by the actor launch
     int stride, ngroups;
+    long long* trace;          // tuning aid (PIME_TD3_TRACE): wall-clock marks of workgroup 0 / thread 0, NULL in production
 };
 
 struct Td3ApplyArgs {
@@ -97,12 +100,10 @@ struct Td3ApplyArgs {
     const float* slab;
     int nslabs;
     float *param, *target, *grad, *exp_avg, *exp_avg_sq;   // flat tensors of this net (layout above)
-    float* step;               // [0] Adam step count, [1] arrival counter (scratch, zero between launches)
+    const float* step;         // [0] optimizer steps applied before table row 0 (the host adds an update's step count behind it)
+    long long row;             // this launch is Adam step number step[0] + row + 1
     float lr, b1, b2, eps, tau;
-    int soft_mode;             // 0: no soft target update, 1: always, 2: when cursor % update_freq == 0 (agent.py:320-321,330-331)
-    int update_freq;
-    int64_t* cursor;           // NULL or the table row cursor (read for soft_mode 2)
-    int advance_cursor;        // the last workgroup to finish adds 1 to the cursor (the actor's launch: end of an optimizer step)
+    int soft;                  // 1: soft target update in this launch (delayed steps: row % update_freq == 0, agent.py:320-321,330-331)
     float* loss;               // [4]: [slot] += value of this step, [2 + slot] = value of this step
     int loss_slot;             // 0: actor objective = -(q sum) / B, 1: critic objective = (loss sum) / B
     float inv_B;

@@ -22,8 +22,9 @@
 //   * every workgroup leaves one partial gradient (slab, block-major in accumulator order); td3_apply_kernel sums the slabs in slab
 //     order (bit-reproducible), applies torch.optim.Adam to the element it has just reduced and, on delayed steps, the soft target
 //     update -- the parameters are the only copy of the weights, so that is all an optimizer step has to write.
-// The minibatch rows come from an index table [steps][B] walked by a device-side cursor (one HIP graph serves every step); the
-// smoothing noise from a table of normals (parity tests inject the reference's draws) or from Philox stream 3 in the kernel.
+// The minibatch rows come from an index table [steps][B]; the row of a step is a launch argument (a captured graph of an update's
+// steps bakes each row into its nodes: no launch advances shared state); the smoothing noise comes from a table of normals (parity
+// tests inject the reference's draws) or from Philox stream 3 in the kernel.
 #include <cstdlib>
 #include "td3.hpp"
 #include "pime_common.hpp"
@@ -38,13 +39,18 @@ constexpr uint32_t STREAM_TD3_SMOOTH = 3;
 
 #define TD3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define TD3_NO_HOIST() asm volatile("" ::: "memory")
+// PIME_TD3_TRACE=1: 100 MHz wall-clock marks of workgroup 0 (tuning aid; the pointer is NULL in production)
+#define TD3_MARK(i)                                                                        \
+    do {                                                                                   \
+        if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = wall_clock64();   \
+    } while (0)
 
 __device__ __forceinline__ f32x4_t mfma16(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4_t ld4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
 __device__ __forceinline__ void st4(float* p, const f32x4_t& v) { *reinterpret_cast<f32x4_t*>(p) = v; }
-__device__ __forceinline__ f32x4_t relu4(f32x4_t v) {
+__device__ __forceinline__ f32x4_t relu4(f32x4_t v) {   // one v_med3_f32 per element (`v > 0 ? v : 0` compiles to a canonicalising max + a max)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, __builtin_inff());
     return v;
 }
 // d * [h > 0] (torch's threshold_backward)
@@ -88,24 +94,26 @@ __device__ __forceinline__ float chain_elem(const float* __restrict__ buf, int l
 
 // ---- weights: global -> registers --------------------------------------------------------------------------------------------------
 // forward: A operand of output tile t0 + n, k-step (kt, r) = W[16 (t0 + n) + i][16 kt + 4 q + r]: component r of one 16-byte load
+// (a wave-uniform base pointer + ONE 32-bit lane offset + compile-time offsets: with a 64-bit per-lane pointer hipcc spends two
+// vector adds per load on the address; one wave per SIMD means every such instruction is exposed issue time)
 template <int NT, int PER>
 __device__ __forceinline__ void load_w(const float* __restrict__ W, int t0, int lane, f32x4_t (&w)[PER][NT]) {
-    const float* p = W + (size_t)(16 * t0 + (lane & 15)) * (NT * 16) + 4 * (lane >> 4);
+    const int o = (16 * t0 + (lane & 15)) * (NT * 16) + 4 * (lane >> 4);
 #pragma unroll
     for (int n = 0; n < PER; ++n)
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) w[n][kt] = ld4(p + n * 16 * (NT * 16) + 16 * kt);
+        for (int kt = 0; kt < NT; ++kt) w[n][kt] = ld4(W + (o + n * 16 * (NT * 16) + 16 * kt));
 }
 // transposed (dX = W^T dZ): A operand of output (= input-feature) tile t0 + n, k-step (kt, r) = W[16 kt + 4 q + r][16 (t0 + n) + i]
 template <int NT, int PER>
 __device__ __forceinline__ void load_wt(const float* __restrict__ W, int t0, int lane, f32x4_t (&w)[PER][NT]) {
-    const float* p = W + (size_t)(4 * (lane >> 4)) * (NT * 16) + 16 * t0 + (lane & 15);
+    const int o = (4 * (lane >> 4)) * (NT * 16) + 16 * t0 + (lane & 15);
 #pragma unroll
-    for (int n = 0; n < PER; ++n)
+    for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int n = 0; n < PER; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[n][kt][r] = p[(size_t)(16 * kt + r) * (NT * 16) + 16 * n];
+            for (int r = 0; r < 4; ++r) w[n][kt][r] = W[o + (16 * kt + r) * (NT * 16) + 16 * n];
 }
 
 // out[n] = bias + W in (output tiles t0 .. t0 + PER - 1); bias == nullptr: no bias (the backward chain)
@@ -204,6 +212,23 @@ __device__ __forceinline__ void slab_put(float* __restrict__ p, f32x4_t v, bool 
     if (accum) v += ld4(p);
     st4(p, v);
 }
+// a finished weight-gradient job -> the slab, block-major (one 16-byte store per lane and block).  The accumulate / overwrite decision
+// (a later sample group of the same workgroup: batches beyond 512 tiles) is taken once per job, not per block.
+template <int NT, int PER>
+__device__ __forceinline__ void slab_blocks(float* __restrict__ seg, int t0, int lane, const f32x4_t (&acc)[PER][NT], bool accum) {
+    float* const p = seg + (t0 * NT * 64 + lane) * 4;
+    if (!accum) {
+#pragma unroll
+        for (int n = 0; n < PER; ++n)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) st4(p + (n * NT + b) * 256, acc[n][b]);
+    } else {
+#pragma unroll
+        for (int n = 0; n < PER; ++n)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) st4(p + (n * NT + b) * 256, acc[n][b] + ld4(p + (n * NT + b) * 256));
+    }
+}
 // a vector gradient (bias, head weights) of this wave's features: v = per-sample terms, summed over the tile's samples
 template <int PER>
 __device__ __forceinline__ void vec_grad(float* __restrict__ seg, int t0, int lane, const f32x4_t (&v)[PER], bool accum) {
@@ -262,17 +287,23 @@ __device__ __forceinline__ void small_store(float* __restrict__ dst, int n4, int
 __device__ __forceinline__ float td3_noise(const Td3Batch& b, long long trow, int pos) {
     if (b.noise) return b.noise[(size_t)trow * b.B + pos];
     double ua, ub;
-    const uint32_t epoch = b.noise_epoch + (b.cursor ? (uint32_t)b.cursor[1] : 0u);   // cursor[1]: bumped by the host per update
+    const uint32_t epoch = b.noise_epoch + (b.epoch ? (uint32_t)b.epoch[0] : 0u);   // bumped by the host per update
     philox_pair(b.noise_seed, (uint32_t)pos, epoch, (uint32_t)trow, STREAM_TD3_SMOOTH, ua, ub);
-    return (float)(sqrt(-2.0 * log(1.0 - ua)) * cos(6.283185307179586476925286766559 * ub));
+    // Box-Muller (cosine branch) in float32 on the hardware transcendentals: the float64 log / sqrt / cos of the exploration kernels
+    // are several hundred instructions, exposed issue time in front of this kernel's first barrier (1 - ua in (0, 1]: log finite)
+    const float rad = __builtin_sqrtf(-2.0f * __logf((float)(1.0 - ua)));
+    return rad * __cosf(6.2831853071795864769f * (float)ub);
 }
 
 // ======================================================================================================== critic gradients
-template <int MD>
+// DD: the state width as a compile-time constant (3: pH, 4: water tank Integrator), 0: read from the arguments.  With DD fixed every
+// offset of the parameter / slab / LDS layouts folds into an immediate; as run-time values they are ~100 live scalars that hipcc
+// spills through VGPR lanes (v_readlane / v_writelane) and re-derives with scalar arithmetic in every phase.
+template <int MD, int DD>
 __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs a) {
     constexpr int NT = MD / 16, PER = NT / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int D = a.D, Dc = D + 1;
+    const int D = DD ? DD : a.D, Dc = D + 1;
     const Td3Lds F = td3_lds(NT, D);
     float* const B0 = lds + F.buf[0];
     float* const B1 = lds + F.buf[1];
@@ -290,9 +321,10 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
     const float* const ct = lds + F.small[2];   // target critic
     const Td3SlabLayout SL = td3_critic_slab(D, MD);
     const float invB = 1.0f / (float)a.b.B;
-    const long long trow = a.b.cursor ? a.b.cursor[0] : 0;
+    const long long trow = a.b.row;
     float* const sl = a.slab + (size_t)blockIdx.x * a.stride;
     float loss_acc = 0.f;   // wave 0, lanes 0..15: this workgroup's loss terms
+    TD3_MARK(0);
 
 #pragma unroll 1
     for (int group = blockIdx.x; group < a.ngroups; group += gridDim.x) {
@@ -304,6 +336,8 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         const bool valid = pos < a.b.B;
         const int p = valid ? pos : a.b.B - 1;
         const long long row = a.b.idx[(size_t)trow * a.b.B + p], nrow = a.b.nxt[(size_t)trow * a.b.B + p];
+        f32x4_t wA[PER][NT], wB[PER][NT], in[NT];
+        load_w<NT, PER>(a.act + PA.W2, t0, lane, wA);   // the first md x md weights: in flight behind the gather's two round trips
         // the nets' small tensors ride behind the index loads (first group only): seven 16-byte loads per thread, one round trip
         const bool stage = !accum;
         const int nA0 = (PA.W2 - PA.W1) / 4, nA1 = MD / 4, nA2 = (PA.total - PA.b3) / 4, nC0 = (PC.W2 - PC.W1) / 4, nC1 = (PC.total - PC.b2) / 4;
@@ -332,17 +366,15 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
             small_store(c + SC.W1 + 1024, nC0 - 256, tid, sv[7]); small_store(t + SC.W1 + 1024, nC0 - 256, tid, sv[8]);
         }
         TD3_BARRIER();   // the previous group is done with the LDS images; the small tensors are in
-        if (wave == 0) {   // the online critic's input rows [s, a, 0 ..] for its first-layer weight gradient
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int col = 4 * c + q;
-                xin[j * 16 + col] = col < D ? srow[col] : (col == D ? action : 0.f);
-            }
+        TD3_MARK(1);   // gather + small tensors
+        // the online critic's input [s, a, 0 ..]: column q / 4 + q of sample j (this lane's first-layer B operands)
+        const float xs0 = q < D ? s0 : (q == D ? action : 0.f), xs1 = 4 + q < D ? s1 : (4 + q == D ? action : 0.f);
+        if (wave == 0) {   // ... as rows [16 samples][16 columns] for its first-layer weight gradient, and for the actor launch
+            xin[j * 16 + q] = xs0; xin[j * 16 + 4 + q] = xs1; xin[j * 16 + 8 + q] = 0.f; xin[j * 16 + 12 + q] = 0.f;
+            if (valid) { a.xg[(size_t)pos * 8 + q] = xs0; a.xg[(size_t)pos * 8 + 4 + q] = xs1; }
         }
-        f32x4_t wA[PER][NT], wB[PER][NT], in[NT];
 
         // ------------------------------------------------------------------ next_a = clamp(tanh(act_target(s')) + clamp(noise))
-        load_w<NT, PER>(a.act + PA.W2, t0, lane, wA);
         {
             f32x4_t h[PER];
             layer_first<PER>(at + SA.W1, at + SA.b1, D, t0, lane, n0, n1, h);
@@ -351,6 +383,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         }
         load_w<NT, PER>(a.act + PA.W3, t0, lane, wB);
         TD3_BARRIER();
+        TD3_MARK(2);   // target actor layer 1
         chain_get<NT>(B0, lane, in);
         {
             f32x4_t h[PER];
@@ -360,6 +393,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         }
         load_w<NT, PER>(a.cri_target + PC.W2, t0, lane, wA);
         TD3_BARRIER();
+        TD3_MARK(3);   // layer 2
         chain_get<NT>(B1, lane, in);
         float next_a;
         {
@@ -373,6 +407,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
             const float nz = fminf(fmaxf(eps * a.b.policy_noise, -a.b.noise_clip), a.b.noise_clip);   // net.py:109
             next_a = fminf(fmaxf(tanhf(pre) + nz, -1.0f), 1.0f);
         }
+        TD3_MARK(4);   // layer 3 + head: next_a
         // ------------------------------------------------------------------ q_label = r + mask * min(cri_target twin heads)(s', next_a)
         load_w<NT, PER>(a.cri + PC.W2, t0, lane, wB);
         float label;
@@ -394,12 +429,11 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
             const float tq1 = red_get(red, 1, lane) + ct[SC.q1b], tq2 = red_get(red, 2, lane) + ct[SC.q2b];
             label = reward + mask * fminf(tq1, tq2);
         }
+        TD3_MARK(5);   // target critic: label
         // ------------------------------------------------------------------ online twin critic on (s, a): forward
         f32x4_t h1[PER], h2[PER];
         {
-            const float x0 = q < D ? s0 : (q == D ? action : 0.f);
-            const float x1 = 4 + q < D ? s1 : (4 + q == D ? action : 0.f);
-            layer_first<PER>(cr + SC.W1, cr + SC.b1, Dc, t0, lane, x0, x1, h1);
+            layer_first<PER>(cr + SC.W1, cr + SC.b1, Dc, t0, lane, xs0, xs1, h1);
 #pragma unroll
             for (int n = 0; n < PER; ++n) { h1[n] = relu4(h1[n]); chain_put(B1, lane, t0 + n, h1[n]); }
         }
@@ -412,6 +446,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         red_put(red, 3, wave, lane, head_partial<PER>(cr + SC.q1w, t0, lane, h2));
         red_put(red, 4, wave, lane, head_partial<PER>(cr + SC.q2w, t0, lane, h2));
         TD3_BARRIER();
+        TD3_MARK(6);   // online critic forward
         // ------------------------------------------------------------------ SmoothL1 x 2 (beta = 1, mean) and its gradient
         float g1 = 0.f, g2 = 0.f;
         {
@@ -448,16 +483,14 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
             }
         }
         TD3_BARRIER();   // dZ2 published
+        TD3_MARK(7);   // loss, head gradients, dZ2
         {   // net_sa.2 weight gradient
             f32x4_t acc[PER][NT];
             dw_blocks<NT, PER>(B2, B1, t0, lane, acc);
-            float* seg = sl + SL.seg[2].slab_off;
-#pragma unroll
-            for (int n = 0; n < PER; ++n)
-#pragma unroll
-                for (int b = 0; b < NT; ++b) slab_put(seg + (((t0 + n) * NT + b) * 64 + lane) * 4, acc[n][b], accum);
+            slab_blocks<NT, PER>(sl + SL.seg[2].slab_off, t0, lane, acc, accum);
         }
         TD3_NO_HOIST();
+        TD3_MARK(8);   // dW2
         chain_get<NT>(B2, lane, in);
         {
             f32x4_t d1[PER];
@@ -467,6 +500,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
             vec_grad<PER>(sl + SL.seg[1].slab_off, t0, lane, d1, accum);   // net_sa.0 bias
         }
         TD3_BARRIER();   // dZ1 published
+        TD3_MARK(9);   // dH1, dZ1
         {
             f32x4_t acc[PER];
             dw_first<PER>(B0, xin, t0, lane, acc);
@@ -475,6 +509,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
             for (int n = 0; n < PER; ++n) slab_put(seg + ((t0 + n) * 64 + lane) * 4, acc[n], accum);
         }
     }
+    TD3_MARK(10);   // dW1
     if (wave == 0) {
         const float t = row_sum16(loss_acc);
         if (tid == 0) st4(sl + SL.scalar_off, f32x4_t{t, 0.f, 0.f, 0.f});
@@ -483,11 +518,11 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
 
 // ======================================================================================================== actor gradients
 // obj_actor = -mean(cri_target.q1(s, tanh(act(s))))  (agent.py:323-324), differentiated down to the actor's parameters
-template <int MD>
+template <int MD, int DD>
 __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a) {
     constexpr int NT = MD / 16, PER = NT / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int D = a.D, Dc = D + 1;
+    const int D = DD ? DD : a.D, Dc = D + 1;
     const Td3Lds F = td3_lds(NT, D);
     float* const B0 = lds + F.buf[0];
     float* const B1 = lds + F.buf[1];
@@ -505,9 +540,9 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
     const float* const ct = lds + F.small[1];   // target critic
     const Td3SlabLayout SL = td3_actor_slab(D, MD);
     const float invB = 1.0f / (float)a.b.B;
-    const long long trow = a.b.cursor ? a.b.cursor[0] : 0;
     float* const sl = a.slab + (size_t)blockIdx.x * a.stride;
     float q_acc = 0.f;
+    TD3_MARK(0);
 
 #pragma unroll 1
     for (int group = blockIdx.x; group < a.ngroups; group += gridDim.x) {
@@ -518,8 +553,11 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
         const int pos = group * kTd3Tile + j;
         const bool valid = pos < a.b.B;
         const int p = valid ? pos : a.b.B - 1;
-        const long long row = a.b.idx[(size_t)trow * a.b.B + p];
-        const bool stage = !accum;   // the small tensors ride behind the index load (first group only)
+        f32x4_t wA[PER][NT], wB[PER][NT], in[NT];
+        load_w<NT, PER>(a.act + PA.W2, t0, lane, wA);
+        // the minibatch's state rows as the critic launch of this step gathered them (one round trip instead of index -> row)
+        const float s0 = q < D ? a.xg[(size_t)p * 8 + q] : 0.f, s1 = 4 + q < D ? a.xg[(size_t)p * 8 + 4 + q] : 0.f;
+        const bool stage = !accum;   // the small tensors ride along (first group only)
         const int nA0 = (PA.W2 - PA.W1) / 4, nA1 = MD / 4, nA2 = (PA.total - PA.b3) / 4, nC0 = (PC.W2 - PC.W1) / 4, nC1 = (PC.total - PC.b2) / 4;
         f32x4_t sv[6];
         if (stage) {
@@ -527,8 +565,6 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
             sv[3] = small_load(a.cri + PC.W1, nC0, tid); sv[4] = small_load(a.cri + PC.b2, nC1, tid);
             sv[5] = small_load(a.cri + PC.W1 + 1024, nC0 - 256, tid);   // D = 7 only
         }
-        const float* srow = a.b.state + (size_t)row * D;
-        const float s0 = q < D ? srow[q] : 0.f, s1 = 4 + q < D ? srow[4 + q] : 0.f;
         if (stage) {
             float* const w = lds + F.small[0];
             small_store(w + SA.W1, nA0, tid, sv[0]); small_store(w + SA.b2, nA1, tid, sv[1]); small_store(w + SA.b3, nA2, tid, sv[2]);
@@ -537,18 +573,13 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
             small_store(c + SC.W1 + 1024, nC0 - 256, tid, sv[5]);
         }
         TD3_BARRIER();   // the previous group is done with the LDS images; the small tensors are in
-        if (wave == 0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int col = 4 * c + q;
-                xin[j * 16 + col] = col < D ? srow[col] : 0.f;
-            }
+        TD3_MARK(1);
+        if (wave == 0) {   // the actor's input rows [16 samples][16 columns, zero beyond D] for its first-layer weight gradient
+            xin[j * 16 + q] = s0; xin[j * 16 + 4 + q] = s1; xin[j * 16 + 8 + q] = 0.f; xin[j * 16 + 12 + q] = 0.f;
         }
-        f32x4_t wA[PER][NT], wB[PER][NT], in[NT];
         f32x4_t a1[PER], a2[PER], a3[PER], c1[PER], c2[PER];
 
         // ------------------------------------------------------------------ action = tanh(act(s))
-        load_w<NT, PER>(a.act + PA.W2, t0, lane, wA);
         layer_first<PER>(ac + SA.W1, ac + SA.b1, D, t0, lane, s0, s1, a1);
 #pragma unroll
         for (int n = 0; n < PER; ++n) { a1[n] = relu4(a1[n]); chain_put(B0, lane, t0 + n, a1[n]); }
@@ -567,6 +598,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
         red_put(red, 0, wave, lane, head_partial<PER>(ac + SA.w4, t0, lane, a3));
         TD3_BARRIER();
         const float act = tanhf(red_get(red, 0, lane) + ac[SA.b4]);
+        TD3_MARK(2);   // actor forward
         // ------------------------------------------------------------------ q1 = cri_target.q1(s, action)
         {
             const float x0 = q < D ? s0 : (q == D ? act : 0.f);
@@ -591,6 +623,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
         }
         load_wt<NT, PER>(a.act + PA.W3, t0, lane, wA);   // dA2 = W3^T dZ3
         TD3_BARRIER();
+        TD3_MARK(3);   // target critic forward, dZc2
         if (valid && wave == 0 && q == 0) q_acc += red_get(red, 1, lane) + ct[SC.q1b];
         chain_get<NT>(B3, lane, in);
         float dpre;
@@ -610,6 +643,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
             TD3_BARRIER();
             dpre = red_get(red, 2, lane) * (1.0f - act * act);   // tanh'
         }
+        TD3_MARK(4);   // critic backward to the action
         // ------------------------------------------------------------------ actor backward + weight gradients
         {
             f32x4_t v[PER], dz[PER];
@@ -632,14 +666,11 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
         }
         load_wt<NT, PER>(a.act + PA.W2, t0, lane, wB);   // dA1 = W2^T dZ2
         TD3_BARRIER();   // dZ3 published
+        TD3_MARK(5);
         {
             f32x4_t acc[PER][NT];
             dw_blocks<NT, PER>(B2, B1, t0, lane, acc);   // net.4: dZ3^T A2
-            float* seg = sl + SL.seg[4].slab_off;
-#pragma unroll
-            for (int n = 0; n < PER; ++n)
-#pragma unroll
-                for (int b = 0; b < NT; ++b) slab_put(seg + (((t0 + n) * NT + b) * 64 + lane) * 4, acc[n][b], accum);
+            slab_blocks<NT, PER>(sl + SL.seg[4].slab_off, t0, lane, acc, accum);
         }
         TD3_NO_HOIST();
         chain_get<NT>(B2, lane, in);
@@ -651,14 +682,11 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
             vec_grad<PER>(sl + SL.seg[3].slab_off, t0, lane, d, accum);    // net.2 bias
         }
         TD3_BARRIER();   // dZ2 published
+        TD3_MARK(6);   // dW3, dA2
         {
             f32x4_t acc[PER][NT];
             dw_blocks<NT, PER>(B3, B0, t0, lane, acc);   // net.2: dZ2^T A1
-            float* seg = sl + SL.seg[2].slab_off;
-#pragma unroll
-            for (int n = 0; n < PER; ++n)
-#pragma unroll
-                for (int b = 0; b < NT; ++b) slab_put(seg + (((t0 + n) * NT + b) * 64 + lane) * 4, acc[n][b], accum);
+            slab_blocks<NT, PER>(sl + SL.seg[2].slab_off, t0, lane, acc, accum);
         }
         TD3_NO_HOIST();
         chain_get<NT>(B3, lane, in);
@@ -670,6 +698,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
             vec_grad<PER>(sl + SL.seg[1].slab_off, t0, lane, d, accum);    // net.0 bias
         }
         TD3_BARRIER();   // dZ1 published
+        TD3_MARK(7);   // dW2, dA1
         {
             f32x4_t acc[PER];
             dw_first<PER>(B1, xin, t0, lane, acc);
@@ -678,6 +707,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
             for (int n = 0; n < PER; ++n) slab_put(seg + ((t0 + n) * 64 + lane) * 4, acc[n], accum);
         }
     }
+    TD3_MARK(8);   // dW1
     if (wave == 0) {
         const float t = row_sum16(q_acc);
         if (tid == 0) st4(sl + SL.scalar_off, f32x4_t{t, 0.f, 0.f, 0.f});
@@ -685,29 +715,33 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
 }
 
 // ======================================================================================================== slab reduction + Adam + soft update
-// Workgroup = 64 consecutive 16-byte words of the slab layout; wave w sums slabs w, w + 4, ...; the partial sums meet in LDS and are
-// combined in wave order (bit-reproducible); wave 0 then owns four gradient elements per lane: writes them, applies torch.optim.Adam
-// (defaults: no weight decay, no amsgrad) to their parameters and, on a delayed step, target = tau * param + (1 - tau) * target
-// (agent.py:116-124, the reference's operand order).
+// Workgroup = 16 consecutive 16-byte words of the slab layout x 16 slab groups: thread (g, l) sums word l of slabs g, g + 16, ... with
+// ALL of them in flight at once (the slabs were written by other compute units a kernel ago: every load is an Infinity-Cache / HBM
+// round trip, and the launch is a few hundred workgroups of one such round trip each -- the first version, 64 words x 4 groups with
+// four loads in flight, took 11.5 us of a 78 us optimizer step); the 16 partial sums meet in LDS and are combined in group order
+// (bit-reproducible); the threads of group 0 then own four gradient elements each: they write them, apply torch.optim.Adam (defaults:
+// no weight decay, no amsgrad) to their parameters and, on a delayed step, target = tau * param + (1 - tau) * target (agent.py:116-124,
+// the reference's operand order).
+constexpr int kApplyWords = 16, kApplyGroups = kTd3Threads / kApplyWords;
 __global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) {
-    __shared__ float4 part[4][64];
-    __shared__ float adam_sh[3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float4 part[kApplyGroups][kApplyWords];
+    __shared__ float adam_sh[3];   // [1] step size, [2] sqrt of the second bias correction
+    const int tid = threadIdx.x, l = tid & (kApplyWords - 1), g = tid / kApplyWords;
     const int nwords = a.L.stride / 4;
-    const int unit = blockIdx.x * 64 + lane;
-    if (wave == 1) {   // Adam's bias corrections, off wave 0's critical path; every workgroup reads the OLD step count
-        const float tn = a.step[0] + 1.0f;
-        const double t = (double)tn;
-        const float ss = a.lr / (float)(1.0 - pow((double)a.b1, t));
-        const float bs = (float)sqrt(1.0 - pow((double)a.b2, t));
-        if (lane == 0) { adam_sh[0] = tn; adam_sh[1] = ss; adam_sh[2] = bs; }
+    const int unit = blockIdx.x * kApplyWords + l;
+    const bool finisher = g == 0 && unit < nwords;
+    if (tid == 64) {   // Adam's bias corrections, off the finishers' critical path.  The step number is a launch argument + a base the
+        // host moves once per update: no workgroup writes shared state, so the launch needs no arrival counter (the first version's
+        // atomic on one word cost ~12 ns per workgroup: 2.5 us of its 11.5 with 200 workgroups, 10 us with 850)
+        const double t = (double)a.step[0] + (double)a.row + 1.0;
+        adam_sh[1] = a.lr / (float)(1.0 - pow((double)a.b1, t));
+        adam_sh[2] = (float)sqrt(1.0 - pow((double)a.b2, t));
     }
-    bool soft = a.soft_mode == 1;
-    if (a.soft_mode == 2) soft = (a.cursor ? a.cursor[0] : 0) % a.update_freq == 0;
-    // which elements this lane finishes
+    const bool soft = a.soft != 0;
+    // which elements a finisher owns
     long long flat[4] = {-1, -1, -1, -1};
     bool scalar_word = false;
-    if (unit < nwords) {
+    if (finisher) {
         const int off = unit * 4;
         if (off >= a.L.scalar_off) scalar_word = true;
         else {
@@ -732,47 +766,42 @@ __global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) 
     }
     // optimizer state of those elements, requested before the slab loads
     float pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f}, pp[4] = {0.f, 0.f, 0.f, 0.f}, pt[4] = {0.f, 0.f, 0.f, 0.f};
-    if (wave == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (flat[k] >= 0) {
-                pm[k] = a.exp_avg[flat[k]]; pv[k] = a.exp_avg_sq[flat[k]]; pp[k] = a.param[flat[k]];
-                if (soft) pt[k] = a.target[flat[k]];
-            }
-    }
+    for (int k = 0; k < 4; ++k)
+        if (flat[k] >= 0) {
+            pm[k] = a.exp_avg[flat[k]]; pv[k] = a.exp_avg_sq[flat[k]]; pp[k] = a.param[flat[k]];
+            if (soft) pt[k] = a.target[flat[k]];
+        }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (unit < nwords) {
         const float* base = a.slab + (size_t)unit * 4;
         const size_t stride = (size_t)a.L.stride;
-        // A wave's slabs were written by other compute units a kernel ago: every load is an Infinity-Cache / HBM round trip, so
-        // the loop is bound by how many are in flight -- sixteen per lane (four dependent batches for 256 slabs; with four in flight
-        // the kernel took 11.5 us of a 78 us optimizer step).  Summed in slab order w, w + 4, ...: bit-reproducible.
-        int s = wave;
-        for (; s + 60 < a.nslabs; s += 64) {
+        int s = g;
+        for (; s + 15 * kApplyGroups < a.nslabs; s += 16 * kApplyGroups) {   // sixteen loads in flight (256 slabs: one batch)
             float4 v[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const float4*>(base + (size_t)(s + 4 * k) * stride);
+            for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const float4*>(base + (size_t)(s + kApplyGroups * k) * stride);
 #pragma unroll
             for (int k = 0; k < 16; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
         }
-        for (; s + 12 < a.nslabs; s += 16) {
+        for (; s + 3 * kApplyGroups < a.nslabs; s += 4 * kApplyGroups) {
             float4 v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(base + (size_t)(s + 4 * k) * stride);
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(base + (size_t)(s + kApplyGroups * k) * stride);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
         }
-        for (; s < a.nslabs; s += 4) {
+        for (; s < a.nslabs; s += kApplyGroups) {
             const float4 v = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
-    part[wave][lane] = acc;
+    part[g][l] = acc;
     __syncthreads();
-    const float t_new = adam_sh[0], step_size = adam_sh[1], bc2_sqrt = adam_sh[2];
-    if (wave == 0 && unit < nwords) {
-        float4 t = part[0][lane];
-        for (int w = 1; w < 4; ++w) { const float4 v = part[w][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    const float step_size = adam_sh[1], bc2_sqrt = adam_sh[2];
+    if (finisher) {
+        float4 t = part[0][l];
+        for (int w = 1; w < kApplyGroups; ++w) { const float4 v = part[w][l]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
         const float gv[4] = {t.x, t.y, t.z, t.w};
         if (scalar_word) {
             if (a.loss) {
@@ -796,15 +825,6 @@ __global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) 
             }
         }
     }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned int* arrivals = reinterpret_cast<unsigned int*>(a.step + 1);
-        if (atomicAdd(arrivals, 1u) == gridDim.x - 1) {   // every workgroup has read the old step count and the cursor
-            *arrivals = 0;
-            a.step[0] = t_new;
-            if (a.advance_cursor && a.cursor) a.cursor[0] += 1;
-        }
-    }
 }
 
 // ======================================================================================================== host side
@@ -814,17 +834,23 @@ int td3_grid(int B) {
 }
 int64_t td3_workspace_floats(int D, int md, int B) {
     const int64_t g = td3_grid(B);
-    return g * (td3_actor_slab(D, md).stride + td3_critic_slab(D, md).stride);
+    return g * (td3_actor_slab(D, md).stride + td3_critic_slab(D, md).stride) + (int64_t)B * 8;   // slabs + the gathered rows [B][8]
 }
 bool td3_supported(int D, int A, int md) { return A == 1 && D >= 1 && D <= kTd3MaxD && (md == 64 || md == 128); }
 
-template <int MD>
-static int launch_grad(bool critic, const Td3GradArgs& a, int grid, hipStream_t s) {
+template <int MD, int DD>
+static int launch_grad_d(bool critic, const Td3GradArgs& a, int grid, hipStream_t s) {
     const size_t lds_bytes = sizeof(float) * (size_t)td3_lds(MD / 16, a.D).total;
-    if (critic) hipLaunchKernelGGL((td3_critic_kernel<MD>), dim3(grid), dim3(kTd3Threads), lds_bytes, s, a);
-    else hipLaunchKernelGGL((td3_actor_kernel<MD>), dim3(grid), dim3(kTd3Threads), lds_bytes, s, a);
+    if (critic) hipLaunchKernelGGL((td3_critic_kernel<MD, DD>), dim3(grid), dim3(kTd3Threads), lds_bytes, s, a);
+    else hipLaunchKernelGGL((td3_actor_kernel<MD, DD>), dim3(grid), dim3(kTd3Threads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
+}
+template <int MD>
+static int launch_grad(bool critic, const Td3GradArgs& a, int grid, hipStream_t s) {
+    if (a.D == 3) return launch_grad_d<MD, 3>(critic, a, grid, s);   // pH observation
+    if (a.D == 4) return launch_grad_d<MD, 4>(critic, a, grid, s);   // water-tank Integrator observation
+    return launch_grad_d<MD, 0>(critic, a, grid, s);
 }
 int launch_td3_grad(bool critic, int md, const Td3GradArgs& a, int grid, hipStream_t s) {
     if (md == 128) return launch_grad<128>(critic, a, grid, s);
@@ -834,7 +860,7 @@ int launch_td3_grad(bool critic, int md, const Td3GradArgs& a, int grid, hipStre
 }
 int launch_td3_apply(const Td3ApplyArgs& a, hipStream_t s) {
     const int nwords = a.L.stride / 4;
-    hipLaunchKernelGGL(td3_apply_kernel, dim3((nwords + 63) / 64), dim3(kTd3Threads), 0, s, a);
+    hipLaunchKernelGGL(td3_apply_kernel, dim3((nwords + kApplyWords - 1) / kApplyWords), dim3(kTd3Threads), 0, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }

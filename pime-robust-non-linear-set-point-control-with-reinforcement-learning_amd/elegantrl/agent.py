@@ -945,7 +945,7 @@ class AgentTD3(AgentBase):
 
     def _update_fused(self, f, buffer, n_steps, batch_size, n_updates):
         """update_net on the fused step: the sampled rows of ALL n_steps optimizer steps are drawn at once into an index table that
-        the kernels walk with a device-side cursor (so every step is the same launch sequence), the smoothing noise is drawn inside
+        the kernels read by row (a launch argument), the smoothing noise is drawn inside
         the critic kernel (Philox stream 3; `draw_hook` injects tables instead), and from the second call on the whole update --
         n_steps x 4 launches -- is ONE HIP graph.  The only host synchronisation is the read of the four loss words at the end."""
         dev = self.device
@@ -977,13 +977,12 @@ class AgentTD3(AgentBase):
         if not hasattr(self, "_smooth_seed"):
             self._smooth_seed = (int(torch.initial_seed()) ^ 0x5DEECE66D) & (2 ** 63 - 1)   # smoothing noise follows torch's seed
         f.loss.zero_()
-        f.cursor[0] = 0
-        f.cursor[1] += 1   # the noise epoch: a captured graph draws fresh noise in every replay
+        f.begin_update()   # table row 0; the noise epoch advances (a captured graph draws fresh noise in every replay)
 
         def run():
-            for _ in range(n_steps):
+            for k in range(n_steps):   # the row is a launch argument: every node of the captured graph carries its own
                 f.step(buffer.buf_state, buffer.buf_other, idx, nxt, noise, self.soft_update_tau, self.update_freq, self.policy_noise,
-                       noise_seed=self._smooth_seed)
+                       noise_seed=self._smooth_seed, row=k)
 
         key = (buffer.buf_state.data_ptr(), buffer.buf_other.data_ptr(), noise is None, self.soft_update_tau, self.update_freq,
                self.policy_noise)
@@ -994,7 +993,6 @@ class AgentTD3(AgentBase):
                 with _no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                     run()
                 st["graph"], st["key"] = g, key
-                f.cursor[0] = 0   # (a capture executes nothing, but keep the state explicit)
             except RuntimeError as exc:
                 print(f"| HIP graph capture of the TD3 update failed ({exc}); continuing with eager launches")
                 self.use_hip_graphs = False
@@ -1006,6 +1004,7 @@ class AgentTD3(AgentBase):
         else:
             go()
         st["warm"] = True
+        f.row = n_steps        # (begin_update of the next call moves them into the optimizers' step base)
         self._n_updates += n_updates
         tot = f.loss.tolist()   # the update's only host synchronisation
         logger.record("train/n_updates", self._n_updates, exclude="tensorboard")

@@ -16,7 +16,7 @@ LIB_PATH = _override or os.path.join(PACKAGE_DIR, "libpime_hip.so")
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
-ABI_VERSION = 15
+ABI_VERSION = 16
 ENV_PH, ENV_WT = 0, 1
 STATE_F64, STATE_MIXED, STATE_MIXED16 = 0, 1, 2
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
@@ -67,7 +67,7 @@ class Td3Net(C.Structure):
 
 class Td3Batch(C.Structure):
     _fields_ = [("state", C.c_void_p), ("other", C.c_void_p), ("idx", C.c_void_p), ("nxt", C.c_void_p), ("noise", C.c_void_p),
-                ("cursor", C.c_void_p), ("B", C.c_int32), ("noise_seed", C.c_uint64), ("noise_epoch", C.c_uint32),
+                ("row", C.c_int64), ("epoch", C.c_void_p), ("B", C.c_int32), ("noise_seed", C.c_uint64), ("noise_epoch", C.c_uint32),
                 ("policy_noise", C.c_float), ("noise_clip", C.c_float)]
 
 

@@ -437,12 +437,20 @@ class FusedTD3:
                 p.grad = g[off:off + p.numel()].view_as(p)
         self.state = {k: torch.zeros_like(t) for k, t in (("act_m", self.act_flat), ("act_v", self.act_flat),
                                                           ("cri_m", self.cri_flat), ("cri_v", self.cri_flat))}
-        self.act_step, self.cri_step = torch.zeros(2, **f32), torch.zeros(2, **f32)
+        self.steps_done = torch.zeros(1, **f32)   # optimizer steps applied before table row 0 of the running update (both nets step together)
         self.workspace = None
         self.ensure_batch(self.max_batch)
         self.loss = torch.zeros(4, **f32)          # [0] sum of obj_actor, [1] sum of obj_critic, [2], [3] the last step's
-        self.cursor = torch.zeros(2, dtype=torch.int64, device=dev)   # [0] table row of the next step, [1] noise epoch offset
+        self.epoch = torch.zeros(1, dtype=torch.int64, device=dev)    # added to the noise epoch: bumped once per update
+        self.row = 0                                                   # table row of the next step (host side: a launch argument)
         self._structs()
+
+    def begin_update(self):
+        """Table row 0 again: the steps of the previous update move into the optimizers' step base, the noise epoch advances."""
+        if self.row:
+            self.steps_done += float(self.row)
+        self.row = 0
+        self.epoch += 1
 
     def ensure_batch(self, batch):
         """Workspace (one partial-gradient slab per workgroup) for minibatches of up to `batch` rows; the optimizer state stays."""
@@ -473,29 +481,34 @@ class FusedTD3:
     def _structs(self):
         s = self.state
         self._actor = native.Td3Net(param=self.act_flat.data_ptr(), target=self.act_t_flat.data_ptr(), grad=self.act_grad.data_ptr(),
-                                    exp_avg=s["act_m"].data_ptr(), exp_avg_sq=s["act_v"].data_ptr(), step=self.act_step.data_ptr(),
+                                    exp_avg=s["act_m"].data_ptr(), exp_avg_sq=s["act_v"].data_ptr(), step=self.steps_done.data_ptr(),
                                     lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
         self._critic = native.Td3Net(param=self.cri_flat.data_ptr(), target=self.cri_t_flat.data_ptr(), grad=self.cri_grad.data_ptr(),
-                                     exp_avg=s["cri_m"].data_ptr(), exp_avg_sq=s["cri_v"].data_ptr(), step=self.cri_step.data_ptr(),
+                                     exp_avg=s["cri_m"].data_ptr(), exp_avg_sq=s["cri_v"].data_ptr(), step=self.steps_done.data_ptr(),
                                      lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
 
     def step(self, buf_state, buf_other, idx, nxt, noise, tau, update_freq, policy_noise, noise_clip=0.5, noise_seed=0,
-             noise_epoch=0, soft_mode=2, phases=3, use_cursor=True):
-        """One optimizer step on table row cursor[0] of idx / nxt (int64 [rows, B]) and noise (float32 [rows, B] or None: Philox in
-        the kernel); advances the cursor.  use_cursor=False: idx / nxt / noise are single rows [B] and soft_mode must be 0 or 1."""
+             noise_epoch=0, soft_mode=2, phases=3, row=None):
+        """One optimizer step on table row `row` (default: self.row, which then advances) of idx / nxt (int64 [rows, B]) and noise
+        (float32 [rows, B] or None: Philox in the kernel).  The row is a launch argument: a captured graph of an update's steps
+        bakes each step's row into its nodes."""
         _need_cuda(buf_state, buf_other, idx, nxt)
         B = idx.shape[-1]
+        advance = row is None
+        row = self.row if advance else int(row)
+        assert idx.dim() == 2 and 0 <= row < idx.shape[0], (row, idx.shape)
         assert B <= self.max_batch and idx.dtype == nxt.dtype == torch.int64 and idx.is_contiguous() and nxt.is_contiguous()
         assert buf_state.dtype == buf_other.dtype == torch.float32 and buf_state.is_contiguous() and buf_other.is_contiguous()
         assert buf_state.shape[1] == self.D and buf_other.shape[1] == 3
         assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape == idx.shape)
-        assert use_cursor or soft_mode in (0, 1)
         batch = native.Td3Batch(state=buf_state.data_ptr(), other=buf_other.data_ptr(), idx=idx.data_ptr(), nxt=nxt.data_ptr(),
-                                noise=noise.data_ptr() if noise is not None else None,
-                                cursor=self.cursor.data_ptr() if use_cursor else None, B=B, noise_seed=int(noise_seed),
-                                noise_epoch=int(noise_epoch), policy_noise=float(policy_noise), noise_clip=float(noise_clip))
+                                noise=noise.data_ptr() if noise is not None else None, row=row, epoch=self.epoch.data_ptr(), B=B,
+                                noise_seed=int(noise_seed), noise_epoch=int(noise_epoch), policy_noise=float(policy_noise),
+                                noise_clip=float(noise_clip))
         with torch.cuda.device(self.device):
             native.check(native.lib().pime_td3_step(self.D, self.md, C.byref(self._actor), C.byref(self._critic), C.byref(batch),
                                                     C.c_float(tau), int(update_freq), int(soft_mode), int(phases),
                                                     native.ptr(self.workspace), native.ptr(self.loss), _stream(buf_state)),
                          "pime_td3_step")
+        if advance and phases & 2:
+            self.row += 1
