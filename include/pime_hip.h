@@ -463,14 +463,20 @@ int pime_adam_step_dp(const pime_adam* opt, const pime_ppo_net* actor, const pim
  * Life cycle, per rank (one process per GPU): create -> export the 64-byte handle -> exchange the handles of all ranks (any
  * transport: torch.distributed all_gather) -> connect -> allreduce_mean per optimizer step (one launch on the caller's stream,
  * HIP-graph capturable) -> destroy.  world <= 8.  A peer that never arrives does not hang the device: the kernel gives up after
- * ~2 s and pime_oneshot_status() returns non-zero. */
+ * ~2 s and pime_oneshot_status() returns non-zero -- which the caller must treat as fatal. */
 typedef struct pime_oneshot pime_oneshot;
 pime_oneshot* pime_oneshot_create(int32_t rank, int32_t world, int64_t n_floats, int32_t device);
 int pime_oneshot_export(pime_oneshot* h, void* handle_out /* [host] 64 bytes */);
 int pime_oneshot_connect(pime_oneshot* h, const void* handles /* [host] world x 64 bytes, rank order */);
 /* data [dev] float32[n_floats]: replaced by the mean over the ranks */
 int pime_oneshot_allreduce_mean(pime_oneshot* h, float* data, pime_stream stream);
+/* 0: every call so far completed.  Non-zero: a peer's rows did not arrive within ~2 s (1) or the local grid barrier timed out (2) --
+ * the launch then left `data` partly or wholly UN-averaged: treat it as fatal (the replicas have diverged); the Python side checks it
+ * at the end of every update and raises on every rank.  Synchronises the device. */
 int pime_oneshot_status(pime_oneshot* h);
+/* info [host] int32[5]: [0] 1 = the region is fine-grained memory (required between DIFFERENT devices), 0 = the runtime fell back to
+ * coarse-grained memory (valid only between processes sharing one device); [1] device ordinal; [2..4] PCI domain / bus / device. */
+int pime_oneshot_info(pime_oneshot* h, int32_t* info);
 void pime_oneshot_destroy(pime_oneshot* h);
 
 #pragma GCC visibility pop

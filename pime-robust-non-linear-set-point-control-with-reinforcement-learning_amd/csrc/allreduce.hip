@@ -133,6 +133,7 @@ struct pime_oneshot {
     void* peer[kArMaxWorld] = {};      // opened peer regions (peer[rank] = region)
     unsigned* local = nullptr;
     bool connected = false;
+    bool fine_grained = false;         // region obtained with hipDeviceMallocFinegrained (coherent for peers on OTHER devices while kernels run)
 };
 
 extern "C" {
@@ -149,7 +150,8 @@ pime_oneshot* pime_oneshot_create(int32_t rank, int32_t world, int64_t n_floats,
     // fine-grained memory: peer writes and system-scope atomics are coherent while the kernels run; plain hipMalloc (coarse-grained)
     // if the runtime refuses (still correct between processes that share one device and its L2)
     hipError_t e = hipExtMallocWithFlags(&h->region, bytes, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&h->region, bytes); }
+    h->fine_grained = e == hipSuccess;
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&h->region, bytes); }   // recorded: pime_oneshot_info, and refused across devices
     if (e != hipSuccess || hipMalloc(reinterpret_cast<void**>(&h->local), 8 * sizeof(unsigned)) != hipSuccess) {
         set_error("pime_oneshot_create: allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
         delete h;
@@ -172,6 +174,7 @@ int pime_oneshot_export(pime_oneshot* h, void* handle_out) {
         const size_t bytes = ArRegion::bytes(h->n);
         (void)hipFree(h->region);
         h->region = nullptr;
+        h->fine_grained = false;
         PIME_HIP_TRY(hipMalloc(&h->region, bytes));
         PIME_HIP_TRY(hipMemset(h->region, 0, bytes));
         PIME_HIP_TRY(hipDeviceSynchronize());
@@ -206,6 +209,19 @@ int pime_oneshot_allreduce_mean(pime_oneshot* h, float* data, pime_stream stream
     }
     hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(h->world * kArChunks), dim3(kArThreads), 0, static_cast<hipStream_t>(stream), a);
     PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+
+/* info[0] = 1 if the exported region is fine-grained device memory (coherent for peers on other devices while kernels run), 0 if the
+ * runtime only gave coarse-grained memory (coherent between processes that share ONE device and its L2 -- wrong means, silently, across
+ * devices); info[1] = device ordinal; info[2..4] = PCI domain, bus, device of that GPU (ranks compare them to see whether they share it). */
+int pime_oneshot_info(pime_oneshot* h, int32_t* info) {
+    PIME_REQUIRE(h && info, "pime_oneshot_info: NULL argument");
+    int dom = 0, bus = 0, dev = 0;
+    PIME_HIP_TRY(hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, h->device));
+    PIME_HIP_TRY(hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, h->device));
+    PIME_HIP_TRY(hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, h->device));
+    info[0] = h->fine_grained ? 1 : 0; info[1] = h->device; info[2] = dom; info[3] = bus; info[4] = dev;
     return PIME_OK;
 }
 

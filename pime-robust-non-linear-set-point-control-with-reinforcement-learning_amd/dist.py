@@ -62,10 +62,29 @@ class OneShotAllReduce:
             raise native.PimeError(f"pime_oneshot_create failed: {native.last_error()}")
         mine = (C.c_ubyte * 64)()
         native.check(self._lib.pime_oneshot_export(self._h, mine), "pime_oneshot_export")
+        info = (C.c_int32 * 5)()   # after the export: it may have re-allocated the region as coarse-grained memory
+        native.check(self._lib.pime_oneshot_info(self._h, info), "pime_oneshot_info")
         dev = self.device if td.get_backend() == "nccl" else torch.device("cpu")
         t = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
         gathered = [torch.empty_like(t) for _ in range(world)]
         td.all_gather(gathered, t)
+        # which memory every rank obtained and which GPU it sits on (PCI domain / bus / device + host name hash): coarse-grained
+        # regions are coherent only between processes that share ONE device, so a fallback anywhere with ranks on different devices
+        # is refused -- on every rank alike, from the gathered facts -- and the caller falls back to the RCCL / gloo all-reduce
+        import socket
+        import zlib
+        me = torch.tensor([int(info[0]), int(info[2]), int(info[3]), int(info[4]), zlib.crc32(socket.gethostname().encode()) & 0x7FFFFFFF],
+                          dtype=torch.int64, device=dev)
+        infos = [torch.empty_like(me) for _ in range(world)]
+        td.all_gather(infos, me)
+        infos = [i.cpu().tolist() for i in infos]
+        self.fine_grained = all(i[0] == 1 for i in infos)
+        self.same_device = all(i[1:] == infos[0][1:] for i in infos)
+        if not self.fine_grained and not self.same_device:
+            self.close()
+            raise native.PimeError("one-shot all-reduce refused: the runtime gave coarse-grained memory on rank(s) "
+                                   f"{[r for r, i in enumerate(infos) if i[0] != 1]} and the ranks sit on different devices "
+                                   "(peer writes would not be coherent while the kernels run)")
         handles = (C.c_ubyte * (64 * world))(*[int(b) for g in gathered for b in g.cpu().tolist()])
         native.check(self._lib.pime_oneshot_connect(self._h, handles), "pime_oneshot_connect")
         td.barrier()   # every rank has mapped every region before the first push
@@ -80,6 +99,16 @@ class OneShotAllReduce:
     def status(self):
         """0: every call so far completed; non-zero: a peer did not arrive within the kernel's spin limit (synchronises)."""
         return int(self._lib.pime_oneshot_status(self._h))
+
+    def check(self):
+        """A timed-out call left the buffer partly or wholly un-averaged and the replicas diverged: fatal, on whichever rank sees it
+        (its peers time out on its absence in turn)."""
+        from . import native
+        st = self.status()
+        if st != 0:
+            what = "a peer's rows did not arrive within the kernel's spin limit (~2 s)" if st == 1 else "the local grid barrier timed out"
+            raise native.PimeError(f"one-shot all-reduce failed (status {st}): {what}; the gradient was NOT averaged and the "
+                                   "replicas have diverged -- aborting")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -104,8 +133,9 @@ class DataParallel:
         # fine-grained memory ACROSS devices over xGMI cannot be exercised on this pool's one-GPU boxes.
         self.use_oneshot = os.environ.get("PIME_ONESHOT_ALLREDUCE") == "1"
         self._oneshot = {}
-        # RCCL collectives are kernels on the current stream and can be captured into a HIP graph; gloo's are host calls
-        self.graph_capturable = td.is_initialized() and (td.get_backend() == "nccl" or os.environ.get("PIME_ONESHOT_ALLREDUCE") == "1")
+        # RCCL collectives are kernels on the current stream and can be captured into a HIP graph, and so is the one-shot kernel;
+        # gloo's are host calls (all_reduce_mean clears the flag again if the one-shot path has to be refused under gloo)
+        self.graph_capturable = td.is_initialized() and (td.get_backend() == "nccl" or self.use_oneshot)
 
     def lane_offset(self, lanes_per_rank):
         """Global id of this rank's lane 0 (the env kernels' Philox counter word / Mt19937 seed offset)."""
@@ -127,8 +157,15 @@ class DataParallel:
         if self.use_oneshot and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and self.world <= 8:
             ar = self._oneshot.get(t.numel())
             if ar is None:
-                ar = self._oneshot[t.numel()] = OneShotAllReduce(self.rank, self.world, t.numel(), t.device)
-            return ar(t)
+                from .native import PimeError
+                try:
+                    ar = self._oneshot[t.numel()] = OneShotAllReduce(self.rank, self.world, t.numel(), t.device)
+                except PimeError as exc:   # decided from all-gathered facts: every rank lands here together
+                    print(f"| {exc}; using the {td.get_backend()} all-reduce")
+                    self.use_oneshot = False
+                    self.graph_capturable = td.get_backend() == "nccl"
+            if ar is not None:
+                return ar(t)
         if td.get_backend() == "nccl":
             td.all_reduce(t, op=td.ReduceOp.AVG)
         else:
@@ -155,6 +192,11 @@ class DataParallel:
             g.copy_(self._flat[off:off + g.numel()].view_as(g))
             off += g.numel()
         return grads[-1] if extra is not None else None
+
+    def check(self):
+        """Raises if a one-shot all-reduce of this rank timed out (called where the update synchronises anyway)."""
+        for ar in self._oneshot.values():
+            ar.check()
 
     def barrier(self):
         td.barrier()

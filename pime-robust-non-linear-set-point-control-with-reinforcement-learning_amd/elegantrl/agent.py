@@ -628,6 +628,8 @@ class AgentPPO(AgentBase):
         if not n_steps:
             return 0.0, 0.0
         tot = fused.loss_sums.tolist()                                             # the only host sync of the update
+        if self.dp is not None:
+            self.dp.check()   # a timed-out one-shot all-reduce left gradients un-averaged: fatal, here where the stream is drained
         lst = last.tolist()
         B = float(batch_size)
         ent, cri = tot[1] / (n_steps * B), tot[2] / (n_steps * B)

@@ -139,6 +139,7 @@ _SIGNATURES = {
     "pime_oneshot_connect": (C.c_int, [_vp, _vp]),
     "pime_oneshot_allreduce_mean": (C.c_int, [_vp, _vp, _vp]),
     "pime_oneshot_status": (C.c_int, [_vp]),
+    "pime_oneshot_info": (C.c_int, [_vp, _vp]),
     "pime_oneshot_destroy": (None, [_vp]),
     "pime_rollout_h": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pime_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),

@@ -11,11 +11,26 @@ import torch.distributed as td  # noqa: E402
 from pime_amd import dist as pdist  # noqa: E402
 
 out, n = sys.argv[1], int(sys.argv[2])
+mode = sys.argv[3] if len(sys.argv) > 3 else "parity"
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda", 0)      # every rank on the one GPU of the box; gloo carries the handle exchange and the reference sums
 torch.cuda.set_device(0)
 td.init_process_group(backend="gloo", rank=rank, world_size=world)
 ar = pdist.OneShotAllReduce(rank, world, n, dev)
+assert ar.fine_grained or ar.same_device
+
+if mode == "absent":   # rank 1 maps the regions and then never calls: rank 0's launch must give up and the check must raise
+    import time
+    if rank == 1:
+        time.sleep(8.0)              # keep the region mapped while rank 0 spins out (~2 s) and reports
+        sys.exit(0)
+    x = torch.ones(n, device=dev)
+    ar(x)
+    torch.cuda.synchronize()
+    dp = pdist.DataParallel(rank, world, 0, dev)
+    dp._oneshot[n] = ar
+    dp.check()                       # raises PimeError: the process exits non-zero with the message on stderr
+    sys.exit(0)                      # (not reached)
 
 
 def vec(k):

@@ -88,3 +88,29 @@ def test_data_parallel_update_with_the_oneshot_allreduce(tmp_path):
     assert torch.equal(fast[0]["flat"], fast[1]["flat"]), "replicas diverged under the one-shot all-reduce"
     assert torch.equal(fast[0]["flat"], ref[0]["flat"]), "one-shot and gloo all-reduce give different weights"
     assert torch.isfinite(fast[0]["flat"]).all()
+
+
+def test_a_peer_that_never_arrives_is_fatal(tmp_path):
+    """a one-shot all-reduce whose peer does not show up used to leave the gradient silently un-averaged (the kernel gives
+    up after ~2 s and only sets a status word nobody read).  DataParallel.check(), which update_net calls where it synchronises
+    anyway, now raises on that status: the rank exits non-zero and says why."""
+    world, port = 2, _free_port()
+    out = str(tmp_path / "absent")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "oneshot_worker.py"), out, "4096", "absent"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode()[-3000:])
+    assert procs[1].returncode == 0, logs[1]
+    assert procs[0].returncode != 0, "rank 0 must fail loudly when its peer never pushes:\n" + logs[0]
+    assert "one-shot all-reduce failed" in logs[0] and "replicas have diverged" in logs[0], logs[0]
