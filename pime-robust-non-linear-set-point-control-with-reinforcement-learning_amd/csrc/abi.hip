@@ -343,7 +343,8 @@ static int rollout_eval_t(pime_env* e, const PhPtrs<S>& ph, const WtPtrs<S>& wt,
     a.img = packed_actor;
     for (int j = 0; j < e->obs_dim; ++j) a.K.k[j] = priorK[j];
     a.n_steps = n_steps; a.seg_len = seg_len;
-    for (int j = 0; j < n_setpoints; ++j) a.setpoint[j] = setpoints[j];
+    if (seg_len > 0)   // (validated by the caller: setpoints != NULL, 1 <= n_setpoints <= kMaxSetpoints)
+        for (int j = 0; j < n_setpoints && j < kMaxSetpoints; ++j) a.setpoint[j] = setpoints[j];
     a.ret = ret; a.trace = trace;
     return launch_rollout_eval<S>(kind, md, a, static_cast<hipStream_t>(stream));
 }
@@ -832,6 +833,7 @@ int pime_rollout_eval(pime_env* e, int32_t kind, int32_t md, const float* packed
     PIME_REQUIRE(pime_rollout_eval_supported(e, kind, md), "pime_rollout_eval: not served for this handle / actor kind %d width %d "
                  "(pime_rollout_eval_supported)", kind, md);
     PIME_REQUIRE(priorK && n_steps >= 1 && (kind == -1 || packed_actor) && (ret || trace), "pime_rollout_eval: bad arguments");
+    PIME_REQUIRE(n_setpoints >= 0 && n_setpoints <= kMaxSetpoints, "pime_rollout_eval: n_setpoints %d (0 .. %d)", n_setpoints, kMaxSetpoints);
     PIME_REQUIRE(seg_len >= 0 && (seg_len == 0 || (setpoints && n_setpoints >= 1 && n_setpoints <= kMaxSetpoints &&
                                                    (n_steps + seg_len - 1) / seg_len <= n_setpoints)),
                  "pime_rollout_eval: the set-point schedule does not cover n_steps (at most %d segments)", kMaxSetpoints);

@@ -56,8 +56,12 @@ __global__ __launch_bounds__(kEvalThreads) void rollout_eval_kernel(EvalArgs<S> 
         PIME_NO_HOIST();
         if (a.seg_len > 0 && t % a.seg_len == 0) {   // segment boundary of a step-response protocol (wave-uniform)
             const double sp = a.setpoint[t / a.seg_len];
-            if constexpr (ENV == 0) { E.r = (S)sp; E.I = S(0); E.t = 0; obs[1] = (float)E.r; obs[2] = 0.f; }
-            else { W.r = (S)sp; W.I = S(0); W.t = 0; obs[2] = (float)W.r; obs[3] = 0.f; }
+            // a boundary stands for the env.reset() the step-per-launch protocol does per segment (protocols.py): beyond the first
+            // one it starts a new EPISODE -- the process noise is keyed on (episode, t), so without the bump every segment would
+            // replay segment 0's noise sequence
+            const int bump = t > 0 ? 1 : 0;
+            if constexpr (ENV == 0) { E.r = (S)sp; E.I = S(0); E.t = 0; E.episode += bump; obs[1] = (float)E.r; obs[2] = 0.f; }
+            else { W.r = (S)sp; W.I = S(0); W.t = 0; W.episode += bump; obs[2] = (float)W.r; obs[3] = 0.f; }
         }
         double a_env = 0.0;                                                        // agent_residual.py:61 without the noise
 #pragma unroll

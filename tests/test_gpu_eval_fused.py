@@ -92,6 +92,48 @@ def test_fused_episode_returns_against_oracle_and_stepwise(env_name, algo, md):
         e.close()
 
 
+@pytest.mark.parametrize("algo,md,N", [("ResidualIntegratorModularPPO", 128, 2048), ("ResidualPPO", 64, 2048),
+                                       ("ResidualIntegratorModularPPO", 128, 6144)])   # 6 144 lanes: the 16-lane-tile (non-QUAD) instantiation
+def test_fused_ph_evaluation_replays_cell_exact_through_the_oracle(algo, md, N):
+    """The pH evaluation episode pinned lane by lane (the return comparison above is statistical for pH
+    because a float32 rounding difference of the policy MEAN can move a lane into the neighbouring titration cell).  The kernel's
+    trace mode records every step's observation, env action, reward and plant state; the recorded ACTIONS are replayed through
+    OraclePH (as tests/rollout_replay.py does for the training rollout): every lane reads the oracle's titration cell at every step
+    (float32 y bit-equal), x to 1e-12 relative, rewards and returns to 2e-5; and the recorded action itself is the oracle's forward of
+    the recorded observation + prior term to 3e-5 at every step."""
+    import oracle
+    from pime_amd import gym_control
+    seed, off = 13, 512
+    env = gym_control.make_vec(gym_control.PH_V35, N, device=DEV, state_mode="mixed", seed=seed, env_offset=off)
+    ag = make_agent(algo, env, md)
+    fused = ag.fused_eval_policy(env)
+    assert fused is not None and env.eval_supported(fused[0], trace=True)
+    _no_stepwise(env)
+    T = env.max_step
+    env.reset()
+    ret, tr = env.rollout_eval(fused[0], fused[1], T, want_trace=True)
+    torch.cuda.synchronize()
+    ret, tr = ret.cpu().numpy(), tr.cpu().numpy()      # tr [T, 6, N]: y, r, I before the step | env action, reward, x after
+    ref = oracle.OraclePH(N, oracle.ph_table(), seed=seed, env_offset=off)
+    sd = {k: v.detach().cpu().numpy() for k, v in ag.act.state_dict().items()}
+    priorK = ag._rollout_priorK()
+    obs = ref.reset()
+    want_ret = np.zeros(N)
+    for t in range(T):
+        seen = tr[t, 0:3].T.astype(np.float32)                              # what the policy saw (float32 observation)
+        np.testing.assert_array_equal(seen[:, 0], obs[:, 0].astype(np.float32), err_msg=f"titration cell, step {t}")
+        np.testing.assert_allclose(seen, obs, rtol=2e-5, atol=2e-5, err_msg=f"observation, step {t}")
+        want_act = oracle.residual_action(oracle_mean(algo, seen, sd).astype(np.float32), seen, priorK)
+        np.testing.assert_allclose(tr[t, 3], want_act, rtol=0, atol=3e-5, err_msg=f"policy forward + prior term, step {t}")
+        obs, _, rew, _ = ref.step(tr[t, 3])                                  # the RECORDED env action
+        np.testing.assert_allclose(tr[t, 5], ref.get("x"), rtol=1e-12, err_msg=f"plant state x, step {t}")
+        np.testing.assert_allclose(tr[t, 4], rew, rtol=2e-5, atol=2e-5, err_msg=f"reward, step {t}")
+        want_ret += rew.astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(ret, want_ret, rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(ret, tr[:, 4].sum(0), rtol=1e-12)
+    env.close()
+
+
 def test_evaluator_uses_the_fused_path_and_explore_resets_afterwards():
     """train_and_evaluate's evaluator on the shared vectorised env: evaluation = reset + one launch; the next explore_env must
     start from a fresh reset (the evaluation leaves the lanes mid-episode)."""
@@ -133,3 +175,21 @@ def test_stacking10_width_256_evaluation_is_one_launch():
     np.testing.assert_allclose(got, slow, rtol=1e-4, atol=1e-3)
     for e in envs:
         e.close()
+
+
+def test_step_response_segments_draw_fresh_process_noise():
+    """the fused protocol restarted t at every set-point segment without starting a new episode, so the water tank's
+    process noise -- Philox keyed on (lane, episode, t) -- repeated segment 0's sequence in every segment.  A boundary now counts
+    as the env.reset() it stands for: the fused protocol must equal the step-per-launch protocol (which does reset per segment, i.e.
+    draws episode e + k's noise in segment k) lane by lane, with a process noise 5x the registered one so that a shared sequence
+    would show at once."""
+    from pime_amd import gym_control, protocols
+    N, steps = 64, 40
+    kw = dict(device=DEV, state_mode="f64", seed=3, reward_type="distance", noise_scale=0.05)
+    env = gym_control.make_vec(gym_control.WT_INTEGRATOR, N, **kw)
+    fused = protocols.wt_step_response(env, setpoints=(5.0, 5.0, 5.0), steps=steps)
+    env.close()
+    env = gym_control.make_vec(gym_control.WT_INTEGRATOR, N, **kw)
+    slow = protocols.wt_step_response(env, policy=protocols._prior(env), setpoints=(5.0, 5.0, 5.0), steps=steps)
+    np.testing.assert_allclose(fused["obs"], slow["obs"], rtol=1e-9, atol=1e-9)
+    env.close()

@@ -175,14 +175,15 @@ def test_config2_residual_td3_4096_lanes_replays_through_oracle():
     env.close()
 
 
-def test_fused_offpolicy_explore_matches_lock_step_launches():
+@pytest.mark.parametrize("N", [512, 4608])   # 4 608 lanes: beyond one tile per compute unit -> the 16-lane-tile (non-QUAD) instantiation
+def test_fused_offpolicy_explore_matches_lock_step_launches(N):
     """The one-launch exploration against the lock-step-by-lock-step path it replaces (torch actor, pime_env_step, torch copies
     into the ring; its torch.randn replaced by the noise the kernel drew), two calls so that the episodes continue across them,
     48 slots for 70 lock-steps so that the ring wraps: same transitions to float32 rounding of the policy forward."""
     from pime_amd import gym_control
     from pime_amd.elegantrl.agent_residual import AgentResidualTD3
     from pime_amd.elegantrl.replay import VecReplayBuffer
-    N, steps = 512, 70
+    steps = 70
 
     def run(fused, noise_from=None):
         env = gym_control.make_vec(gym_control.WT_INTEGRATOR, N, device=DEV, state_mode="mixed", seed=6, reward_type="distance",
