@@ -207,6 +207,27 @@ def cpu_baseline():
                                     "the reference cannot travel to the GPU box"}}
 
 
+def grad_roofline(agent, update, D, md, kernel):
+    """`roofline` block of a PPO workload: HIP events around the gradient launches of every minibatch of ONE extra, untimed update
+    (agent.launch_timer; the first such update captures the two-graph step sequence and is discarded), against the f32 matrix peak.
+    Algorithmic flops per sample: forward + input-gradient chain + weight gradients (3x) of both nets, each 2 (D md + 2 md^2 + md)
+    multiply-adds (the modular actor's towers add up to the same count)."""
+    timer = KernelTimer()
+    timer.enabled = True
+    agent.launch_timer = timer.bracket
+    update()
+    timer.pairs.clear()
+    update()
+    torch.cuda.synchronize()
+    agent.launch_timer = None
+    n_g, ms_g = timer.summary()["ppo_minibatch_grad"]
+    flops = 2 * 3 * 2 * (D * md + 2 * md * md + md) * BATCH
+    tf = flops / (ms_g * 1e-3) / 1e12
+    return {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launches_per_step": n_g, "avg_launch_ms": ms_g,
+            "algorithmic_flops_per_launch": flops}
+
+
 def bench_water_tank(args, device, json_fd):
     """BASELINE config 2: water-tank Integrator env, 4096 lanes x 200-step episodes, ResidualIntegratorModularPPO
     net_dim 128, batch 65536, repeat 8 (run_watertank_changing.sh shape scaled to N*T samples)."""
@@ -235,11 +256,15 @@ def bench_water_tank(args, device, json_fd):
     total = sum(step() for _ in range(args.steps))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    roofline = grad_roofline(agent, lambda: agent.update_net(buf, lanes * T, BATCH, REPEAT), env.state_dim, NET_DIM,
+                             "ppo_minibatch_grad = ppo_fused_dual_kernel<4, modular_actor> + ppo_grad_reduce_kernel (one minibatch of "
+                             "65536 water-tank samples, D = 4)")
     out = {"metric": "env-steps/sec (rollout+update), water-tank env, 4096 parallel envs", "value": total / dt,
            "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "water tank Integrator-v2 (reward 'distance'), 4096 lanes x 200-step episodes, "
-                                  "ResidualIntegratorModularPPO net_dim 128, batch 65536, repeat 8"}}
+                                  "ResidualIntegratorModularPPO net_dim 128, batch 65536, repeat 8"},
+           "roofline": roofline}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
@@ -283,11 +308,18 @@ def bench_water_tank_256(args, device, json_fd, modular=False):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         took_hip = bool(agent._packed.get("fused"))
+        roof = None
+        if took_hip:
+            roof = grad_roofline(agent, lambda: agent.update_net(buf, lanes * T, BATCH, REPEAT), env.state_dim, 256,
+                                 ("ppo_minibatch_grad = ppo16_kernel<16, critic> + ppo16m_kernel (modular actor) + ppo_grad_reduce_kernel"
+                                  if modular else
+                                  "ppo_minibatch_grad = ppo16_kernel<16, critic> + ppo16_kernel<16, plain actor> + ppo_grad_reduce_kernel")
+                                 + " (one minibatch of 65536 samples at width 256, streamed 16-tile family)")
         env.close()
-        return total / dt, dt / steps * 1e3, took_hip
-    v, ms, hip = run(True, args.steps, args.warmup)
+        return total / dt, dt / steps * 1e3, took_hip, roof
+    v, ms, hip, roofline = run(True, args.steps, args.warmup)
     assert hip, "width 256 did not take the HIP gradient path"
-    v_t, ms_t, _ = run(False, max(1, args.steps // 2), 1)
+    v_t, ms_t, _, _ = run(False, max(1, args.steps // 2), 1)
     name = "Integrator env, ResidualIntegratorModularPPO" if modular else "Stacking10 env"
     out = {"metric": f"env-steps/sec (rollout+update), water-tank {name}, 4096 parallel envs, net_dim 256", "value": v,
            "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -297,6 +329,7 @@ def bench_water_tank_256(args, device, json_fd, modular=False):
                       if modular else
                                   ("water tank Stacking10-v2 (30-float observation, reward 'distance'), 4096 lanes x 200-step "
                                    "episodes, ResidualPPO net_dim 256 (run_watertank_changing.sh), batch 65536, repeat 8")},
+           "roofline": roofline,
            "torch_update": {"value": v_t, "unit": "env-steps/s", "ms_per_step": ms_t,
                             "what": "same step, update_net on PyTorch-ROCm autograd + rocBLAS (round 1's width-256 path)"}}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -543,6 +576,13 @@ def bench_mixed16(args, device, json_fd, rank, world, dp):
     if dp is not None:
         dt = dp.max_over_ranks(dt)
         total = dp.sum_over_ranks(total)
+    roofline = None
+    if dp is None:   # (the event bracket forces the two-graph step sequence: single-rank runs only)
+        env_w, agent_w, buf_w, _ = stacks[1]
+        roofline = grad_roofline(agent_w, lambda: agent_w.update_net(buf_w, lanes * env_w.max_step, BATCH, REPEAT), env_w.state_dim,
+                                 NET_DIM, "ppo_minibatch_grad = ppo_fused_dual_kernel<4, modular_actor> + ppo_grad_reduce_kernel (one "
+                                 "minibatch of 65536 samples of the water-tank half, widened from the binary16 trajectory; 200 of the "
+                                 "step's 250 optimizer steps)")
     if rank == 0:
         out = {"metric": "env-steps/sec (rollout+update), mixed pH + water-tank batch, fp16 state, 16384 lanes/GPU",
                "value": total / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -552,7 +592,8 @@ def bench_mixed16(args, device, json_fd, rank, world, dp):
                                       "Integrator-v2 lanes (reward 'distance') x 200-step episodes, state_mode mixed16 (binary16 "
                                       "I / observation / reward storage, f32 math, f64 x), ensemble ranges x1.5, "
                                       "ResidualIntegratorModularPPO net_dim 128 per family, batch 65536, repeat 8",
-                          "lanes_per_gpu": LANES, "parallelism": f"dp{world}"}}
+                          "lanes_per_gpu": LANES, "parallelism": f"dp{world}"},
+               "roofline": roofline}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp is not None:
         torch.distributed.destroy_process_group()

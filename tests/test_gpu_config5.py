@@ -108,14 +108,29 @@ def test_config5_mixed16_rank_slice_rollout_and_update():
     assert np.array_equal(I_dev, I_dev.astype(np.float16).astype(np.float64)), "the handle's I must be a binary16 value"
     # the update consumes the binary16 trajectory (widened once) on the fused gradient kernels; identical to an update on a
     # float32 buffer holding the same (widened) rows
+    from pime_amd.elegantrl.replay import TrajectoryBuffer
     for ag, env, buf, n in ((ag_ph, ph, b_ph, 2 * LANES * 50), (ag_wt, wt, b_wt, LANES * 200)):
+        # a float32 TrajectoryBuffer holding the widened rows, and an identical agent (weights, fresh optimizer state) to update on it
+        wide = TrajectoryBuffer(buf.horizon, buf.num_envs, buf.state_dim, buf.action_dim, DEV)
+        wide.state.copy_(buf.state.float()); wide.reward.copy_(buf.reward.float())
+        wide.mask.copy_(buf.mask); wide.action.copy_(buf.action); wide.noise.copy_(buf.noise); wide.done.copy_(buf.done)
+        wide.length = buf.length
+        twin = make_agent(ALGO, env, 128)
+        twin.act.load_state_dict(ag.act.state_dict()); twin.cri.load_state_dict(ag.cri.state_dict())
+        twin.weights_changed()
         w0 = torch.cat([p.detach().reshape(-1) for p in ag.act.parameters()]).clone()
         torch.manual_seed(5)
         oa, oc = ag.update_net(buf, n, 65536, 2)
+        torch.manual_seed(5)
+        oa2, oc2 = twin.update_net(wide, n, 65536, 2)
         torch.cuda.synchronize()
-        assert ag._packed.get("fused"), "update_net did not take the fused HIP gradient path"
-        w1 = torch.cat([p.detach().reshape(-1) for p in ag.act.parameters()])
-        assert np.isfinite(oa) and np.isfinite(oc) and torch.isfinite(w1).all() and not torch.equal(w0, w1)
+        assert ag._packed.get("fused") and twin._packed.get("fused"), "update_net did not take the fused HIP gradient path"
+        w1 = torch.cat([p.detach().reshape(-1) for p in list(ag.act.parameters()) + list(ag.cri.parameters())])
+        w2 = torch.cat([p.detach().reshape(-1) for p in list(twin.act.parameters()) + list(twin.cri.parameters())])
+        assert np.isfinite(oa) and np.isfinite(oc) and torch.isfinite(w1).all()
+        assert not torch.equal(w0, torch.cat([p.detach().reshape(-1) for p in ag.act.parameters()]))
+        assert torch.equal(w1, w2) and (oa, oc) == (oa2, oc2), \
+            "the update from the binary16 buffer must be bit-equal to the update from a float32 buffer holding the widened rows"
     ph.close(); wt.close()
 
 

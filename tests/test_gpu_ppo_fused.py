@@ -255,22 +255,39 @@ def test_fused_rollout_matches_stepwise_rollout(env_name, algo):
     assert f.done[T - 1].all() and f.done[2 * T - 1].all() and not f.done[:T - 1].any()
     np.testing.assert_array_equal(f.state[0].cpu().numpy(), s.state[0].cpu().numpy())
     alive = np.ones(N, dtype=bool)
+    # pH: each path's recorded actions are also replayed through its own OraclePH (as tests/rollout_replay.py does), so that the
+    # episode's LAST step -- whose y is not stored: state[t + 1] is the next episode's first observation -- is held to the oracle's
+    # reward on EVERY lane of BOTH paths instead of to the other path within an allowance
+    refs = None
+    if is_ph:
+        import oracle
+        refs = [oracle.OraclePH(N, oracle.ph_table(), seed=11) for _ in range(2)]
+        for r_ in refs:
+            r_.reset()
+        priorK = ag._rollout_priorK()
     for t in range(2 * T):
         if t == T:
             alive[:] = True   # a new episode starts from the same Philox reset draws on every lane
         fa, sa = f.action[t, :, 0].cpu().numpy(), s.action[t, :, 0].cpu().numpy()
         fs, ss = f.state[t + 1].cpu().numpy(), s.state[t + 1].cpu().numpy()
         np.testing.assert_allclose(fa[alive], sa[alive], rtol=1e-4, atol=1e-5)
+        want_rew = None
+        if is_ph:
+            want_rew = []
+            for buf_, ref_, act_ in ((f, refs[0], fa), (s, refs[1], sa)):
+                env_act = oracle.residual_action(act_, buf_.state[t].cpu().numpy(), priorK)
+                want_rew.append(ref_.step(env_act, auto_reset=True)[2])
         if is_ph:   # a lane whose action differs in the last bit may read the neighbouring titration cell at THIS step: its reward
             dy = np.abs(fs[:, 0] - ss[:, 0])   # and next state differ from here on, so it leaves the comparison before they are checked
             if t not in (T - 1, 2 * T - 1):
                 assert dy[alive].max() <= 0.0297
             alive &= dy <= 1e-5
-        fr, sr = f.reward[t].cpu().numpy()[alive], s.reward[t].cpu().numpy()[alive]
+        fr_all, sr_all = f.reward[t].cpu().numpy(), s.reward[t].cpu().numpy()
+        fr, sr = fr_all[alive], sr_all[alive]
         if is_ph and t in (T - 1, 2 * T - 1):
-            # the episode's last step: state[t + 1] is the reset observation, so a cell flip of this step shows in the reward only
-            off = np.abs(fr - sr) > 3e-4 + 3e-4 * np.abs(sr)
-            assert off.mean() <= 0.005 and np.abs(fr - sr).max() <= 0.5, (off.mean(), np.abs(fr - sr).max())
+            # the episode's last step: every lane of either path against the oracle's reward for that path's own action
+            for got, want in ((fr_all, want_rew[0]), (sr_all, want_rew[1])):
+                np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5, err_msg=f"last-step reward, step {t}")
         else:
             np.testing.assert_allclose(fr, sr, rtol=3e-4, atol=3e-4)
         np.testing.assert_allclose(fs[alive], ss[alive], rtol=1e-4, atol=1e-4)
