@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """usage: tools/kernel_resources.py [out.txt]
 Compiler-reported resources of every kernel in libpime_hip.so (hipcc -Rpass-analysis=kernel-resource-usage, gfx950):
-VGPRs, AGPRs, scratch (spill) bytes per lane, static LDS, SGPRs, occupancy in waves per SIMD.  Needs no GPU."""
+VGPRs, AGPRs, scratch (spill) bytes per lane, static LDS, SGPRs, occupancy in waves per SIMD -- and, from the ISA of the same
+compile (-S), how many scratch / private-memory INSTRUCTIONS and SGPR-spill lane moves the kernel actually contains: a frame can
+be reserved (an SGPR-tuple spill slot the allocator then served from VGPR lanes) without a single access.  Needs no GPU."""
 import os
 import re
 import subprocess
@@ -25,6 +27,17 @@ def main():
             continue
         p = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-c", os.path.join(CSRC, f), "-o", "/dev/null"],
                            capture_output=True, text=True)
+        tmp = f"/tmp/kres_{os.getpid()}_{f}.s"
+        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS[:-1], "--cuda-device-only", "-S", os.path.join(CSRC, f), "-o", tmp],
+                       capture_output=True, text=True)
+        asm = open(tmp).read() if os.path.exists(tmp) else ""
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        isa = {}
+        for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", asm, re.S | re.M):
+            body = m.group(2)
+            isa[m.group(1)] = (len(re.findall(r"^\s+(?:scratch_|buffer_(?:load|store)\S* .*\boff(?:en)?\b)", body, re.M)),
+                               len(re.findall(r"^\s+v_(?:readlane|writelane)_b32", body, re.M)))
         cur, rows = None, []
         for line in p.stderr.splitlines():
             m = re.search(r"remark: .*?Function Name: (\S+)", line)
@@ -40,7 +53,8 @@ def main():
             g = r.get
             lines.append(f"{f}: {demangle(r['name'])[:84]:84s} VGPR {g('VGPRs', '?'):>4} AGPR {g('AGPRs', '?'):>4} "
                          f"scratch {g('ScratchSize [bytes/lane]', '?'):>5} B/lane  static LDS {g('LDS Size [bytes/block]', '?'):>6} B  "
-                         f"SGPR {g('TotalSGPRs', '?'):>4}  spilled VGPRs {g('VGPRs Spill', '?'):>3}  waves/SIMD {g('Occupancy [waves/SIMD]', '?')}")
+                         f"SGPR {g('TotalSGPRs', '?'):>4}  spilled VGPRs {g('VGPRs Spill', '?'):>3}  waves/SIMD {g('Occupancy [waves/SIMD]', '?')}"
+                         f"  ISA: scratch instrs {isa.get(r['name'], ('?', '?'))[0]}, SGPR-spill lane moves {isa.get(r['name'], ('?', '?'))[1]}")
     text = "\n".join(lines) + "\n"
     open(out, "w").write(text)
     sys.stdout.write(text)
