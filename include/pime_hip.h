@@ -357,8 +357,9 @@ int pime_rollout_h(pime_env* env, int32_t kind, int32_t md, const float* packed_
  *   trace        [dev] float64[n_steps, 6, N] or NULL, per step and lane: pH (y, r, I BEFORE the step; action, reward, x after it: the
  *                protocol's per-step records, utils/test.py:1388-1396), water tank (h1, h2, r, I after the step; reward; action)
  * Leaves every lane n_steps further; the caller resets the env before it rolls out again.
- * pime_rollout_eval_supported: 0 = not served; 1 = served; 2 = served for per-lane returns only (width 256, any observation the
- * width-256 rollout serves, PIME_STATE_MIXED: trace and set-point schedule must be NULL / 0). */
+ * pime_rollout_eval_supported: 0 = not served; 1 = served (widths 64 / 128 in either state mode; width 256 -- the streamed rollout
+ * kernel's evaluation mode, csrc/mlp16.hip -- in PIME_STATE_MIXED on the pH / Integrator observation, trace and schedule included);
+ * 2 = returns and trace, but no set-point schedule (a Stacking observation at width 256: seg_len must be 0). */
 int pime_rollout_eval_supported(const pime_env* env, int32_t kind, int32_t md);
 int pime_rollout_eval(pime_env* env, int32_t kind, int32_t md, const float* packed_actor, const double* priorK, int32_t n_steps,
                       int32_t seg_len, const double* setpoints, int32_t n_setpoints, double* ret, double* trace,

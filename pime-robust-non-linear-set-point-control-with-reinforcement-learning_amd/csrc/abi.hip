@@ -819,10 +819,10 @@ int pime_rollout_eval_supported(const pime_env* e, int32_t kind, int32_t md) {
     if (e->cfg.kind != PIME_ENV_PH && e->cfg.num_stack != 0) {   // Stacking: the width-256 kernel only (plain actor, returns only)
         const int S = e->cfg.num_stack;
         return (md == 256 && kind == PIME_MLP_PLAIN_ACTOR && e->cfg.state_mode == PIME_STATE_MIXED && (S == 1 || S == 4 || S == 10)) ? 2 : 0;
-    }
+    }   // (2: returns and trace, no set-point schedule -- the protocols of utils/test.py are written for the Integrator observation)
     if (kind == -1) return 1;                                            // the prior controller alone
     if (kind != PIME_MLP_PLAIN_ACTOR && kind != PIME_MLP_MODULAR_ACTOR) return 0;
-    if (md == 256) return e->cfg.state_mode == PIME_STATE_MIXED ? 2 : 0;   // 2: returns only (no trace, no set-point schedule)
+    if (md == 256) return e->cfg.state_mode == PIME_STATE_MIXED ? 1 : 0;   // the streamed kernel's evaluation mode (float32 state)
     return (md == 64 || md == 128) && !family16(kind, md) ? 1 : 0;
 }
 
@@ -839,9 +839,9 @@ int pime_rollout_eval(pime_env* e, int32_t kind, int32_t md, const float* packed
                  "pime_rollout_eval: the set-point schedule does not cover n_steps (at most %d segments)", kMaxSetpoints);
     if (!e->was_reset) { set_error("pime_rollout_eval before pime_env_reset"); return PIME_ERR_STATE; }
     if (int rc = use_device(e)) return rc;
-    if (md == 256 && kind != -1) {   // the streamed 16-tile rollout kernel in evaluation mode (mlp16.hip): returns only
-        PIME_REQUIRE(trace == nullptr && seg_len == 0 && ret != nullptr, "pime_rollout_eval at width 256 returns per-lane returns only "
-                     "(no trace, no set-point schedule)");
+    if (md == 256 && kind != -1) {   // the streamed 16-tile rollout kernel in evaluation mode (mlp16.hip)
+        PIME_REQUIRE(seg_len == 0 || pime_rollout_eval_supported(e, kind, md) == 1, "pime_rollout_eval: no set-point schedule on a "
+                     "Stacking observation (the protocols are defined on the Integrator observation)");
         RolloutArgs a{};
         a.env = e->cfg.kind == PIME_ENV_PH ? 0 : (e->cfg.num_stack == 0 ? 1 : 2);
         a.n = e->cfg.n_envs;
@@ -851,7 +851,9 @@ int pime_rollout_eval(pime_env* e, int32_t kind, int32_t md, const float* packed
         a.img = packed_actor;
         a.a_std_log = nullptr;                  // not read in evaluation mode (no exploration noise)
         for (int j = 0; j < e->obs_dim; ++j) a.K.k[j] = priorK[j];
-        a.n_steps = n_steps; a.eval_mode = 1; a.ret = ret;
+        a.n_steps = n_steps; a.eval_mode = 1; a.ret = ret; a.trace = trace; a.seg_len = seg_len;
+        if (seg_len > 0)
+            for (int j = 0; j < n_setpoints && j < 16; ++j) a.setpoint[j] = setpoints[j];
         return launch_rollout(kind, md, a, static_cast<hipStream_t>(stream));
     }
     if (e->cfg.state_mode == PIME_STATE_F64)

@@ -1349,6 +1349,19 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
     double ret = 0.0;
     for (int t = 0; t < a.n_steps; ++t) {
         PIME_NO_HOIST();
+        if (evaluating && a.seg_len > 0 && t % a.seg_len == 0) {   // segment boundary of a step-response protocol (wave-uniform), as
+            const float sp = (float)a.setpoint[t / a.seg_len];     // rollout_eval_kernel: new set-point, I = 0, clock 0, next noise episode
+            const int bump = t > 0 ? 1 : 0;
+            if constexpr (ENV == 0) { E.r = sp; E.I = 0.f; E.t = 0; E.episode += bump; obs[1] = sp; obs[2] = 0.f; }
+            else {
+                W.r = sp; W.I = 0.f; W.t = 0; W.episode += bump;
+                if constexpr (ENV == 1) { obs[2] = sp; obs[3] = 0.f; }
+                else {   // Stacking: what a reset leaves -- every frame the current one
+#pragma unroll
+                    for (int f = 0; f < STACK; ++f) { obs[3 * f] = W.h1; obs[3 * f + 1] = W.h2; obs[3 * f + 2] = sp; }
+                }
+            }
+        }
         float a_avg;
         if constexpr (MODULAR) {
             float xo[8], xi[8];
@@ -1417,7 +1430,9 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
         const double a_env = residual_tanh(a_pre) + dot;
         float nxt[D], rew;
         bool d;
+        double tr0 = 0, tr1 = 0, tr2 = 0;
         if constexpr (ENV == 0) {
+            if (a.trace) { tr0 = (double)ph_lookup<float>(a.p, a.st.table, E.C, E.x); tr1 = (double)E.r; tr2 = (double)E.I; }
             float o3[3];
             d = ph_lane_step<float>(a.p, a.st.table, a_env, E, o3, rew);
             if (d && !evaluating) ph_lane_reset<float>(a.p, a.st.table, gid, nullptr, E, o3);     // in-kernel auto-reset
@@ -1437,6 +1452,16 @@ __global__ __launch_bounds__(k16Threads, 1) void rollout16_kernel(RolloutArgs a)
             }
         }
         ret += (double)rew;
+        if (evaluating && a.trace && writer) {   // the evaluation kernel's trace layout (rollout_eval.hip)
+            double* q = a.trace + (size_t)t * 6 * N + i;
+            if constexpr (ENV == 0) {
+                q[0] = tr0; q[(size_t)N] = tr1; q[2 * (size_t)N] = tr2; q[3 * (size_t)N] = a_env; q[4 * (size_t)N] = (double)rew;
+                q[5 * (size_t)N] = E.x;
+            } else {
+                q[0] = (double)W.h1; q[(size_t)N] = (double)W.h2; q[2 * (size_t)N] = (double)W.r; q[3 * (size_t)N] = (double)W.I;
+                q[4 * (size_t)N] = (double)rew; q[5 * (size_t)N] = a_env;
+            }
+        }
         const size_t k = (size_t)t * N + i;
         if (writer && !evaluating) {
             a.action[k] = a_pre;

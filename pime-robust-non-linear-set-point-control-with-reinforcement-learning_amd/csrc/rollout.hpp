@@ -26,5 +26,11 @@ struct RolloutArgs {
     // auto-reset, no trajectory writes; ret[lane] += the launch's sum of rewards (state / action / noise / reward / done unused)
     int eval_mode;
     double* ret;
+    // ... with the evaluation kernel's extras (rollout_eval.hpp): a set-point schedule (every seg_len steps the set-point becomes
+    // setpoint[t / seg_len], the integrated error and the episode clock restart, a new noise episode begins) and a float64 trace
+    // [n_steps][6][N] (pH: y, r, I before the step | env action, reward, x after; tank: h1, h2, r, I after | reward, env action)
+    int seg_len;
+    double setpoint[16];
+    double* trace;
 };
 }  // namespace pime

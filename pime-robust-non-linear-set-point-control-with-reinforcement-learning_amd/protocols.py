@@ -34,9 +34,9 @@ def _fused_policy(env, policy, agent):
     if policy is not None or not hasattr(env, "eval_supported"):
         return None
     if agent is None:
-        return (None, -env.K) if env.eval_supported(None, trace=True) else None
+        return (None, -env.K) if env.eval_supported(None, trace=True, schedule=True) else None
     fused = agent.fused_eval_policy(env) if hasattr(agent, "fused_eval_policy") else None
-    return fused if fused is not None and env.eval_supported(fused[0], trace=True) else None
+    return fused if fused is not None and env.eval_supported(fused[0], trace=True, schedule=True) else None
 
 
 def ph_step_response(env, policy=None, setpoints=PH_SETPOINTS, steps=50, plants=None, agent=None):

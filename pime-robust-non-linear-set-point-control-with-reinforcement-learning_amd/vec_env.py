@@ -385,10 +385,10 @@ class VecControlEnv:
         else:
             self._t_lanes = (self._t_lanes + n_steps) % self.max_step
 
-    def eval_supported(self, packed_actor=None, trace=False):
+    def eval_supported(self, packed_actor=None, trace=False, schedule=False):
         """Does the fused evaluation kernel serve this env (with this packed actor, or the prior controller alone)?
-        (pime_rollout_eval_supported: 1 = everything, 2 = per-lane returns only -- the width-256 kernel: no trace, no set-point
-        schedule; float64 or mixed state, in-kernel draws)"""
+        (pime_rollout_eval_supported: 1 = everything, 2 = returns and trace but no set-point schedule -- a Stacking observation
+        at width 256; float64 or mixed state, in-kernel draws).  `schedule`: the caller wants a set-point schedule."""
         if self.draws.injects:
             return False
         if packed_actor is None:
@@ -398,7 +398,7 @@ class VecControlEnv:
                 return False
             kind = native.MLP_MODULAR_ACTOR if packed_actor.kind == "modular_actor" else native.MLP_PLAIN_ACTOR
             level = self._lib.pime_rollout_eval_supported(self._h, kind, int(packed_actor.md))
-        return level == 1 or (level == 2 and not trace)
+        return level == 1 or (level == 2 and not schedule)
 
     def rollout_eval(self, packed_actor, priorK, n_steps, setpoints=None, seg_len=0, want_trace=False, ret=None):
         """`n_steps` steps of every lane under the deterministic residual policy in ONE launch (csrc/rollout_eval.hip; no

@@ -159,22 +159,59 @@ def test_evaluator_uses_the_fused_path_and_explore_resets_afterwards():
 
 
 def test_stacking10_width_256_evaluation_is_one_launch():
-    """The reference's live water-tank configuration (ResidualPPO, net_dim 256, Stacking10): the evaluator's episode through the
-    width-256 kernel's evaluation mode against the launch-by-launch path."""
+    """The reference's live water-tank configuration (ResidualPPO, net_dim 256, Stacking10; run_watertank_changing.sh:20-27): the
+    evaluator's episode through the width-256 kernel's evaluation mode against the launch-by-launch path, and its TRACE mode
+    (VERDICT r03 task 6): the traced levels / rewards / actions of the same launch against the step-per-launch records."""
     from pime_amd import gym_control
     from pime_amd.elegantrl.run import get_episode_return_vec
     N = 1000
     envs = [gym_control.make_vec(gym_control.WT_STACKING.format(10), N, device=DEV, state_mode="mixed", seed=4, reward_type="distance",
-                                 max_step=60) for _ in range(2)]
+                                 max_step=60) for _ in range(3)]
     ag = make_agent("ResidualPPO", envs[0], 256)
     fused = ag.fused_eval_policy(envs[0])
-    assert fused is not None and not envs[0].eval_supported(fused[0], trace=True)
+    assert fused is not None and envs[0].eval_supported(fused[0], trace=True), "the width-256 evaluation must serve a trace"
+    assert not envs[0].eval_supported(fused[0], trace=True, schedule=True)    # (no protocol schedule on a Stacking observation)
     _no_stepwise(envs[0])
     got = get_episode_return_vec(envs[0], ag.act, fused=fused)
     slow = get_episode_return_vec(envs[1], ag.act)
     np.testing.assert_allclose(got, slow, rtol=1e-4, atol=1e-3)
+    # trace: one launch records (h1, h2, r, I after the step | reward, env action) of every step
+    envs[2].reset()
+    ret, tr = envs[2].rollout_eval(fused[0], fused[1], 60, want_trace=True)
+    torch.cuda.synchronize()
+    tr = tr.cpu().numpy()
+    np.testing.assert_allclose(ret.cpu().numpy(), got, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(tr[:, 4].sum(0), got, rtol=1e-6, atol=1e-4)
+    assert np.isfinite(tr).all() and (tr[:, 0] >= 0).all() and (np.abs(tr[:, 5]) < 5).all()
+    np.testing.assert_allclose(tr[-1, 0], envs[2].get_field("h1"), rtol=1e-6)
+    np.testing.assert_allclose(tr[-1, 1], envs[2].get_field("h2"), rtol=1e-6)
     for e in envs:
         e.close()
+
+
+def test_width_256_step_response_protocol_is_one_launch_and_matches_the_golden_records():
+    """utils/test.py:209-349 (r = 3, 6, 9, 4, 2 x 500 steps, noise 0, the robust_test.py plants) through a WIDTH-256 agent on the
+    Integrator observation -- ResidualIntegratorModularPPO net_dim 256, the commented block of run_watertank_changing.sh:11-18 --
+    whose output layer is zero (agent_residual.py:45-50: the initial policy IS the prior controller): one launch of the streamed
+    kernel's evaluation mode with the set-point schedule and the trace, against the reference's golden protocol records.  The kernel
+    keeps float32 state (PIME_STATE_MIXED): levels to 2e-3 of the 10-unit range over 2 500 steps, actions to 2e-3."""
+    from pime_amd import gym_control, protocols
+    gw = load_golden("wt_stepresponse.npz")
+    env = gym_control.make_vec(gym_control.WT_INTEGRATOR, 2, device=DEV, state_mode="mixed", seed=0, reward_type="distance",
+                               noise_scale=0.0)
+    torch.manual_seed(0)
+    from pime_amd.utils import MODELS
+    ag = MODELS["residualintegratormodularppo"](device=DEV)
+    ag.init(256, env.state_dim, 1, 1)
+    ag.init_residual({"init_K": env.K.reshape(-1, 1)})      # zero output layer: residual 0
+    fused = ag.fused_eval_policy(env)
+    assert fused is not None and fused[0].md == 256 and env.eval_supported(fused[0], trace=True, schedule=True)
+    _no_stepwise(env)
+    res = protocols.wt_step_response(env, steps=500, plants=[gw["robust1_params"][:3], gw["robust3_params"][:3]], agent=ag)
+    for lane, tag in enumerate(("robust1", "robust3")):
+        np.testing.assert_allclose(res["obs"][:, lane, :3], gw[tag + "_obs"][:, :3], rtol=2e-3, atol=2e-2)
+        np.testing.assert_allclose(res["action"][:, lane], gw[tag + "_act"], rtol=0, atol=1e-2)
+    env.close()
 
 
 def test_step_response_segments_draw_fresh_process_noise():
