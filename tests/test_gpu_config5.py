@@ -129,8 +129,9 @@ def test_config5_mixed16_rank_slice_rollout_and_update():
         w2 = torch.cat([p.detach().reshape(-1) for p in list(twin.act.parameters()) + list(twin.cri.parameters())])
         assert np.isfinite(oa) and np.isfinite(oc) and torch.isfinite(w1).all()
         assert not torch.equal(w0, torch.cat([p.detach().reshape(-1) for p in ag.act.parameters()]))
-        assert torch.equal(w1, w2) and (oa, oc) == (oa2, oc2), \
+        assert torch.equal(w1, w2), \
             "the update from the binary16 buffer must be bit-equal to the update from a float32 buffer holding the widened rows"
+        np.testing.assert_allclose([oa, oc], [oa2, oc2], rtol=1e-5)   # (the LOGGED loss sums are float atomics: order-dependent last bits)
     ph.close(); wt.close()
 
 
