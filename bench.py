@@ -150,13 +150,14 @@ def _cpu_model():
 
 
 def cpu_baseline():
-    """The same hot path on the host cores of this box: the C oracle's env restatement (OpenMP over the
-    lanes) + torch-CPU nets driven by the product's own agent code, on a bounded sample: ONE step of the same workload
+    """The same hot path on the host cores of this box: the env on libpime_cpu.so -- the CPU twin of the env entry
+    points, i.e. the product's own lane functions compiled for the host (include/pime_cpu.h), threads over the
+    lanes -- + torch-CPU nets driven by the product's own agent code, on a bounded sample: ONE step of the same workload
     (16 384 lanes x one 50-step episode, batch 65 536, repeat 8 -> 100 optimizer steps) on all cores -> `value`; plus
     env-only points (prior controller + tanh(N(0,1) e^-0.5) residual) at N = 1 / 4 096 / 16 384 with one
     thread and with all cores."""
     import oracle  # noqa: F401  (allowed here: bench.py's cpu_baseline leg)
-    from oracle.cpu_stack import OracleBackend, OracleVecEnv
+    from oracle.cpu_stack import OracleBackend, TwinVecEnv
     from pime_amd.elegantrl.agent_residual import AgentResidualIntegratorModularPPO
     from pime_amd.elegantrl.replay import TrajectoryBuffer
     # the box's CPU share, not the host's core count (oversubscribing torch's intra-op pool stalls for minutes)
@@ -164,7 +165,7 @@ def cpu_baseline():
     torch.set_num_threads(cores)
     oracle.set_threads(cores)
     n = LANES  # the full workload
-    env = OracleVecEnv("ph", n, seed=0)
+    env = TwinVecEnv("ph", n, seed=0, threads=cores)
     torch.manual_seed(0)
     agent = AgentResidualIntegratorModularPPO(backend=OracleBackend(), device="cpu")
     agent.lambda_gae_adv = LAMBDA
@@ -197,10 +198,25 @@ def cpu_baseline():
             if lanes == 1:
                 break   # one lane has nothing to spread over threads
     oracle.set_threads(cores)
+    from oracle.twin import TwinEnv
+    for lanes in (4096, 16384):   # the same sweep on the CPU twin (product arithmetic on the host)
+        for thr in (1, cores):
+            e = TwinEnv("ph", lanes, table=env.table, seed=0, threads=thr)
+            obs = e.reset()
+            episodes = max(1, min(2000, int(4e6 // (lanes * T_EP))))
+            a_pre = (rng.standard_normal((T_EP, lanes)) * np.exp(-0.5)).astype(np.float32)
+            ta = time.perf_counter()
+            for _ in range(episodes):
+                for t in range(T_EP):
+                    obs, _, _ = e.step_residual(a_pre[t], obs, K)
+            tb = time.perf_counter()
+            points.append({"lanes": lanes, "threads": thr, "env": "twin", "env_steps_per_s": episodes * T_EP * lanes / (tb - ta)})
+            e.close()
     return {"value": steps / (t2 - t0), "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
             "nproc": os.cpu_count(),
+            "env": "libpime_cpu.so: the product's lane functions (csrc/env_device.hpp) compiled for the host, float64 state",
             "sample": f"{n} lanes x {T_EP} steps (= {steps} env-steps), batch {n * T_EP * BATCH // (LANES * T_EP)}, "
-                      f"repeat {REPEAT}: C oracle env + torch-CPU policy forward (OpenMP / intra-op {cores} threads) {t1 - t0:.2f}s "
+                      f"repeat {REPEAT}: CPU-twin env + torch-CPU policy forward ({cores} threads) {t1 - t0:.2f}s "
                       f"+ torch-CPU PPO update ({cores} threads) {t2 - t1:.2f}s",
             "env_only_points": points,
             "reference_python_n1": {"value": 316, "unit": "env-steps/s", "where": "build container, 8 threads (BASELINE.md §2); "

@@ -102,3 +102,41 @@ class OracleVecEnv:
         k = -self.K if priorK is None else np.asarray(priorK).reshape(-1)
         a = B.residual_action(a_pre.detach().reshape(-1).numpy(), obs_in.detach().numpy(), k)
         return self._finish(self.core.step(a, auto_reset=auto_reset), out_obs, out_reward, out_done)
+
+
+class _TwinCore:
+    """OraclePH / OracleWT's call shape on top of the CPU twin (oracle/twin.py: libpime_cpu.so)."""
+
+    def __init__(self, tw):
+        self.tw, self.obs_dim = tw, tw.obs_dim
+
+    def reset(self, mask=None):
+        return self.tw.reset(mask=mask)
+
+    def step(self, a, auto_reset=True):
+        obs, rew, done = self.tw.step(a, auto_reset=auto_reset)
+        return obs, None, rew, done
+
+    def get(self, name):
+        return self.tw.get(name)
+
+
+class TwinVecEnv(OracleVecEnv):
+    """OracleVecEnv with the env arithmetic done by libpime_cpu.so -- the product's own lane functions compiled for the host
+    (include/pime_cpu.h) -- instead of the C oracle: what bench.py's cpu_baseline times."""
+
+    def __init__(self, kind, num_envs, seed=0, env_offset=0, table=None, threads=1, **kw):
+        super().__init__(kind, num_envs, seed=seed, env_offset=env_offset, table=table, **kw)
+        from .twin import TwinEnv
+        over = {}
+        if kind != "ph":
+            import pime_amd.native as nt
+            over = dict(reward_type=nt.REWARD[kw.get("reward_type", "square_distance")], max_steps=kw.get("max_steps", 200))
+        self.twin = TwinEnv(kind, num_envs, table=self.table if kind == "ph" else None, seed=seed, env_offset=env_offset,
+                            threads=threads, **over)
+        self.core = _TwinCore(self.twin)
+
+    def step_residual(self, a_pre, obs_in, priorK=None, auto_reset=True, out_obs=None, out_reward=None, out_done=None):
+        k = -self.K if priorK is None else np.asarray(priorK).reshape(-1)
+        obs, rew, done = self.twin.step_residual(a_pre.detach().reshape(-1).numpy(), obs_in.detach().numpy(), k, auto_reset=auto_reset)
+        return self._finish((obs, None, rew, done), out_obs, out_reward, out_done)

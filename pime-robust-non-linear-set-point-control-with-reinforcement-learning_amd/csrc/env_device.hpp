@@ -3,18 +3,20 @@
 // Reference semantics: /root/reference/gym_control/envs/ph.py:320-348 (step), :448-478 (NoBound), :409-445 (reset),
 // :114-121 (ZOH), :187-189 (LUT), gym TimeLimit.
 #pragma once
+// Every lane function is __host__ __device__: the kernels (env_kernels.hip, the fused rollouts) run them on the GPU, and
+// cpu_twins.hip compiles the SAME source for the host into libpime_cpu.so (float64 state), the CPU twin of SURVEY.md section 8(b).
 #include "env_state.hpp"
 
 namespace pime {
 
 template <typename T>
-__device__ __forceinline__ T clip(T v, T lo, T hi) {  // np.clip = minimum(maximum(v, lo), hi)
+__host__ __device__ __forceinline__ T clip(T v, T lo, T hi) {  // np.clip = minimum(maximum(v, lo), hi)
     const T m = v > lo ? v : lo;
     return m < hi ? m : hi;
 }
 
 template <typename S>
-__device__ __forceinline__ S reward_of(int reward_type, S achieved, S goal, S thr) {
+__host__ __device__ __forceinline__ S reward_of(int reward_type, S achieved, S goal, S thr) {
     const S d = fabs(achieved - goal);
     if (reward_type == PIME_REWARD_DISTANCE) return -d;
     if (reward_type == PIME_REWARD_SQUARE) return -(d * d);
@@ -22,9 +24,9 @@ __device__ __forceinline__ S reward_of(int reward_type, S achieved, S goal, S th
 }
 
 template <typename S>
-__device__ __forceinline__ S ph_lookup(const PhParams& p, const S* __restrict__ table, double C, double x) {
+__host__ __device__ __forceinline__ S ph_lookup(const PhParams& p, const S* __restrict__ table, double C, double x) {
     // observe_state (ph.py:187-189): first i with MHCl[i] >= around(C*x, 5)  ==  rint(C*x*1e5)  
-    long long k = __double2ll_rn(C * x * p.table_scale);  // round-half-even like np.around
+    long long k = (long long)rint(C * x * p.table_scale);  // round-half-even like np.around (v_rndne_f64 on the device, rint on the host)
     k = k < 0 ? 0 : (k >= p.table_len ? p.table_len - 1 : k);  // reference: IndexError (unreachable in range)
     return table[k];
 }
@@ -38,7 +40,7 @@ struct PhLane {
 };
 
 template <typename S, typename SI>
-__device__ __forceinline__ void ph_lane_load(const PhParams& p, const PhPtrs<S, SI>& st, int i, PhLane<S>& L) {
+__host__ __device__ __forceinline__ void ph_lane_load(const PhParams& p, const PhPtrs<S, SI>& st, int i, PhLane<S>& L) {
     L.x = st.x[i]; L.A = st.A[i]; L.B = st.B[i]; L.C = st.C[i];
     L.I = (S)st.I[i]; L.r = st.r[i];
     L.t = st.t[i]; L.episode = st.episode[i];
@@ -48,7 +50,7 @@ __device__ __forceinline__ void ph_lane_load(const PhParams& p, const PhPtrs<S, 
 }
 
 template <typename S, typename SI>
-__device__ __forceinline__ void ph_lane_store(const PhParams& p, const PhPtrs<S, SI>& st, int i, const PhLane<S>& L) {
+__host__ __device__ __forceinline__ void ph_lane_store(const PhParams& p, const PhPtrs<S, SI>& st, int i, const PhLane<S>& L) {
     st.x[i] = L.x; st.I[i] = (SI)L.I; st.r[i] = L.r; st.t[i] = L.t; st.episode[i] = L.episode;
     if (p.has_punish) st.last_a[i] = L.last_a;
     if (L.plant_changed) {
@@ -59,7 +61,7 @@ __device__ __forceinline__ void ph_lane_store(const PhParams& p, const PhPtrs<S,
 // reset_all / reset_r (ph.py:412-445).  gid = global lane id (Philox counter word); draws = this lane's 4 injected
 // values (qww_V, qc_V, x0, r) or nullptr for in-kernel Philox.
 template <typename S>
-__device__ __forceinline__ void ph_lane_reset(const PhParams& p, const S* __restrict__ table, uint32_t gid,
+__host__ __device__ __forceinline__ void ph_lane_reset(const PhParams& p, const S* __restrict__ table, uint32_t gid,
                                               const double* __restrict__ draws, PhLane<S>& L, float (&obs)[3]) {
     const int ep = L.episode + 1;
     L.episode = ep;
@@ -94,7 +96,7 @@ __device__ __forceinline__ void ph_lane_reset(const PhParams& p, const S* __rest
 
 // One env step for the (unclipped) env action `a`; no reset.  Returns the TimeLimit done flag.
 template <typename S>
-__device__ __forceinline__ bool ph_lane_step(const PhParams& p, const S* __restrict__ table, double a, PhLane<S>& L,
+__host__ __device__ __forceinline__ bool ph_lane_step(const PhParams& p, const S* __restrict__ table, double a, PhLane<S>& L,
                                              float (&obs)[3], float& reward) {
     a = clip(a, -1.0, 1.0);                                   // ph.py:321
     S delta_u = S(0);
@@ -123,10 +125,10 @@ __device__ __forceinline__ bool ph_lane_step(const PhParams& p, const S* __restr
 // tanh differs between implementations by an ulp (ocml tanhf vs glibc tanhf vs numpy's), which now and then moves C*x*1e5 across
 // a rounding boundary of the titration table; the float64 functions agree to ~1e-16 relative, so their float32 roundings differ
 // with probability ~1e-9 per call and the device, the oracle and numpy's correctly-rounded float32 tanh all read the same cell.
-__device__ __forceinline__ double residual_tanh(float a_pre) { return (double)(float)tanh((double)a_pre); }
+__host__ __device__ __forceinline__ double residual_tanh(float a_pre) { return (double)(float)tanh((double)a_pre); }
 
 // env action of the residual policy: np.tanh(action_f32) + state_f32 @ priorK_f64 (agent_residual.py:61)
-__device__ __forceinline__ double ph_residual_action(float a_pre, const float (&obs_in)[3], const PriorK& K) {
+__host__ __device__ __forceinline__ double ph_residual_action(float a_pre, const float (&obs_in)[3], const PriorK& K) {
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) dot += (double)obs_in[j] * K.k[j];
@@ -145,7 +147,7 @@ struct WtLane {
 };
 
 template <typename S, typename SI>
-__device__ __forceinline__ void wt_lane_load(const WtParams& p, const WtPtrs<S, SI>& st, int i, WtLane<S>& L) {
+__host__ __device__ __forceinline__ void wt_lane_load(const WtParams& p, const WtPtrs<S, SI>& st, int i, WtLane<S>& L) {
     L.h1 = st.h1[i]; L.h2 = st.h2[i]; L.r = st.r[i];
     L.I = p.num_stack == 0 ? (S)st.I[i] : S(0);
     L.a1 = st.a1[i]; L.a2 = st.a2[i]; L.kp = st.kp[i];
@@ -154,7 +156,7 @@ __device__ __forceinline__ void wt_lane_load(const WtParams& p, const WtPtrs<S, 
 }
 
 template <typename S, typename SI>
-__device__ __forceinline__ void wt_lane_store(const WtParams& p, const WtPtrs<S, SI>& st, int i, const WtLane<S>& L) {
+__host__ __device__ __forceinline__ void wt_lane_store(const WtParams& p, const WtPtrs<S, SI>& st, int i, const WtLane<S>& L) {
     st.h1[i] = L.h1; st.h2[i] = L.h2; st.r[i] = L.r; st.t[i] = L.t; st.episode[i] = L.episode;
     if (p.num_stack == 0) st.I[i] = (SI)L.I;
     if (L.plant_changed) { st.a1[i] = L.a1; st.a2[i] = L.a2; st.kp[i] = L.kp; }
@@ -162,7 +164,7 @@ __device__ __forceinline__ void wt_lane_store(const WtParams& p, const WtPtrs<S,
 
 // draws = this lane's 6 injected values (a1, a2, Kp, h1, h2, r) or nullptr for in-kernel Philox
 template <typename S>
-__device__ __forceinline__ void wt_lane_reset(const WtParams& p, uint32_t gid, const double* __restrict__ draws,
+__host__ __device__ __forceinline__ void wt_lane_reset(const WtParams& p, uint32_t gid, const double* __restrict__ draws,
                                               WtLane<S>& L) {
     const int ep = L.episode + 1;
     L.episode = ep;
@@ -193,7 +195,7 @@ __device__ __forceinline__ void wt_lane_reset(const WtParams& p, uint32_t gid, c
 
 // the two process-noise normals of step L.t+1 (already scaled): injected pair or Philox Box-Muller (:271-272,:810-811)
 template <typename S>
-__device__ __forceinline__ void wt_lane_noise(const WtParams& p, uint32_t gid, const WtLane<S>& L,
+__host__ __device__ __forceinline__ void wt_lane_noise(const WtParams& p, uint32_t gid, const WtLane<S>& L,
                                               const double* __restrict__ noise, double& z1n, double& z2n) {
     if (noise) {
         z1n = noise[0]; z2n = noise[1];
@@ -224,14 +226,14 @@ __device__ __forceinline__ void wt_lane_noise(const WtParams& p, uint32_t gid, c
 // ~10-instruction Newton / scale fix-up -- 40 of them per env step made the kernel VALU-bound at 0.32 of HBM (profiles/
 // r02_m_env_pmc.json).  One ulp of a root is a 6e-8 relative perturbation of a smooth map, inside the mode's stated 2e-4.
 template <typename S>
-__device__ __forceinline__ S tank_sqrt(S v) {
+__host__ __device__ __forceinline__ S tank_sqrt(S v) {
     if constexpr (sizeof(S) == 4) return __builtin_amdgcn_sqrtf(v);
     else return sqrt(v);
 }
 
 // One env step for env action `a` (NOT clipped, :258-260); returns done (:816-821)
 template <typename S>
-__device__ __forceinline__ bool wt_lane_step(const WtParams& p, double a, double z1n, double z2n, WtLane<S>& L,
+__host__ __device__ __forceinline__ bool wt_lane_step(const WtParams& p, double a, double z1n, double z2n, WtLane<S>& L,
                                              float& reward) {
     L.t += 1;                                                           // :801
     const S u = (S)(a * p.pmax / 2. + p.pmax / 2.);                     // action_P
