@@ -14,3 +14,7 @@ done
 timeout -k 10 300 bash tools/profile_bench.sh $TAG || exit 1
 timeout -k 10 400 bash tools/pmc_traffic.sh $OUT/${TAG}_pmc_hbm_traffic.json bench.py --steps 2 --warmup 1 --no-cpu-baseline || exit 1
 timeout -k 10 400 bash tools/env_pmc.sh $OUT/${TAG}_env_pmc.json || exit 1
+# the TD3 step's kernels (BASELINE config 2): per-kernel stats and HBM traffic of the same bench command
+timeout -k 10 300 bash tools/profile_bench.sh ${TAG}_td3 --workload wt_td3 || exit 1
+timeout -k 10 400 bash tools/pmc_traffic.sh $OUT/${TAG}_td3_hbm_traffic_pmc.json bench.py --workload wt_td3 --steps 2 --warmup 1 --no-cpu-baseline || exit 1
+timeout -k 10 300 bash tools/profile_bench.sh ${TAG}_wt256 --workload wt256 || exit 1
