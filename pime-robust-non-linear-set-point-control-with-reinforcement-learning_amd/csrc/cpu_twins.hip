@@ -7,7 +7,10 @@
 // reference's precision (float64 state, PIME_STATE_F64 semantics).  replaces, per lane: PH1D...Integrator.step / reset
 // (/root/reference/gym_control/envs/ph.py:320-348,409-445) and NonLinearWaterTank...Integrator.step / reset
 // (nonlinear_watertank.py:800-826,890-939), as pime_env_step / pime_env_reset do on the GPU.
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -41,18 +44,67 @@ struct pime_env_cpu {
 };
 
 namespace {
-// lanes [lo, hi) per thread, contiguous; results do not depend on the thread count (lanes are independent)
+// lanes [lo, hi) per thread, contiguous chunks, on a persistent pool (a fork-join of std::threads per call cost more than a
+// 16 384-lane step); results do not depend on the thread count (lanes are independent)
+class Pool {
+  public:
+    void run(int threads, const std::function<void(int)>& job) {   // job(t) for t in [0, threads); returns when all are done
+        std::unique_lock<std::mutex> lk(mu_);
+        while ((int)workers_.size() < threads - 1) {
+            const int id = (int)workers_.size();
+            workers_.emplace_back([this, id] { loop(id); });
+        }
+        job_ = &job; active_ = threads - 1; pending_ = threads - 1; ++gen_;
+        lk.unlock();
+        cv_.notify_all();
+        job(threads - 1);   // the caller takes the last chunk
+        lk.lock();
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+
+  private:
+    void loop(int id) {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (stop_) return;
+            if (id >= active_) continue;
+            const std::function<void(int)>* job = job_;
+            lk.unlock();
+            (*job)(id);
+            lk.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)>* job_ = nullptr;
+    unsigned long long gen_ = 0;
+    int active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+Pool g_pool;
+std::mutex g_pool_user;   // one parallel region at a time
+
 template <class F>
 void for_lanes(int n, int threads, F&& body) {
-    if (threads <= 1 || n < 2 * threads) { body(0, n); return; }
-    std::vector<std::thread> pool;
+    if (threads > 64) threads = 64;
+    if (threads <= 1 || n < 64 * threads) { body(0, n); return; }
     const int per = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; ++t) {
+    std::lock_guard<std::mutex> user(g_pool_user);
+    g_pool.run(threads, [&](int t) {
         const int lo = t * per, hi = lo + per < n ? lo + per : n;
-        if (lo >= hi) break;
-        pool.emplace_back([&body, lo, hi] { body(lo, hi); });
-    }
-    for (auto& th : pool) th.join();
+        if (lo < hi) body(lo, hi);
+    });
 }
 }  // namespace
 
