@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 16
+#define PIME_ABI_VERSION 17
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -427,10 +427,14 @@ int pime_td3_supported(int32_t D, int32_t action_dim, int32_t md);
 int64_t pime_td3_param_floats(int32_t which, int32_t D, int32_t md);
 int pime_td3_param_offsets(int32_t which, int32_t D, int32_t md, int32_t* offsets);
 int64_t pime_td3_workspace_floats(int32_t D, int32_t md, int32_t B);
-/* soft_mode: 0 no soft target update, 1 soft update, 2 soft update when cursor[0] % update_freq == 0 (the reference's delayed update).
- * phases: bit 0 = critic half (gradients, Adam, soft update), bit 1 = actor half; 3 = the whole step (the cursor advances with bit 1).
- *         The actor half reads the minibatch's state rows as the critic half of the SAME table row left them in the workspace: run
- *         bit 1 alone only behind a bit-0 call on that row.
+/* soft_mode: 0 no soft target update, 1 soft update, 2 soft update when row % update_freq == 0 (the reference's delayed update).
+ * phases: bit 0 = critic gradients, bit 1 = critic apply (slab reduction, Adam, soft update), bit 2 = actor gradients, bit 3 = actor
+ *         apply; 15 = the whole step on one stream.  The four launches may also be issued on TWO streams, the data dependencies
+ *         being: actor gradients(row) read the state rows the critic gradients(row) gathered (kept per row parity in the workspace)
+ *         and, on a soft row, the critic target the critic apply(row) wrote; critic gradients(row + 1) read the critic the critic
+ *         apply(row) wrote and, behind a soft row, the actor target the actor apply(row) wrote.  So on rows without a soft update
+ *         the critic apply may run beside the actor gradients, and the actor apply beside the next row's critic gradients
+ *         (AgentTD3._update_fused does that: parallel branches of the update's HIP graph).
  * loss [dev] float32[4] or NULL: [0] += obj_actor, [1] += obj_critic of this step (zero them per update), [2], [3] = this step's values.
  * workspace [dev] float32[pime_td3_workspace_floats]. */
 int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_td3_net* critic, const pime_td3_batch* batch,

@@ -1201,13 +1201,15 @@ int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_t
     PIME_REQUIRE(soft_mode >= 0 && soft_mode <= 2 && (soft_mode != 2 || update_freq >= 1), "pime_td3_step: soft_mode %d / update_freq %d", soft_mode, update_freq);
     PIME_REQUIRE(b->row >= 0, "pime_td3_step: table row %lld", (long long)b->row);
     const int soft = soft_mode == 1 || (soft_mode == 2 && b->row % update_freq == 0);
-    PIME_REQUIRE(phases >= 1 && phases <= 3, "pime_td3_step: phases %d", phases);
+    PIME_REQUIRE(phases >= 1 && phases <= 15, "pime_td3_step: phases %d", phases);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = td3_grid(b->B), ngroups = (b->B + 15) / 16;
     const Td3SlabLayout LA = td3_actor_slab(D, md), LC = td3_critic_slab(D, md);
     float* const slab_c = workspace;
     float* const slab_a = workspace + (size_t)grid * LC.stride;
-    float* const xg = slab_a + (size_t)grid * LA.stride;   // [B][8] gathered rows: written by the critic launch, read by the actor launch
+    // [2][B][8] gathered rows, by row parity: written by the critic launch of a row, read by its actor launch -- which may still run
+    // while the critic launch of the NEXT row (other parity) gathers (the caller's two-stream schedule, see include/pime_hip.h)
+    float* const xg = slab_a + (size_t)grid * LA.stride + (size_t)(b->row & 1) * b->B * 8;
     Td3Batch tb{b->state, b->other, b->idx, b->nxt, b->noise, (long long)b->row, b->epoch, b->B, b->noise_seed, b->noise_epoch, b->policy_noise, b->noise_clip};
     auto apply = [&](const pime_td3_net* n, const Td3SlabLayout& L, const float* slab, int slot) {
         Td3ApplyArgs a{};
@@ -1225,13 +1227,15 @@ int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_t
     if (phases & 1) {
         Td3GradArgs g{tb, D, actor->target, critic->param, critic->target, slab_c, xg, LC.stride, ngroups, tracing ? trace_dev : nullptr};
         if (int rc = launch_td3_grad(true, md, g, grid, s)) return rc;
-        if (int rc = apply(critic, LC, slab_c, 1)) return rc;
     }
-    if (phases & 2) {
+    if (phases & 2)
+        if (int rc = apply(critic, LC, slab_c, 1)) return rc;
+    if (phases & 4) {
         Td3GradArgs g{tb, D, actor->param, critic->target, nullptr, slab_a, xg, LA.stride, ngroups, tracing ? trace_dev + 32 : nullptr};
         if (int rc = launch_td3_grad(false, md, g, grid, s)) return rc;
-        if (int rc = apply(actor, LA, slab_a, 0)) return rc;
     }
+    if (phases & 8)
+        if (int rc = apply(actor, LA, slab_a, 0)) return rc;
     if (tracing) {
         long long t[64];
         PIME_HIP_TRY(hipStreamSynchronize(s));

@@ -834,7 +834,7 @@ int td3_grid(int B) {
 }
 int64_t td3_workspace_floats(int D, int md, int B) {
     const int64_t g = td3_grid(B);
-    return g * (td3_actor_slab(D, md).stride + td3_critic_slab(D, md).stride) + (int64_t)B * 8;   // slabs + the gathered rows [B][8]
+    return g * (td3_actor_slab(D, md).stride + td3_critic_slab(D, md).stride) + (int64_t)2 * B * 8;   // slabs + the gathered rows [2][B][8] (by row parity)
 }
 bool td3_supported(int D, int A, int md) { return A == 1 && D >= 1 && D <= kTd3MaxD && (md == 64 || md == 128); }
 

@@ -711,6 +711,7 @@ class AgentTD3(AgentBase):
         # per bench step.  PIME_TD3_FUSED_TARGETS=1 switches it on (parity: tests/test_gpu_td3.py).
         self.use_fused_targets = os.environ.get("PIME_TD3_FUSED_TARGETS", "0") == "1"
         self.use_fused_update = os.environ.get("PIME_TD3_FUSED", "1") == "1"   # the optimizer step on the hand-written kernels
+        self.use_two_streams = os.environ.get("PIME_TD3_TWO_STREAMS", "1") == "1"   # critic / actor chains as parallel graph branches
         self.draw_hook = None      # tests: callable(n_steps, batch) -> (idx, nxt, noise) tables of a whole update (injected draws)
         self.launch_timer = None   # bench.py: callable(name, fn) timing one update's launches with HIP events
         self._fused_td3 = None
@@ -981,13 +982,44 @@ class AgentTD3(AgentBase):
         f.loss.zero_()
         f.begin_update()   # table row 0; the noise epoch advances (a captured graph draws fresh noise in every replay)
 
+        side = st.get("side")
+        if side is None and self.use_two_streams:
+            side = st["side"] = torch.cuda.Stream(device=dev)
+
+        def one(k, phases):   # the row is a launch argument: every node of the captured graph carries its own
+            f.step(buffer.buf_state, buffer.buf_other, idx, nxt, noise, self.soft_update_tau, self.update_freq, self.policy_noise,
+                   noise_seed=self._smooth_seed, row=k, phases=phases)
+
         def run():
-            for k in range(n_steps):   # the row is a launch argument: every node of the captured graph carries its own
-                f.step(buffer.buf_state, buffer.buf_other, idx, nxt, noise, self.soft_update_tau, self.update_freq, self.policy_noise,
-                       noise_seed=self._smooth_seed, row=k)
+            """The critic chain (gradients, apply) on the current stream, the actor chain on a side stream.  Only rows with the
+            delayed soft update tie the two completely: the actor's gradients read the critic TARGET (written by the critic's apply
+            on soft rows only) and the state rows its critic launch gathered; the next row's critic gradients read the actor TARGET
+            (written by the actor's apply on soft rows only).  On the other rows the critic's apply runs beside the actor's
+            gradients and the actor's apply beside the next row's critic gradients -- inside the captured graph these are parallel
+            branches.  Same arithmetic, same bits as the one-stream order (tests/test_gpu_td3_fused.py)."""
+            if side is None:
+                for k in range(n_steps):
+                    one(k, 15)
+                return
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            for k in range(n_steps):
+                soft = k % self.update_freq == 0
+                one(k, 1)                       # critic gradients (gathers the row's states)
+                if soft:
+                    one(k, 2)                   # critic apply writes the critic target: the actor's gradients must see it
+                    side.wait_stream(main)
+                else:
+                    side.wait_stream(main)      # the actor's gradients need the gathered rows only
+                    one(k, 2)
+                with torch.cuda.stream(side):
+                    one(k, 4)
+                    one(k, 8)
+                if soft or k == n_steps - 1:
+                    main.wait_stream(side)      # the next critic gradients read the actor target this row's actor apply wrote
 
         key = (buffer.buf_state.data_ptr(), buffer.buf_other.data_ptr(), noise is None, self.soft_update_tau, self.update_freq,
-               self.policy_noise)
+               self.policy_noise, side is not None)
         if self.use_hip_graphs and st["warm"] and (st["graph"] is None or st["key"] != key):
             try:
                 torch.cuda.synchronize(dev)

@@ -488,10 +488,11 @@ class FusedTD3:
                                      lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
 
     def step(self, buf_state, buf_other, idx, nxt, noise, tau, update_freq, policy_noise, noise_clip=0.5, noise_seed=0,
-             noise_epoch=0, soft_mode=2, phases=3, row=None):
+             noise_epoch=0, soft_mode=2, phases=15, row=None):
         """One optimizer step on table row `row` (default: self.row, which then advances) of idx / nxt (int64 [rows, B]) and noise
         (float32 [rows, B] or None: Philox in the kernel).  The row is a launch argument: a captured graph of an update's steps
-        bakes each step's row into its nodes."""
+        bakes each step's row into its nodes.  phases: bit 0 critic gradients, 1 critic apply, 2 actor gradients, 3 actor apply
+        (include/pime_hip.h: what may run beside what)."""
         _need_cuda(buf_state, buf_other, idx, nxt)
         B = idx.shape[-1]
         advance = row is None
@@ -510,5 +511,5 @@ class FusedTD3:
                                                     C.c_float(tau), int(update_freq), int(soft_mode), int(phases),
                                                     native.ptr(self.workspace), native.ptr(self.loss), _stream(buf_state)),
                          "pime_td3_step")
-        if advance and phases & 2:
+        if advance and phases & 8:
             self.row += 1
