@@ -711,7 +711,9 @@ class AgentTD3(AgentBase):
         # per bench step.  PIME_TD3_FUSED_TARGETS=1 switches it on (parity: tests/test_gpu_td3.py).
         self.use_fused_targets = os.environ.get("PIME_TD3_FUSED_TARGETS", "0") == "1"
         self.use_fused_update = os.environ.get("PIME_TD3_FUSED", "1") == "1"   # the optimizer step on the hand-written kernels
-        self.use_two_streams = os.environ.get("PIME_TD3_TWO_STREAMS", "1") == "1"   # critic / actor chains as parallel graph branches
+        # critic / actor chains as parallel graph branches (rows without a soft update): bit-identical, measured NEUTRAL (58.1 vs 58.4 M:
+        # each launch already fills the chip, overlapped launches only stretch each other -- DESIGN.md section 4c), so off by default
+        self.use_two_streams = os.environ.get("PIME_TD3_TWO_STREAMS", "0") == "1"
         self.draw_hook = None      # tests: callable(n_steps, batch) -> (idx, nxt, noise) tables of a whole update (injected draws)
         self.launch_timer = None   # bench.py: callable(name, fn) timing one update's launches with HIP events
         self._fused_td3 = None
