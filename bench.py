@@ -223,6 +223,21 @@ def cpu_baseline():
                                     "the reference cannot travel to the GPU box"}}
 
 
+def emit(json_fd, out):
+    """The ONE JSON line.  Opt-in kernel variants (environment switches read by libpime_hip.so) are named in it."""
+    variants = []
+    if os.environ.get("PIME_MLP16"):
+        variants.append("PIME_MLP16=1: widths 64 / 128 on the streamed 16-tile kernel family")
+    if os.environ.get("PIME_GRAD_BF16X3", "0") not in ("", "0"):
+        variants.append("PIME_GRAD_BF16X3=1: the streamed layers of the 16-tile gradient kernels (widths 128 / 256) as six "
+                        "v_mfma_f32_16x16x32_bf16 per product block, every f32 operand split into three bf16 pieces (f32-level "
+                        "error; roofline.achieved stays f32-equivalent flops against the f32 matrix peak)")
+        out["dtype"] = "f32 (bf16x3 matrix products in the streamed gradient layers)"
+    if variants:
+        out.setdefault("config", {})["variant"] = "; ".join(variants)
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
 def grad_roofline(agent, update, D, md, kernel):
     """`roofline` block of a PPO workload: HIP events around the gradient launches of every minibatch of ONE extra, untimed update
     (agent.launch_timer; the first such update captures the two-graph step sequence and is discarded), against the f32 matrix peak.
@@ -281,7 +296,7 @@ def bench_water_tank(args, device, json_fd):
            "config": {"workload": "water tank Integrator-v2 (reward 'distance'), 4096 lanes x 200-step episodes, "
                                   "ResidualIntegratorModularPPO net_dim 128, batch 65536, repeat 8"},
            "roofline": roofline}
-    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    emit(json_fd, out)
 
 
 def bench_water_tank_256(args, device, json_fd, modular=False):
@@ -348,7 +363,7 @@ def bench_water_tank_256(args, device, json_fd, modular=False):
            "roofline": roofline,
            "torch_update": {"value": v_t, "unit": "env-steps/s", "ms_per_step": ms_t,
                             "what": "same step, update_net on PyTorch-ROCm autograd + rocBLAS (round 1's width-256 path)"}}
-    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    emit(json_fd, out)
 
 
 def spawn_ranks(n, argv):
@@ -527,7 +542,7 @@ def bench_water_tank_td3(args, device, json_fd):
            "config": {"workload": "water tank Integrator-v2 (reward 'distance'), 4096 lanes x 200 lock-steps, AgentResidualTD3 "
                                   "net_dim 128, 200 optimizer steps of batch 4096 per step (one HIP graph per update)"},
            "roofline": roofline}
-    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    emit(json_fd, out)
 
 
 def bench_mixed16(args, device, json_fd, rank, world, dp):
@@ -610,7 +625,7 @@ def bench_mixed16(args, device, json_fd, rank, world, dp):
                                       "ResidualIntegratorModularPPO net_dim 128 per family, batch 65536, repeat 8",
                           "lanes_per_gpu": LANES, "parallelism": f"dp{world}"},
                "roofline": roofline}
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(json_fd, out)
     if dp is not None:
         torch.distributed.destroy_process_group()
 
@@ -804,7 +819,7 @@ def main():
         log("cpu baseline (oracle env + torch CPU update) ...")
         out["cpu_baseline"] = cpu_baseline()
         log("cpu baseline done")
-    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    emit(json_fd, out)
     if dp is not None:
         torch.distributed.destroy_process_group()
 

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 17
+#define PIME_ABI_VERSION 18
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -266,6 +266,14 @@ typedef struct pime_ppo_batch {
  * LDS-resident gradient kernel (the stacked water tank, 30 floats) take the streamed 16-tile family here. */
 int64_t pime_ppo_fwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t md);
 int64_t pime_ppo_bwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t md);
+/* The leading part of img_bwd that is a permutation of the parameters (what pime_ppo_image_map covers).  Equal to
+ * pime_ppo_bwd_image_floats unless the process runs with PIME_GRAD_BF16X3=1 (opt-in; widths 128 / 256 on the 16-tile family --
+ * PIME_MLP16=1 routes width 128 there): the streamed layers of the gradient kernels then run on bf16 matrix instructions with every
+ * f32 operand split into hi + mid + lo bf16 pieces (six v_mfma_f32_16x16x32_bf16 per product block; error at the f32 rounding level,
+ * not bit-equal to the f32 MFMA chain), and the three bf16 planes of those layers' weights follow the f32 image.  The library
+ * re-splits them itself after every optimizer step it applies (pime_ppo_minibatch_step, pime_adam_step_images / _dp) and in
+ * pime_ppo_repack / pime_ppo_pack_bwd. */
+int64_t pime_ppo_bwd_image_f32_floats(int32_t kind, int32_t D, int32_t Di, int32_t md);
 int64_t pime_ppo_workspace_floats(int32_t kind, int32_t B, int32_t md);
 int pime_ppo_pack_bwd(int32_t kind, int32_t D, int32_t Di, int32_t md, const float* const* params, float* image,
                       pime_stream stream);

@@ -109,6 +109,9 @@ bool family16_grad(int, int, int, int);
 int64_t ppo_fwd_image_floats(int, int, int, int);
 int grid16(int, int, int, int, int);
 int launch_pack16(const PackArgs&, float*, float*, hipStream_t);
+int launch_pack16_b3(const PackArgs&, float*, hipStream_t);
+bool b3_grad(int, int, int, int);
+int64_t ppo_bwd_image_f32_floats(int, int, int, int);
 int launch_ppo16(int, int, const PpoArgs&, hipStream_t);
 int build_dw_jobs(int, int, const PpoArgs&, const float* const*, float* const*, DwJob*);
 int launch_dw(const DwArgs&, int, hipStream_t);
@@ -657,6 +660,10 @@ int64_t pime_ppo_bwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t m
     if (mlp_check(kind, D, Di, md) != PIME_OK) return 0;
     return ppo_bwd_image_floats(kind, D, Di, md);
 }
+int64_t pime_ppo_bwd_image_f32_floats(int32_t kind, int32_t D, int32_t Di, int32_t md) {
+    if (mlp_check(kind, D, Di, md) != PIME_OK) return 0;
+    return ppo_bwd_image_f32_floats(kind, D, Di, md);
+}
 
 int64_t pime_ppo_fwd_image_floats(int32_t kind, int32_t D, int32_t Di, int32_t md) {
     if (mlp_check(kind, D, Di, md) != PIME_OK) return 0;
@@ -832,6 +839,22 @@ static int check_net(const pime_ppo_net* n, bool actor) {
     return PIME_OK;
 }
 
+// PIME_GRAD_BF16X3=1: the bf16x3 planes of the nets that use them, re-split from the parameters (after an optimizer step whose image
+// map kept the f32 images current; pime_ppo_repack does it as part of launch_pack16).
+static int refresh_b3(const pime_ppo_net* actor, const pime_ppo_net* critic, hipStream_t s) {
+    const pime_ppo_net* nets[2] = {critic, actor};
+    for (int k = 0; k < 2; ++k) {
+        const pime_ppo_net* n = nets[k];
+        if (!b3_grad(n->kind, n->md, n->D, n->Di)) continue;
+        PackArgs pa{};
+        const int np = n->kind == PIME_MLP_MODULAR_ACTOR ? 12 : 8;
+        for (int i = 0; i < np; ++i) pa.p[i] = n->params[i];
+        pa.kind = n->kind; pa.D = n->D; pa.Di = n->Di; pa.md = n->md;
+        if (int rc = launch_pack16_b3(pa, const_cast<float*>(n->img_bwd), s)) return rc;
+    }
+    return PIME_OK;
+}
+
 int pime_ppo_repack(const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream) {
     if (int rc = check_net(actor, true)) return rc;
     if (int rc = check_net(critic, false)) return rc;
@@ -934,11 +957,12 @@ int pime_ppo_image_map(const pime_ppo_net* actor, const pime_ppo_net* critic, co
     for (int k = 0; k < 2; ++k) {
         const pime_ppo_net* nk = nets[k];
         floats[k][0] = ppo_fwd_image_floats(nk->kind, nk->D, nk->Di, nk->md);
-        floats[k][1] = pime_ppo_bwd_image_floats(nk->kind, nk->D, nk->Di, nk->md);
+        floats[k][1] = ppo_bwd_image_f32_floats(nk->kind, nk->D, nk->Di, nk->md);   // the map covers the f32 images (bf16x3 planes behind
+        const int64_t alloc[2] = {floats[k][0], pime_ppo_bwd_image_floats(nk->kind, nk->D, nk->Di, nk->md)};   // them are re-split per step)
         for (int w = 0; w < 2; ++w)
-            if (floats[k][w] <= 0 || hipMalloc(&scratch[k][w], sizeof(float) * (size_t)floats[k][w]) != hipSuccess ||
-                hipMemsetAsync(scratch[k][w], 0, sizeof(float) * (size_t)floats[k][w], s) != hipSuccess)   // padding the pack kernels
-                return cleanup(PIME_ERR_DEVICE);                                                        // never write must read 0
+            if (floats[k][w] <= 0 || hipMalloc(&scratch[k][w], sizeof(float) * (size_t)alloc[w]) != hipSuccess ||
+                hipMemsetAsync(scratch[k][w], 0, sizeof(float) * (size_t)alloc[w], s) != hipSuccess)   // padding the pack kernels
+                return cleanup(PIME_ERR_DEVICE);                                                    // never write must read 0
         coded[k] = *nk;
         coded[k].params = fake[k];
         coded[k].img_fwd = scratch[k][0];
@@ -965,8 +989,10 @@ int pime_adam_step_images(const pime_adam* opt, const pime_ppo_net* actor, const
                  "pime_adam_step_images: bad pime_adam (image_map must be set: pime_ppo_image_map)");
     float* const img[2][2] = {{const_cast<float*>(critic->img_fwd), const_cast<float*>(critic->img_bwd)},
                               {const_cast<float*>(actor->img_fwd), const_cast<float*>(actor->img_bwd)}};
-    return launch_adam(opt->param, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n, opt->lr, opt->beta1, opt->beta2, opt->eps,
-                       opt->step, opt->image_map, img, nullptr, 0, 1, static_cast<hipStream_t>(stream));
+    if (int rc = launch_adam(opt->param, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n, opt->lr, opt->beta1, opt->beta2, opt->eps,
+                             opt->step, opt->image_map, img, nullptr, 0, 1, static_cast<hipStream_t>(stream)))
+        return rc;
+    return refresh_b3(actor, critic, static_cast<hipStream_t>(stream));
 }
 
 int pime_adam_step_dp(const pime_adam* opt, const pime_ppo_net* actor, const pime_ppo_net* critic, pime_stream stream) {
@@ -980,9 +1006,11 @@ int pime_adam_step_dp(const pime_adam* opt, const pime_ppo_net* actor, const pim
         img[0][0] = const_cast<float*>(critic->img_fwd); img[0][1] = const_cast<float*>(critic->img_bwd);
         img[1][0] = const_cast<float*>(actor->img_fwd); img[1][1] = const_cast<float*>(actor->img_bwd);
     }
-    return launch_adam(opt->param, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n, opt->lr, opt->beta1, opt->beta2, opt->eps,
-                       opt->step, opt->image_map, img, opt->dp_moments, (long long)opt->critic_offset, opt->dp_world,
-                       static_cast<hipStream_t>(stream));
+    if (int rc = launch_adam(opt->param, opt->grad, opt->exp_avg, opt->exp_avg_sq, opt->n, opt->lr, opt->beta1, opt->beta2, opt->eps,
+                             opt->step, opt->image_map, img, opt->dp_moments, (long long)opt->critic_offset, opt->dp_world,
+                             static_cast<hipStream_t>(stream)))
+        return rc;
+    return opt->image_map ? refresh_b3(actor, critic, static_cast<hipStream_t>(stream)) : PIME_OK;
 }
 
 static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic, const pime_ppo_batch* b, float ratio_clip,
@@ -1131,6 +1159,8 @@ static int minibatch_impl(const pime_ppo_net* actor, const pime_ppo_net* critic,
                                         b->flags & PIME_PPO_OVERWRITE_GRADS, mode[0] != SPLIT ? b->index_row : nullptr,
                                         opt ? &adam : nullptr, b->dp_moments, s))
             return rc;
+        if (opt && opt->image_map)   // (without a map the caller re-packs: pime_ppo_repack splits the planes too)
+            if (int rc = refresh_b3(actor, critic, s)) return rc;
     }
     if (mode[0] == SPLIT)   // scales the split critic's gradients, advances the index-table row
         return launch_critic_scale(critic->D, critic->md, critic->grads, moments, b->B, critic_scale, loss_sums + 3,

@@ -159,11 +159,9 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
 template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else static_assert(N == 0, "add the count");
+__device__ __forceinline__ void wait_vmcnt() {   // all but the N youngest vector-memory operations of this wave are done
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int TK, int TO, int ACT, bool HAS_BIAS>
@@ -240,6 +238,196 @@ __device__ __forceinline__ void layer16r(const float* __restrict__ gimg, const f
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[t][r] = act16<ACT>(out[t][r]);
+}
+
+// ---- the same chain layer on bf16 matrix instructions: every f32 operand as hi + mid + lo ("bf16x3", opt-in) ---------------------
+// v_mfma_f32_16x16x32_bf16 runs at 16x the f32 MFMA rate; a product of two f32 values split into three bf16 pieces each is, to
+// f32 rounding, hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid): six bf16 MFMAs (accumulated in f32, smallest terms first)
+// for what eight 16x16x4 f32 MFMAs compute -- 96 against 256 pipe cycles.  The dropped terms are below 2^-24 of the product
+// (tools/bf16x3_layer_bench.hip: error against float64 3.1e-7 of max |y|, the f32 chain's own is 5.1e-7).
+//   * weights: split once per optimizer step into three bf16 planes (pack16_b3_layer), image [slice][tile][plane][lane][8]:
+//     element e of lane (i, g), k-step ks is W[16 to + i][16 (2 ks + (e >> 2)) + 4 g + (e & 3)] -- a k-step covers the input tiles
+//     2 ks and 2 ks + 1, and the k order inside it is the order a lane HOLDS those two tiles' accumulators (registers 0..3 of tile
+//     2 ks, then of tile 2 ks + 1), so the activation operand is again made from registers, with no lane movement;
+//   * activations: split on the fly (v_cvt_pk_bf16_f32 + a subtraction per level), once per k-step;
+//   * streaming as layer16r: LDS-DMA into three slice buffers, one barrier per slice; slice = one k-step x OT output tiles (24 KB
+//     at OT = 8).  Every wave reads every slice, so the layer moves 1.5x the bytes of the f32 image through LDS in 3/8 of the time.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int TK, int TO = TK>
+struct Layer16B3Geom {
+    static_assert(TK % 2 == 0 && TO % 2 == 0, "k-steps of two input tiles; output tiles in pairs");
+    static constexpr int KS = TK / 2;                       // k-steps of 32 input features
+    static constexpr int OT = TO >= 8 ? 8 : TO;             // output tiles per slice
+    static constexpr int SPK = TO / OT;                     // slices per k-step
+    static constexpr int NS = KS * SPK;
+    static constexpr int SLICE = OT * 3 * 256;              // floats: 3 KB per output tile (three planes of 64 lanes x 16 bytes)
+    static constexpr int PER = SLICE / 4 / k16Threads;      // 4 KB DMA pieces of the workgroup per slice
+    static constexpr int NBUFW = NS >= 3 ? 3 : NS;
+    static constexpr int IMAGE = NS * SLICE;                // floats of the whole layer image
+    static_assert(SLICE / 4 % k16Threads == 0, "slice must split evenly over the workgroup");
+};
+
+__host__ __device__ inline void split_bf16x3(float v, float& hi, float& mid, float& lo) {   // the three pieces, as f32 values
+    auto rne = [](float x) {   // round to nearest even at bf16 precision
+        unsigned u = __builtin_bit_cast(unsigned, x);
+        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+        return __builtin_bit_cast(float, u);
+    };
+    hi = rne(v);
+    const float r1 = v - hi;
+    mid = rne(r1);
+    lo = rne(r1 - mid);
+}
+
+// W: nn.Linear [O][K] row-major; transposed: the layer computes V = W^T (outputs = W's columns, k = W's rows).  dst: bf16 (uint16).
+__device__ inline void pack16_b3_layer(unsigned short* __restrict__ dst, const float* __restrict__ W, int K, int n_out, int n_k,
+                                       bool transposed, int tid, int nthr) {
+    const int TO = n_out / 16, KS = n_k / 32;
+    const int OT = TO >= 8 ? 8 : TO, SPK = TO / OT;
+    const int n = KS * TO * 64 * 8;   // elements of one plane
+    for (int idx = tid; idx < n; idx += nthr) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, tt = (idx >> 9) % OT, sl = idx / (512 * OT);
+        const int ks = sl / SPK, to = (sl % SPK) * OT + tt;
+        const int i = lane & 15, g = lane >> 4;
+        const int out = 16 * to + i, k = 16 * (2 * ks + (e >> 2)) + 4 * g + (e & 3);
+        const float v = transposed ? W[(size_t)k * K + out] : W[(size_t)out * K + k];
+        float p3[3];
+        split_bf16x3(v, p3[0], p3[1], p3[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            dst[((size_t)((sl * OT + tt) * 3 + p) * 64 + lane) * 8 + e] = (unsigned short)(__builtin_bit_cast(unsigned, p3[p]) >> 16);
+    }
+}
+
+template <int TK, int TO, int ACT, bool HAS_BIAS>
+__device__ __forceinline__ void layer16r_b3(const float* __restrict__ gimg, const float* __restrict__ bias, float* __restrict__ wbuf,
+                                            int lane, int tid, const f32x4 (&in)[TK], f32x4 (&out)[TO]) {
+    using G = Layer16B3Geom<TK, TO>;
+    constexpr int OT = G::OT, SPK = G::SPK, NS = G::NS, SLICE = G::SLICE, PER = G::PER;
+    const int g = lane >> 4;
+    const int wave_base = (tid >> 6) * 256;   // floats: this wave's 1 KB piece inside every 4 KB of a slice
+    const unsigned voff = (unsigned)tid * 16u;
+    auto dma_slice = [&](int slice) {         // (source = scalar base + one 32-bit lane offset: see layer16r)
+        const unsigned long long u = reinterpret_cast<unsigned long long>(gimg + slice * SLICE);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        const char* sbase = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+        float* ldst = wbuf + (slice % 3) * SLICE + wave_base;
+#pragma unroll
+        for (int p = 0; p < PER; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(sbase + p * (k16Threads * 16) + voff),
+                                             (lds_void_ptr)(ldst + p * k16Threads * 4), 16, 0, 0);
+    };
+    dma_slice(0);
+    if constexpr (NS > 1) dma_slice(1);
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        if constexpr (HAS_BIAS) out[t] = *reinterpret_cast<const f32x4*>(bias + t * 16 + 4 * g);
+        else out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (NS > 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // slice 0 landed (slice 1 may still fly)
+    PIME16_BARRIER();
+    bf16x8 bh, bm, bl;       // the activation operand of the current k-step
+    bf16x8 wf[2][6];         // fragments of two output tiles (hi, mid, lo each), double-buffered
+    auto load_pair = [&](int slice, int pr, bf16x8 (&dst)[6]) {
+        const bf16x8* wl = reinterpret_cast<const bf16x8*>(wbuf + (slice % 3) * SLICE) + lane;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) dst[m] = wl[(pr * 6 + m) * 64];
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 2 < NS) dma_slice(s + 2);
+        load_pair(s, 0, wf[0]);
+        if (s % SPK == 0) {   // a new k-step: input tiles 2 ks, 2 ks + 1 in three bf16 pieces
+            const int ks = s / SPK;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = in[2 * ks + (e >> 2)][e & 3];
+                const __bf16 a = (__bf16)v;
+                const float r1 = v - (float)a;
+                const __bf16 b = (__bf16)r1;
+                bh[e] = a; bm[e] = b; bl[e] = (__bf16)(r1 - (float)b);
+            }
+        }
+#pragma unroll
+        for (int pr = 0; pr < OT / 2; ++pr) {
+            const int cur = pr & 1;
+            const int t0 = (s % SPK) * OT + 2 * pr;
+            if (pr + 1 < OT / 2) load_pair(s, pr + 1, wf[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 (&w)[6] = wf[cur];   // [0..2] = hi, mid, lo of tile t0; [3..5] of tile t0 + 1
+            f32x4 c0 = out[t0], c1 = out[t0 + 1];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], bh, c0, 0, 0, 0);   // the small terms first
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[5], bh, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], bl, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[3], bl, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], bm, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[4], bm, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], bh, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[4], bh, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], bm, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[3], bm, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], bh, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[3], bh, c1, 0, 0, 0);
+            out[t0] = c0; out[t0 + 1] = c1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // slice s+1 must have landed before the barrier publishes it; the DMA of slice s+2 (the PER youngest) may still fly
+        if (s + 2 < NS) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+        PIME16_BARRIER();   // slice s+1 published; slice s's reads retired (after the last slice: wbuf is free again)
+    }
+#pragma unroll
+    for (int t = 0; t < TO; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[t][r] = act16<ACT>(out[t][r]);
+}
+
+template <int TK, int TO = TK>
+__host__ __device__ constexpr int layer16_b3_lds_floats() {
+    return Layer16B3Geom<TK, TO>::NBUFW * Layer16B3Geom<TK, TO>::SLICE;
+}
+
+// The bf16x3 planes of a net's streamed layers sit BEHIND its transposed f32 image (img_bwd + layoutb16(md).total): forward layers,
+// then their transposes.  A layer <TK, TO> takes (TK / 2) * TO * 768 floats (1.5x its f32 image).
+__host__ __device__ constexpr int b3_layer_floats(int TK, int TO) { return (TK / 2) * TO * 768; }
+struct LayoutB3_16 { int w1, w2, w2t, w1t, total; };
+__host__ __device__ inline LayoutB3_16 layout_b3_16(int md) {
+    const int T = md / 16, I = b3_layer_floats(T, T);
+    return LayoutB3_16{0, I, 2 * I, 3 * I, 4 * I};
+}
+struct LayoutB3_16M { int w1o, w1i, wn, wnt, w1ot, w1it, total; };
+__host__ __device__ inline LayoutB3_16M layout_b3_16m(int md) {
+    const int T = md / 16, I = b3_layer_floats(T, T), Ih = b3_layer_floats(T, T / 2), It = b3_layer_floats(T / 2, T);
+    return LayoutB3_16M{0, Ih, 2 * Ih, 2 * Ih + I, 2 * Ih + 2 * I, 2 * Ih + 2 * I + It, 2 * Ih + 2 * I + 2 * It};
+}
+
+__global__ void pack16_b3_kernel(PackArgs a, float* __restrict__ b3) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+    const int md = a.md, hd = md / 2;
+    unsigned short* const d = reinterpret_cast<unsigned short*>(b3);
+    if (a.kind == MLP_MODULAR_ACTOR) {   // params: other_net.0, other_net.2 [hd][md], integrator_net.0, integrator_net.2, net.0 [md][md], net.2
+        const LayoutB3_16M L = layout_b3_16m(md);
+        pack16_b3_layer(d + 2 * L.w1o, a.p[2], md, hd, md, false, tid, nthr);
+        pack16_b3_layer(d + 2 * L.w1i, a.p[6], md, hd, md, false, tid, nthr);
+        pack16_b3_layer(d + 2 * L.wn, a.p[8], md, md, md, false, tid, nthr);
+        pack16_b3_layer(d + 2 * L.wnt, a.p[8], md, md, md, true, tid, nthr);
+        pack16_b3_layer(d + 2 * L.w1ot, a.p[2], md, md, hd, true, tid, nthr);   // V = W^T: md outputs, hd inputs; W's row length is md
+        pack16_b3_layer(d + 2 * L.w1it, a.p[6], md, md, hd, true, tid, nthr);
+    } else {
+        const LayoutB3_16 L = layout_b3_16(md);
+        pack16_b3_layer(d + 2 * L.w1, a.p[2], md, md, md, false, tid, nthr);
+        pack16_b3_layer(d + 2 * L.w2, a.p[4], md, md, md, false, tid, nthr);
+        pack16_b3_layer(d + 2 * L.w2t, a.p[4], md, md, md, true, tid, nthr);
+        pack16_b3_layer(d + 2 * L.w1t, a.p[2], md, md, md, true, tid, nthr);
+    }
+}
+
+// One streamed layer of a gradient kernel: the f32 image, or (B3) the bf16x3 planes.
+template <int TK, int TO, int ACT, bool HAS_BIAS, bool B3>
+__device__ __forceinline__ void chain16(const float* __restrict__ gimg, const float* __restrict__ b3img, const float* __restrict__ bias,
+                                        float* __restrict__ wbuf, int lane, int tid, const f32x4 (&in)[TK], f32x4 (&out)[TO]) {
+    if constexpr (B3) layer16r_b3<TK, TO, ACT, HAS_BIAS>(b3img, bias, wbuf, lane, tid, in, out);
+    else layer16r<TK, TO, ACT, HAS_BIAS>(gimg, bias, wbuf, lane, tid, in, out);
 }
 
 template <int T, int ACT, bool HAS_BIAS>
@@ -729,6 +917,7 @@ __host__ __device__ inline Lds16 lds16(int D, bool grad) {
         region = region > dwf ? region : dwf;
         const int hacc = k16Waves * md;
         region = region > hacc ? region : hacc;
+        if constexpr (T >= 8) region = region > layer16_b3_lds_floats<T>() ? region : layer16_b3_lds_floats<T>();   // (never larger today)
     }
     seg(S.region, region);
     S.total = o;
@@ -793,7 +982,9 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void mlp16_forward_kern
         if (a.trace && blockIdx.x == a.trace_wg && threadIdx.x == 0 && mark0 + (i) < 32) a.trace[mark0 + (i)] = wall_clock64(); \
     } while (0)
 
-template <int T, bool ACTOR>
+// B3: the four streamed layers (two forward, two dX) on bf16 matrix instructions, every f32 operand as three bf16 pieces
+// (layer16r_b3; PIME_GRAD_BF16X3=1).  The weight gradients, the first layer and the head stay on the f32 path.
+template <int T, bool ACTOR, bool B3 = false>
 __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int ACT = ACTOR ? 1 : 0;
@@ -801,6 +992,8 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
     constexpr int RT = T <= 8 ? 4 : 2;   // tiles per weight-gradient round (dw16)
     const Layout16 L = layout16(a.D, md);
     const LayoutB16 Lb = layoutb16(md);
+    const LayoutB3_16 L3 = layout_b3_16(md);
+    const float* const b3 = a.img_bwd + Lb.total;   // the bf16x3 planes behind the transposed image (B3 only)
     const Lds16 S = lds16<T>(a.D, true);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const region = lds + S.region;
@@ -840,11 +1033,11 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
             first16<T, ACT>(lds + S.w0, lds + S.b0, L.KS0, lane, xr, h1);
             PIME_NO_HOIST();
             PIME16_MARK(1);
-            layer16<T, ACT, true>(a.img_fwd + L.w1, lds + S.b1, region, lane, tid, h1, h2);
+            chain16<T, T, ACT, true, B3>(a.img_fwd + L.w1, b3 + L3.w1, lds + S.b1, region, lane, tid, h1, h2);
         }
         PIME16_MARK(2);
         PIME_NO_HOIST();
-        layer16<T, ACT, true>(a.img_fwd + L.w2, lds + S.b2, region, lane, tid, h2, h3);
+        chain16<T, T, ACT, true, B3>(a.img_fwd + L.w2, b3 + L3.w2, lds + S.b2, region, lane, tid, h2, h3);
         PIME16_MARK(3);
         const float y = head16<T>(lds + S.w3, lds[S.b3], lane, h3);
 
@@ -922,7 +1115,7 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
         f32x4 d2[T];
         PIME16_BARRIER();
         PIME16_MARK(5);
-        layer16<T, 2, false>(a.img_bwd + Lb.w2t, nullptr, region, lane, tid, h3, d2);
+        chain16<T, T, 2, false, B3>(a.img_bwd + Lb.w2t, b3 + L3.w2t, nullptr, region, lane, tid, h3, d2);
         PIME16_MARK(6);
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -938,7 +1131,7 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
         f32x4(&d1)[T] = h3;   // dZ3 is dead
         PIME16_BARRIER();
         PIME16_MARK(7);
-        layer16<T, 2, false>(a.img_bwd + Lb.w1t, nullptr, region, lane, tid, d2, d1);
+        chain16<T, T, 2, false, B3>(a.img_bwd + Lb.w1t, b3 + L3.w1t, nullptr, region, lane, tid, d2, d1);
         PIME16_MARK(8);
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -1062,6 +1255,8 @@ __host__ __device__ inline Lds16M lds16m(int D, int Di, bool grad) {
         int dwf = mx(dw16_lds_floats<T, T, RT>(), mx(dw16_lds_floats<T / 2, T, RT>(), dw16_lds_floats<T, 1, RT>()));
         if constexpr (T == 4 * k16Waves) dwf = mx(dwf, Dw16Sliced<T>::FLOATS);
         region = mx(region, mx(dwf, k16Waves * md));
+        if constexpr (T >= 8)
+            region = mx(region, mx(layer16_b3_lds_floats<T, T>(), mx(layer16_b3_lds_floats<T, T / 2>(), layer16_b3_lds_floats<T / 2, T>())));
     }
     seg(S.region, region);
     S.total = o;
@@ -1131,13 +1326,15 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void mlp16m_forward_ker
 }
 
 // PPO minibatch gradients of the modular actor: ppo16_kernel's structure (no activation stash, slabs in accumulator order)
-template <int T>
+template <int T, bool B3 = false>
 __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16m_kernel(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int ACT = 1, md = T * 16, H = T / 2;
     constexpr int RT = T <= 8 ? 4 : 2;
     const Layout16M L = layout16m(a.D, a.Di, md);
     const LayoutB16M Lb = layoutb16m(md);
+    const LayoutB3_16M L3 = layout_b3_16m(md);
+    const float* const b3 = a.img_bwd + Lb.total;   // the bf16x3 planes behind the transposed image (B3 only)
     const Lds16M S = lds16m<T>(a.D, a.Di, true);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const region = lds + S.region;
@@ -1171,14 +1368,14 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16m_kernel(PpoA
             f32x4 t1[T];
             first16<T, ACT>(lds + S.w0o, lds + S.b0o, L.KS0o, lane, xo, t1);
             PIME_NO_HOIST();
-            layer16r<T, H, ACT, true>(a.img_fwd + L.w1o, lds + S.b1o, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[0]));
+            chain16<T, H, ACT, true, B3>(a.img_fwd + L.w1o, b3 + L3.w1o, lds + S.b1o, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[0]));
             PIME_NO_HOIST();
             first16<T, ACT>(lds + S.w0i, lds + S.b0i, L.KS0i, lane, xi, t1);
             PIME_NO_HOIST();
-            layer16r<T, H, ACT, true>(a.img_fwd + L.w1i, lds + S.b1i, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[H]));
+            chain16<T, H, ACT, true, B3>(a.img_fwd + L.w1i, b3 + L3.w1i, lds + S.b1i, region, lane, tid, t1, *reinterpret_cast<f32x4(*)[H]>(&cat[H]));
         }
         PIME_NO_HOIST();
-        layer16<T, ACT, true>(a.img_fwd + L.wn, lds + S.bn, region, lane, tid, cat, n0);
+        chain16<T, T, ACT, true, B3>(a.img_fwd + L.wn, b3 + L3.wn, lds + S.bn, region, lane, tid, cat, n0);
         const float y = head16<T>(lds + S.w3, lds[S.b3], lane, n0);
 
         // ------------------------------------------------------------------------------------------ loss gradient (agent.py:637-645)
@@ -1238,7 +1435,7 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16m_kernel(PpoA
             dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{n0, g}, PubAcc16<T>{cat, g}, sl + a.poff[8], sl + a.poff[9], accum);
         f32x4 dcat[T];
         PIME16_BARRIER();
-        layer16<T, 2, false>(a.img_bwd + Lb.wnt, nullptr, region, lane, tid, n0, dcat);
+        chain16<T, T, 2, false, B3>(a.img_bwd + Lb.wnt, b3 + L3.wnt, nullptr, region, lane, tid, n0, dcat);
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -1254,7 +1451,7 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16m_kernel(PpoA
             else first16<T, ACT>(lds + S.w0i, lds + S.b0i, L.KS0i, lane, xi, t1);
             dw16<H, T, RT>(region, lane, wave, PubAcc16<H>{dz2, g}, PubAcc16<T>{t1, g}, sl + a.poff[br ? 6 : 2], sl + a.poff[br ? 7 : 3], accum);
             PIME16_BARRIER();
-            layer16r<H, T, 2, false>(a.img_bwd + (br ? Lb.w1it : Lb.w1ot), nullptr, region, lane, tid, dz2, d1);
+            chain16<H, T, 2, false, B3>(a.img_bwd + (br ? Lb.w1it : Lb.w1ot), b3 + (br ? L3.w1it : L3.w1ot), nullptr, region, lane, tid, dz2, d1);
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -1542,18 +1739,38 @@ bool family16(int kind, int md) {
 }
 bool family16_grad(int kind, int md, int D, int Di) {
     if (family16(kind, md)) return true;
-    if (kind == MLP_MODULAR_ACTOR || (md != 64 && md != 128)) return false;
+    if (kind == MLP_MODULAR_ACTOR) return md == 128 && forced16();   // (A/B and the bf16x3 variant at the headline width)
+    if (md != 64 && md != 128) return false;
     return !fused_fits(kind, D, Di, md);
 }
 
 int64_t packed16_floats(int kind, int D, int Di, int md) {
     return kind == MLP_MODULAR_ACTOR ? layout16m(D, Di, md).total : layout16(D, md).total;
 }
+// PIME_GRAD_BF16X3=1 (opt-in): the gradient kernels of this family run their streamed layers on bf16 matrix instructions with every
+// f32 operand split into three bf16 pieces (layer16r_b3) -- a different rounding of the same f32 products, not bit-equal to the f32
+// MFMA chain.  Widths 128 and 256.
+static bool b3_enabled() {
+    static const bool on = std::getenv("PIME_GRAD_BF16X3") != nullptr && std::atoi(std::getenv("PIME_GRAD_BF16X3")) != 0;
+    return on;
+}
+bool b3_grad(int kind, int md, int D, int Di) { return b3_enabled() && (md == 128 || md == 256) && family16_grad(kind, md, D, Di); }
+int64_t b3_floats(int kind, int md) { return kind == MLP_MODULAR_ACTOR ? layout_b3_16m(md).total : layout_b3_16(md).total; }
+
+// the f32 part of the transposed image; with b3_grad the planes follow it (the caller sizes the image with ppo_bwd_image_floats)
 int64_t bwd16_floats(int kind, int md) { return kind == MLP_MODULAR_ACTOR ? layoutb16m(md).total : layoutb16(md).total; }
 
 int launch_pack16(const PackArgs& a, float* fwd, float* bwd, hipStream_t s) {
     if (a.kind == MLP_MODULAR_ACTOR) hipLaunchKernelGGL(pack16m_kernel, dim3(128), dim3(256), 0, s, a, fwd, bwd);
     else hipLaunchKernelGGL(pack16_kernel, dim3(128), dim3(256), 0, s, a, fwd, bwd);
+    if (bwd && b3_grad(a.kind, a.md, a.D, a.Di))
+        hipLaunchKernelGGL(pack16_b3_kernel, dim3(256), dim3(256), 0, s, a, bwd + bwd16_floats(a.kind, a.md));
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+// the planes alone (after an optimizer step that kept the f32 images current through the image map)
+int launch_pack16_b3(const PackArgs& a, float* bwd, hipStream_t s) {
+    hipLaunchKernelGGL(pack16_b3_kernel, dim3(256), dim3(256), 0, s, a, bwd + bwd16_floats(a.kind, a.md));
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
@@ -1569,7 +1786,8 @@ int grid16(int kind, int B, int md, int D, int Di) {
     const int ngroups = (B + k16Group - 1) / k16Group;
     size_t lds = 0;
     int per = 1;
-    if (kind == MLP_MODULAR_ACTOR) { lds = sizeof(float) * lds16m<16>(D, Di, true).total; per = wgs_per_cu<16>(lds); }
+    if (kind == MLP_MODULAR_ACTOR && md == 128) { lds = sizeof(float) * lds16m<8>(D, Di, true).total; per = wgs_per_cu<8>(lds); }
+    else if (kind == MLP_MODULAR_ACTOR) { lds = sizeof(float) * lds16m<16>(D, Di, true).total; per = wgs_per_cu<16>(lds); }
     else if (md == 64) { lds = sizeof(float) * lds16<4>(D, true).total; per = wgs_per_cu<4>(lds); }
     else if (md == 128) { lds = sizeof(float) * lds16<8>(D, true).total; per = wgs_per_cu<8>(lds); }
     else { lds = sizeof(float) * lds16<16>(D, true).total; per = wgs_per_cu<16>(lds); }
@@ -1612,29 +1830,37 @@ int launch_forward16(int kind, const float* x, int M, int D, int Di, int md, con
     return PIME_ERR_ARG;
 }
 
-template <int T, bool ACTOR>
+template <int T, bool ACTOR, bool B3 = false>
 static int launch_grad16(const PpoArgs& a, hipStream_t s) {
     const size_t lds_bytes = sizeof(float) * (size_t)lds16<T>(a.D, true).total;
     PIME_REQUIRE(lds_bytes <= 160 * 1024, "16-tile PPO kernel needs %zu B of LDS", lds_bytes);
     static LdsLimit lds_limit;  // per instantiation
-    PIME_RAISE_LDS(lds_limit, (ppo16_kernel<T, ACTOR>), 160 * 1024);
-    hipLaunchKernelGGL((ppo16_kernel<T, ACTOR>), dim3(grid16(ACTOR ? MLP_PLAIN_ACTOR : MLP_CRITIC, a.B, T * 16, a.D, 0)), dim3(k16Threads), lds_bytes, s, a);
+    PIME_RAISE_LDS(lds_limit, (ppo16_kernel<T, ACTOR, B3>), 160 * 1024);
+    hipLaunchKernelGGL((ppo16_kernel<T, ACTOR, B3>), dim3(grid16(ACTOR ? MLP_PLAIN_ACTOR : MLP_CRITIC, a.B, T * 16, a.D, 0)), dim3(k16Threads), lds_bytes, s, a);
+    PIME_HIP_TRY(hipGetLastError());
+    return PIME_OK;
+}
+template <int T, bool B3>
+static int launch_grad16m(const PpoArgs& a, hipStream_t s) {
+    const size_t lds_bytes = sizeof(float) * (size_t)lds16m<T>(a.D, a.Di, true).total;
+    PIME_REQUIRE(lds_bytes <= 160 * 1024, "16-tile modular PPO kernel needs %zu B of LDS", lds_bytes);
+    static LdsLimit lds_limit;  // per instantiation
+    PIME_RAISE_LDS(lds_limit, (ppo16m_kernel<T, B3>), 160 * 1024);
+    hipLaunchKernelGGL((ppo16m_kernel<T, B3>), dim3(grid16(MLP_MODULAR_ACTOR, a.B, T * 16, a.D, a.Di)), dim3(k16Threads), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
 
 int launch_ppo16(int kind, int md, const PpoArgs& a, hipStream_t s) {
     const int T = md / 16;
+    const bool b3 = b3_grad(kind, md, a.D, a.Di);
     if (kind == MLP_MODULAR_ACTOR) {
-        PIME_REQUIRE(T == 16, "the 16-tile modular actor serves width 256, got %d", md);
-        const size_t lds_bytes = sizeof(float) * (size_t)lds16m<16>(a.D, a.Di, true).total;
-        PIME_REQUIRE(lds_bytes <= 160 * 1024, "16-tile modular PPO kernel needs %zu B of LDS", lds_bytes);
-        static LdsLimit lds_limit;
-        PIME_RAISE_LDS(lds_limit, (ppo16m_kernel<16>), 160 * 1024);
-        hipLaunchKernelGGL((ppo16m_kernel<16>), dim3(grid16(kind, a.B, md, a.D, a.Di)), dim3(k16Threads), lds_bytes, s, a);
-        PIME_HIP_TRY(hipGetLastError());
-        return PIME_OK;
+        PIME_REQUIRE(T == 16 || T == 8, "the 16-tile modular actor serves widths 128 and 256, got %d", md);
+        if (T == 8) return b3 ? launch_grad16m<8, true>(a, s) : launch_grad16m<8, false>(a, s);
+        return b3 ? launch_grad16m<16, true>(a, s) : launch_grad16m<16, false>(a, s);
     }
+    if (b3 && T == 8) return kind == MLP_CRITIC ? launch_grad16<8, false, true>(a, s) : launch_grad16<8, true, true>(a, s);
+    if (b3 && T == 16) return kind == MLP_CRITIC ? launch_grad16<16, false, true>(a, s) : launch_grad16<16, true, true>(a, s);
 #define PIME_G16(TT) \
     if (T == TT) return kind == MLP_CRITIC ? launch_grad16<TT, false>(a, s) : launch_grad16<TT, true>(a, s);
     PIME_G16(4) PIME_G16(8) PIME_G16(16)

@@ -537,11 +537,17 @@ bool family16(int kind, int md);
 bool family16_grad(int kind, int md, int D, int Di);
 int64_t packed16_floats(int kind, int D, int Di, int md);
 int64_t bwd16_floats(int kind, int md);
+bool b3_grad(int kind, int md, int D, int Di);
+int64_t b3_floats(int kind, int md);
 int grid16(int kind, int B, int md, int D, int Di);
 int launch_pack16(const PackArgs& a, float* fwd, float* bwd, hipStream_t s);
 
-int64_t ppo_bwd_image_floats(int kind, int D, int Di, int md) {
+// the transposed image's f32 part (what the image map covers) and the whole image: + the bf16x3 planes under PIME_GRAD_BF16X3=1
+int64_t ppo_bwd_image_f32_floats(int kind, int D, int Di, int md) {
     return family16_grad(kind, md, D, Di) ? bwd16_floats(kind, md) : (int64_t)bwd_layout(kind, D, Di, md).total;
+}
+int64_t ppo_bwd_image_floats(int kind, int D, int Di, int md) {
+    return ppo_bwd_image_f32_floats(kind, D, Di, md) + (b3_grad(kind, md, D, Di) ? b3_floats(kind, md) : 0);
 }
 int64_t ppo_fwd_image_floats(int kind, int D, int Di, int md) {
     return family16_grad(kind, md, D, Di) ? packed16_floats(kind, D, Di, md) : (int64_t)mlp_layout(kind, D, Di, md).total;
@@ -558,7 +564,7 @@ int64_t ppo_workspace_floats(int kind, int B, int md) {
         const int g2 = grid16(kind, B, md, kMaxObsDim, 0);
         g = g > g2 ? g : g2;
         f16 = (int64_t)g * stride;
-    } else if (md == 256) {
+    } else if (md == 256 || md == 128) {
         f16 = (int64_t)grid16(kind, B, md, 4, 1) * slab_layout16m(md, poff, psize);   // (the grid does not depend on the state width)
     }
     if (md == 256) return f16;

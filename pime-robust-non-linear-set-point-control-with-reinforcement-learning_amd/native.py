@@ -16,7 +16,7 @@ LIB_PATH = _override or os.path.join(PACKAGE_DIR, "libpime_hip.so")
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
-ABI_VERSION = 17
+ABI_VERSION = 18
 ENV_PH, ENV_WT = 0, 1
 STATE_F64, STATE_MIXED, STATE_MIXED16 = 0, 1, 2
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}
@@ -124,6 +124,7 @@ _SIGNATURES = {
 
     "pime_ppo_fwd_image_floats": (C.c_int64, [_i32, _i32, _i32, _i32]),
     "pime_ppo_bwd_image_floats": (C.c_int64, [_i32, _i32, _i32, _i32]),
+    "pime_ppo_bwd_image_f32_floats": (C.c_int64, [_i32, _i32, _i32, _i32]),
     "pime_ppo_workspace_floats": (C.c_int64, [_i32, _i32, _i32]),
     "pime_ppo_pack_bwd": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pime_ppo_repack": (C.c_int, [_vp, _vp, _vp]),

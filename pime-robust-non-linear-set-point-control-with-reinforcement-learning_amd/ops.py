@@ -168,6 +168,7 @@ class FusedPPOGrad:
             if n_fwd <= 0 or n_bwd <= 0 or n_ws <= 0:
                 raise native.PimeError(f"fused PPO gradients unsupported for {kind} width {md}: {native.last_error()}")
             net = dict(kind=k, D=D, Di=Di, md=md, plist=plist,
+                       n_bwd_f32=L.pime_ppo_bwd_image_f32_floats(k, D, Di, md),   # < n_bwd under PIME_GRAD_BF16X3=1: bf16 planes follow
                        img_fwd=torch.zeros(n_fwd, dtype=torch.float32, device=self.device),   # zeros: the padding the pack
                        img_bwd=torch.zeros(n_bwd, dtype=torch.float32, device=self.device),   # kernels never write is defined
                        ws=torch.empty(n_ws, dtype=torch.float32, device=self.device))
@@ -211,7 +212,7 @@ class FusedPPOGrad:
             pos, which = code & ((1 << 28) - 1), (code >> 28) & 3
             for net_bit, net in ((1, self.nets[0]), (0, self.nets[1])):     # bits 28..29: 0 critic, 1 actor; self.nets = [actor, critic]
                 sel = valid & (which == net_bit)
-                have = net[key]
+                have = net[key] if col == 0 else net[key][:net["n_bwd_f32"]]   # the part that is a permutation of the parameters
                 if bool((pos[sel] >= have.numel()).any()):
                     return False
                 if all(p.requires_grad for p in net["plist"]):   # every image element is a mapped parameter or zero padding

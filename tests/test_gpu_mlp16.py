@@ -182,6 +182,8 @@ for kind, md, D, M in (("critic", 128, 3, 5000), ("actor", 128, 4, 333), ("criti
     t.check_forward(kind, md, D, M)
 for md, D, B in ((128, 3, 4096), (128, 3, 70000), (128, 30, 1000), (64, 4, 2048), (64, 12, 777)):
     t.check_grads("resid", md, D, B)
+for D, B in ((3, 4096), (4, 1000), (4, 40000)):   # the modular actor at width 128 on ppo16m_kernel<8> (round 4)
+    t.check_grads("modular", 128, D, B)
 print("MLP16_FORCED_OK")
 '''
 
