@@ -870,6 +870,149 @@ __device__ __forceinline__ void dw16_sliced(float* __restrict__ X, int lane, int
     }
 }
 
+// ---- width 256, bf16x3: the same weight gradient on v_mfma_f32_16x16x32_bf16 ----------------------------------------------------
+// dW[a][b] = sum over the group's 64 samples of A[s][a] B[s][b] contracts over the SAMPLE axis, which sits on the lanes of both
+// operands: an MFMA wants it in the elements of a lane (8 consecutive k).  Both operands go through a sample-major bf16 image in LDS
+// (three planes: hi, mid, lo; a lane writes its four consecutive features of a tile as ONE ds_write_b64 per plane) and come back
+// through ds_read_b64_tr_b16, the transposing read: per 16-lane group a block of 4 samples x 16 features, lane i receives feature
+// i's four samples -- two reads make the 8-sample fragment of a k-step.  Two k-steps of 32 samples x six products = 12 MFMAs
+// (192 pipe cycles) per 16 x 16 block, where the f32 path runs 16 (512 cycles).
+// Images: B [plane][sample 0..63][16 tiles x 32 bytes] = 96 KB, published once; A one 4-tile slice per pass [plane][sample][4 x 32 B]
+// = 24 KB (single buffer: with both images padded or double-buffered the map does not fit beside a 32 KB first-layer image).
+// Rows are unpadded; the 32-byte chunk (= tile) index is XOR-swizzled with row bits so that the eight rows a 32-lane half reads
+// (samples 4 hh + q and 8 + 4 hh + q) fall on distinct banks.  Patch assignment and slab layout as dw16_sliced.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int T>
+struct Dw16SlicedB3 {
+    static_assert(T == 4 * k16Waves, "one 4-tile B patch per wave");
+    static constexpr int NA = 4, NB = 4, PASSES = T / NA, ROWS = k16Waves * 16;
+    static constexpr int BROW = T * 32, AROW = NA * 32;                       // bytes per sample row
+    static constexpr int BBYTES = 3 * ROWS * BROW, ABYTES = 3 * ROWS * AROW;
+    static constexpr int FLOATS = (BBYTES + ABYTES) / 4;
+    // byte offset of (plane, sample row, tile, byte inside the tile's 32)
+    __device__ static __forceinline__ int boff(int plane, int row, int tile, int sub) {
+        return (plane * ROWS + row) * BROW + ((tile ^ ((row & 3) | ((row >> 1) & 4))) << 5) + sub;
+    }
+    __device__ static __forceinline__ int aoff(int plane, int row, int tile4, int sub) {
+        return (plane * ROWS + row) * AROW + ((tile4 ^ (((row >> 1) & 1) | ((row >> 2) & 2))) << 5) + sub;
+    }
+};
+
+// four f32 -> the hi / mid / lo bf16 pieces, packed (element r in bits 16 r .. 16 r + 15)
+__device__ __forceinline__ void split4_bf16x3(const f32x4& v, uint2& hi, uint2& mid, uint2& lo) {
+    unsigned short h[4], m[4], l[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const __bf16 a = (__bf16)v[r];
+        const float r1 = v[r] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        const __bf16 c = (__bf16)(r1 - (float)b);
+        h[r] = __builtin_bit_cast(unsigned short, a); m[r] = __builtin_bit_cast(unsigned short, b); l[r] = __builtin_bit_cast(unsigned short, c);
+    }
+    hi = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+    mid = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
+    lo = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+}
+
+template <int T>
+__device__ __forceinline__ void dw16_sliced_b3(float* __restrict__ X, int lane, int wave, const f32x4 (&va)[T], const f32x4 (&vb)[T],
+                                               float* __restrict__ gW, float* __restrict__ gb, bool accum) {
+    using P = Dw16SlicedB3<T>;
+    constexpr int NA = P::NA, NB = P::NB;
+    char* const Bimg = reinterpret_cast<char*>(X);
+    char* const Aimg = Bimg + P::BBYTES;
+    const int s = lane & 15, g = lane >> 4;   // publishing: sample s of this wave's tile, register group g
+    const int row = wave * 16 + s;
+    const int q = s >> 2, p4 = s & 3;         // reading: row q, columns 4 p4 .. of a 4 x 16 block; the lane receives feature s
+    auto pub_a = [&](int p) {                 // tiles 4p .. 4p+3 of this lane's sample, three planes
+#pragma unroll
+        for (int x = 0; x < NA; ++x) {
+            uint2 hi, mid, lo;
+            split4_bf16x3(va[4 * p + x], hi, mid, lo);
+            *reinterpret_cast<uint2*>(Aimg + P::aoff(0, row, x, 8 * g)) = hi;
+            *reinterpret_cast<uint2*>(Aimg + P::aoff(1, row, x, 8 * g)) = mid;
+            *reinterpret_cast<uint2*>(Aimg + P::aoff(2, row, x, 8 * g)) = lo;
+        }
+    };
+    auto slab_ptr = [&](int p, int x, int y) {
+        int off = (((p * NA + x) * T + wave * NB + y) * 64 + lane) * 4;   // slab_layout16: block-major, accumulator order
+        asm volatile("" : "+v"(off));
+        return reinterpret_cast<f32x4*>(gW + off);
+    };
+    // the 8-sample fragment (k-step ks) of feature s of a tile, one plane: two transposing reads
+    auto frag = [&](const char* img, int byte_off0, int byte_off1) {
+        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(img + byte_off0));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(img + byte_off1));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    PIME16_BARRIER();   // X free
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        uint2 hi, mid, lo;
+        split4_bf16x3(vb[t], hi, mid, lo);
+        *reinterpret_cast<uint2*>(Bimg + P::boff(0, row, t, 8 * g)) = hi;
+        *reinterpret_cast<uint2*>(Bimg + P::boff(1, row, t, 8 * g)) = mid;
+        *reinterpret_cast<uint2*>(Bimg + P::boff(2, row, t, 8 * g)) = lo;
+    }
+    const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+#pragma unroll   // (p indexes the register array va: a rolled loop would put it in scratch)
+    for (int p = 0; p < P::PASSES; ++p) {
+        if (p > 0) PIME16_BARRIER();   // the previous pass's reads of the A slice are done
+        pub_a(p);
+        f32x4 acc[NA][NB];
+#pragma unroll
+        for (int x = 0; x < NA; ++x)
+#pragma unroll
+            for (int y = 0; y < NB; ++y) acc[x][y] = accum ? *slab_ptr(p, x, y) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};   // bias gradient of A tile 4p + wave: column sums, as a product with an all-ones operand
+        PIME16_BARRIER();              // the slice (first pass: and the B image) is visible
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r0 = 32 * ks + 8 * g + q, r1 = r0 + 4;
+            bf16x8 bf[NB][3];
+#pragma unroll
+            for (int y = 0; y < NB; ++y)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bf[y][pl] = frag(Bimg, P::boff(pl, r0, wave * NB + y, 8 * p4), P::boff(pl, r1, wave * NB + y, 8 * p4));
+#pragma unroll
+            for (int x = 0; x < NA; ++x) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[pl] = frag(Aimg, P::aoff(pl, r0, x, 8 * p4), P::aoff(pl, r1, x, 8 * p4));
+#pragma unroll
+                for (int y = 0; y < NB; ++y) {
+                    f32x4 c = acc[x][y];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[y][0], c, 0, 0, 0);   // the small terms first
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[y][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[y][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[y][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[y][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[y][0], c, 0, 0, 0);
+                    acc[x][y] = c;
+                }
+                if (gb && x == wave) {
+                    bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], ones, bacc, 0, 0, 0);
+                    bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], ones, bacc, 0, 0, 0);
+                    bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], ones, bacc, 0, 0, 0);
+                }
+            }
+        }
+        // one 16-byte store per lane and block (a wave writes 1 KB contiguous)
+#pragma unroll
+        for (int x = 0; x < NA; ++x)
+#pragma unroll
+            for (int y = 0; y < NB; ++y) *slab_ptr(p, x, y) = acc[x][y];
+        if (gb && s == 0) {   // column 0 of the all-ones product: features 16 (4p + wave) + 4g + r in register r
+            f32x4* qd = reinterpret_cast<f32x4*>(gb + (p * NA + wave) * 16 + 4 * g);
+            *qd = accum ? *qd + bacc : bacc;
+        }
+    }
+    PIME16_BARRIER();   // the images may be rewritten
+}
+
 template <int TA, int TB, int RT>
 __host__ __device__ constexpr int dw16_lds_floats() { return RT * 16 * (Dw16Plan<TA, TB>::PA + Dw16Plan<TA, TB>::PB); }
 
@@ -913,7 +1056,10 @@ __host__ __device__ inline Lds16 lds16(int D, bool grad) {
     if (grad) {
         constexpr int RT = T <= 8 ? 4 : 2;
         int dwf = dw16_lds_floats<T, T, RT>();
-        if constexpr (T == 4 * k16Waves) dwf = dwf > Dw16Sliced<T>::FLOATS ? dwf : Dw16Sliced<T>::FLOATS;
+        if constexpr (T == 4 * k16Waves) {
+            dwf = dwf > Dw16Sliced<T>::FLOATS ? dwf : Dw16Sliced<T>::FLOATS;
+            dwf = dwf > Dw16SlicedB3<T>::FLOATS ? dwf : Dw16SlicedB3<T>::FLOATS;   // (bf16x3 variant: 120 KB; one workgroup per CU at this width anyway)
+        }
         region = region > dwf ? region : dwf;
         const int hacc = k16Waves * md;
         region = region > hacc ? region : hacc;
@@ -1107,9 +1253,11 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
         // ------------------------------------------------------------------------------------------ backward
         PIME16_MARK(4);
         PIME_NO_HOIST();
-        if constexpr (T == 4 * k16Waves)
+        if constexpr (T == 4 * k16Waves && B3)
+            dw16_sliced_b3<T>(region, lane, wave, h3, h2, sl + a.poff[4], sl + a.poff[5], accum);                           // net.4
+        else if constexpr (T == 4 * k16Waves)
             dw16_sliced<T>(region, lane, wave, h3, h2, sl + a.poff[4], sl + a.poff[5], accum,
-                           (a.trace && blockIdx.x == a.trace_wg && !accum) ? a.trace + 40 : nullptr);                      // net.4
+                           (a.trace && blockIdx.x == a.trace_wg && !accum) ? a.trace + 40 : nullptr);
         else
             dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{h3, g}, PubAcc16<T>{h2, g}, sl + a.poff[4], sl + a.poff[5], accum);
         f32x4 d2[T];
@@ -1124,8 +1272,10 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16_kernel(PpoAr
         f32x4(&h1)[T] = h2;   // h2 is dead: its registers take the recomputed first-layer activation
         PIME_NO_HOIST();
         first16<T, ACT>(lds + S.w0, lds + S.b0, L.KS0, lane, xr, h1);
-        if constexpr (T == 4 * k16Waves)
-            dw16_sliced<T>(region, lane, wave, d2, h1, sl + a.poff[2], sl + a.poff[3], accum);                              // net.2
+        if constexpr (T == 4 * k16Waves && B3)
+            dw16_sliced_b3<T>(region, lane, wave, d2, h1, sl + a.poff[2], sl + a.poff[3], accum);                           // net.2
+        else if constexpr (T == 4 * k16Waves)
+            dw16_sliced<T>(region, lane, wave, d2, h1, sl + a.poff[2], sl + a.poff[3], accum);
         else
             dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{d2, g}, PubAcc16<T>{h1, g}, sl + a.poff[2], sl + a.poff[3], accum);
         f32x4(&d1)[T] = h3;   // dZ3 is dead
@@ -1253,7 +1403,7 @@ __host__ __device__ inline Lds16M lds16m(int D, int Di, bool grad) {
     if (grad) {
         constexpr int RT = T <= 8 ? 4 : 2;
         int dwf = mx(dw16_lds_floats<T, T, RT>(), mx(dw16_lds_floats<T / 2, T, RT>(), dw16_lds_floats<T, 1, RT>()));
-        if constexpr (T == 4 * k16Waves) dwf = mx(dwf, Dw16Sliced<T>::FLOATS);
+        if constexpr (T == 4 * k16Waves) dwf = mx(dwf, mx(Dw16Sliced<T>::FLOATS, Dw16SlicedB3<T>::FLOATS));
         region = mx(region, mx(dwf, k16Waves * md));
         if constexpr (T >= 8)
             region = mx(region, mx(layer16_b3_lds_floats<T, T>(), mx(layer16_b3_lds_floats<T, T / 2>(), layer16_b3_lds_floats<T / 2, T>())));
@@ -1429,8 +1579,10 @@ __global__ __launch_bounds__(k16Threads, T <= 8 ? 2 : 1) void ppo16m_kernel(PpoA
         }
         // ------------------------------------------------------------------------------------------ backward
         PIME_NO_HOIST();
-        if constexpr (T == 4 * k16Waves)
-            dw16_sliced<T>(region, lane, wave, n0, cat, sl + a.poff[8], sl + a.poff[9], accum);                                      // net.0
+        if constexpr (T == 4 * k16Waves && B3)
+            dw16_sliced_b3<T>(region, lane, wave, n0, cat, sl + a.poff[8], sl + a.poff[9], accum);                                   // net.0
+        else if constexpr (T == 4 * k16Waves)
+            dw16_sliced<T>(region, lane, wave, n0, cat, sl + a.poff[8], sl + a.poff[9], accum);
         else
             dw16<T, T, RT>(region, lane, wave, PubAcc16<T>{n0, g}, PubAcc16<T>{cat, g}, sl + a.poff[8], sl + a.poff[9], accum);
         f32x4 dcat[T];
