@@ -2,7 +2,9 @@
 split into three bf16 pieces (csrc/mlp16.hip: layer16r_b3, six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block).  A different rounding
 of the same f32 products, so the contract is the f32 path's own: pime_ppo_minibatch_grad against PyTorch fp32 autograd of the
 reference loss (agent.py:637-655) within 3e-4 of each tensor's largest entry, bitwise repeatable (tests/test_gpu_mlp16.py:
-check_grads); the optimizer step fused into the slab reduction leaves the bf16 planes equal to a fresh split of the new parameters.
+check_grads); the optimizer step fused into the slab reduction leaves the bf16 planes equal to a fresh split of the new parameters;
+whole update_net calls against the weights the unmodified reference produced (tests/golden/ppo_update*.npz: width 256 plain and
+modular, width 128 modular) at the f32 path's tolerances.
 Child processes: both switches are read once per process.  The layer alone against float64: tools/layer16_b3_bench.hip
 (profiles/r04_k_layer16_b3_bench.txt: 3.5e-7 of max |y|, the f32 chain 4.0e-7)."""
 import os
@@ -30,6 +32,9 @@ for kind, md, D, B in CASES:
 for kind, md, D in (("modular", 128, 3), ("resid", 128, 3), ("resid", 256, 3)):
     f.test_fused_step_keeps_the_packed_images_current(kind, md, D)
     f.test_adam_fused_into_the_slab_reduction_equals_the_separate_step(kind, md, D)
+import test_gpu_update_golden as u   # the UNMODIFIED reference's weights after a whole update_net, same tolerances as the f32 path
+for tag, mode in (("wts10_256", "one_graph"), ("wtmod256", "two_graph"), ("ph128", "one_graph")):
+    u.test_hip_update_net_matches_reference_weights(tag, mode)
 print("BF16X3_OK")
 '''
 
