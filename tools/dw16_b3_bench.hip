@@ -3,7 +3,7 @@
 // dw16_sliced_b3 (three bf16 planes per operand in LDS, ds_read_b64_tr_b16 transposing reads, six v_mfma_f32_16x16x32_bf16 per
 // block and k-step).  Both against a float64 reference (workgroup 0): max error relative to max |dW|; then the job in a loop
 // (accumulating into the workgroup's slab, as the second and later groups of a workgroup do).
-// Build: see tools/layer16_b3_bench.hip (same recipe).
+//   bash tools/build_b3_benches.sh && ./tools/bin/dw16_b3_bench
 #include "mlp16.hip"
 
 #include <cmath>

@@ -18,3 +18,21 @@ timeout -k 10 400 bash tools/env_pmc.sh $OUT/${TAG}_env_pmc.json || exit 1
 timeout -k 10 300 bash tools/profile_bench.sh ${TAG}_td3 --workload wt_td3 || exit 1
 timeout -k 10 400 bash tools/pmc_traffic.sh $OUT/${TAG}_td3_hbm_traffic_pmc.json bench.py --workload wt_td3 --steps 2 --warmup 1 --no-cpu-baseline || exit 1
 timeout -k 10 300 bash tools/profile_bench.sh ${TAG}_wt256 --workload wt256 || exit 1
+# the opt-in bf16x3 variant (PIME_GRAD_BF16X3=1): width 256 (this family by default), the headline shape through the 16-tile family
+# with and without it, per-kernel stats of the width-256 run, and the two in-place layer / weight-gradient microbenchmarks
+for w in wt256 wtmod256; do
+  PIME_GRAD_BF16X3=1 timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $OUT/${TAG}_bench_${w}_bf16x3.json 2>/dev/null || exit 1
+  python -c "import json; d=json.load(open('$OUT/${TAG}_bench_${w}_bf16x3.json')); print('$w bf16x3', round(d['value'] / 1e6, 2), 'M env-steps/s, frac', round(d['roofline']['frac'], 3))"
+done
+PIME_MLP16=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_ph_mlp16.json 2>/dev/null || exit 1
+PIME_MLP16=1 PIME_GRAD_BF16X3=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_ph_mlp16_bf16x3.json 2>/dev/null || exit 1
+python -c "
+import json
+for f in ('ph_mlp16', 'ph_mlp16_bf16x3'):
+    d = json.load(open('$OUT/${TAG}_bench_' + f + '.json')); print(f, round(d['value'] / 1e6, 2), 'M env-steps/s, minibatch gradient', round(d['roofline']['avg_launch_ms'] * 1e3, 1), 'us')"
+PIME_GRAD_BF16X3=1 timeout -k 10 300 bash tools/profile_bench.sh ${TAG}_wt256_bf16x3 --workload wt256 || exit 1
+if [ -x tools/bin/layer16_b3_bench ]; then
+  timeout -k 10 120 ./tools/bin/layer16_b3_bench > $OUT/${TAG}_layer16_b3_bench.txt 2>&1 || exit 1
+  timeout -k 10 120 ./tools/bin/dw16_b3_bench > $OUT/${TAG}_dw16_b3_bench.txt 2>&1 || exit 1
+  tail -1 $OUT/${TAG}_layer16_b3_bench.txt; tail -1 $OUT/${TAG}_dw16_b3_bench.txt
+fi

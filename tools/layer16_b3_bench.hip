@@ -2,8 +2,7 @@
 // two per compute unit, weight slices by LDS-DMA): layer16r (v_mfma_f32_16x16x4_f32) against layer16r_b3 (three bf16 pieces per f32
 // operand, six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block).  Both against a float64 reference: max and rms error relative to
 // max |y|; then the layer in a loop (x <- 0.05 y between layers), f32-equivalent TFLOP/s.
-//   cd csrc && make && cd ../.. && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I<pkg>/csrc -Iinclude -DPIME_BUILD \
-//       tools/layer16_b3_bench.hip $(ls <pkg>/csrc/build/*.o | grep -v mlp16.o) -o layer16_b3_bench && ./layer16_b3_bench
+//   bash tools/build_b3_benches.sh && ./tools/bin/layer16_b3_bench
 // (the tool includes mlp16.hip itself -- the layer routines are templates of that translation unit -- and links the other objects)
 #include "mlp16.hip"
 
