@@ -254,11 +254,11 @@ __device__ __forceinline__ void layer16r(const float* __restrict__ gimg, const f
 //     at OT = 8).  Every wave reads every slice, so the layer moves 1.5x the bytes of the f32 image through LDS in 3/8 of the time.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int TK, int TO = TK>
+template <int TK, int TO = TK, int OTX = 0>
 struct Layer16B3Geom {
     static_assert(TK % 2 == 0 && TO % 2 == 0, "k-steps of two input tiles; output tiles in pairs");
     static constexpr int KS = TK / 2;                       // k-steps of 32 input features
-    static constexpr int OT = TO >= 8 ? 8 : TO;             // output tiles per slice
+    static constexpr int OT = OTX ? OTX : (TO >= 8 ? 8 : TO);   // output tiles per slice (the image does not depend on it: [ks][to][plane])
     static constexpr int SPK = TO / OT;                     // slices per k-step
     static constexpr int NS = KS * SPK;
     static constexpr int SLICE = OT * 3 * 256;              // floats: 3 KB per output tile (three planes of 64 lanes x 16 bytes)
@@ -300,11 +300,15 @@ __device__ inline void pack16_b3_layer(unsigned short* __restrict__ dst, const f
     }
 }
 
-template <int TK, int TO, int ACT, bool HAS_BIAS>
+// OTX: output tiles per slice (0: 8, or all of a narrower layer); NB: slice buffers in the caller's region (NB * SLICE floats) --
+// slice s + NB - 1 is requested while slice s multiplies.
+template <int TK, int TO, int ACT, bool HAS_BIAS, int OTX = 0, int NB = 3>
 __device__ __forceinline__ void layer16r_b3(const float* __restrict__ gimg, const float* __restrict__ bias, float* __restrict__ wbuf,
                                             int lane, int tid, const f32x4 (&in)[TK], f32x4 (&out)[TO]) {
-    using G = Layer16B3Geom<TK, TO>;
+    using G = Layer16B3Geom<TK, TO, OTX>;
     constexpr int OT = G::OT, SPK = G::SPK, NS = G::NS, SLICE = G::SLICE, PER = G::PER;
+    constexpr int AHEAD = (NB < NS ? NB : NS) - 1;   // slices requested beyond the one being multiplied
+    static_assert(NB >= 2 && NB <= 5 && (AHEAD - 1) * PER < 64, "vmcnt is a 6-bit counter; the counted waits cover three younger slices");
     const int g = lane >> 4;
     const int wave_base = (tid >> 6) * 256;   // floats: this wave's 1 KB piece inside every 4 KB of a slice
     const unsigned voff = (unsigned)tid * 16u;
@@ -312,31 +316,31 @@ __device__ __forceinline__ void layer16r_b3(const float* __restrict__ gimg, cons
         const unsigned long long u = reinterpret_cast<unsigned long long>(gimg + slice * SLICE);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
         const char* sbase = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
-        float* ldst = wbuf + (slice % 3) * SLICE + wave_base;
+        float* ldst = wbuf + (slice % NB) * SLICE + wave_base;
 #pragma unroll
         for (int p = 0; p < PER; ++p)
             __builtin_amdgcn_global_load_lds((glb_void_ptr)(sbase + p * (k16Threads * 16) + voff),
                                              (lds_void_ptr)(ldst + p * k16Threads * 4), 16, 0, 0);
     };
-    dma_slice(0);
-    if constexpr (NS > 1) dma_slice(1);
+#pragma unroll
+    for (int s0 = 0; s0 < (AHEAD > 0 ? AHEAD : 1); ++s0) dma_slice(s0);
 #pragma unroll
     for (int t = 0; t < TO; ++t) {
         if constexpr (HAS_BIAS) out[t] = *reinterpret_cast<const f32x4*>(bias + t * 16 + 4 * g);
         else out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if constexpr (NS > 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // slice 0 landed (slice 1 may still fly)
+    wait_vmcnt<(AHEAD > 1 ? AHEAD - 1 : 0) * PER>();   // slice 0 landed (the younger requests may still fly)
     PIME16_BARRIER();
     bf16x8 bh, bm, bl;       // the activation operand of the current k-step
     bf16x8 wf[2][6];         // fragments of two output tiles (hi, mid, lo each), double-buffered
     auto load_pair = [&](int slice, int pr, bf16x8 (&dst)[6]) {
-        const bf16x8* wl = reinterpret_cast<const bf16x8*>(wbuf + (slice % 3) * SLICE) + lane;
+        const bf16x8* wl = reinterpret_cast<const bf16x8*>(wbuf + (slice % NB) * SLICE) + lane;
 #pragma unroll
         for (int m = 0; m < 6; ++m) dst[m] = wl[(pr * 6 + m) * 64];
     };
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        if (s + 2 < NS) dma_slice(s + 2);
+        if (AHEAD > 0 && s + AHEAD < NS) dma_slice(s + AHEAD);   // into the buffer of slice s - 1, which every wave has left
         load_pair(s, 0, wf[0]);
         if (s % SPK == 0) {   // a new k-step: input tiles 2 ks, 2 ks + 1 in three bf16 pieces
             const int ks = s / SPK;
@@ -372,8 +376,15 @@ __device__ __forceinline__ void layer16r_b3(const float* __restrict__ gimg, cons
             out[t0] = c0; out[t0 + 1] = c1;
             __builtin_amdgcn_sched_barrier(0);
         }
-        // slice s+1 must have landed before the barrier publishes it; the DMA of slice s+2 (the PER youngest) may still fly
-        if (s + 2 < NS) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+        // slice s+1 must have landed before the barrier publishes it; the requests younger than it may still fly
+        {
+            const int last = s + AHEAD < NS - 1 ? s + AHEAD : NS - 1;   // youngest slice requested so far
+            const int younger = last > s + 1 ? last - (s + 1) : 0;
+            if (younger == 0) wait_vmcnt<0>();
+            else if (younger == 1) wait_vmcnt<PER>();
+            else if (younger == 2) wait_vmcnt<(2 * PER < 64 ? 2 * PER : 0)>();
+            else wait_vmcnt<(3 * PER < 64 ? 3 * PER : 0)>();
+        }
         PIME16_BARRIER();   // slice s+1 published; slice s's reads retired (after the last slice: wbuf is free again)
     }
 #pragma unroll
@@ -382,9 +393,10 @@ __device__ __forceinline__ void layer16r_b3(const float* __restrict__ gimg, cons
         for (int r = 0; r < 4; ++r) out[t][r] = act16<ACT>(out[t][r]);
 }
 
-template <int TK, int TO = TK>
+template <int TK, int TO = TK, int OTX = 0, int NB = 3>
 __host__ __device__ constexpr int layer16_b3_lds_floats() {
-    return Layer16B3Geom<TK, TO>::NBUFW * Layer16B3Geom<TK, TO>::SLICE;
+    using G = Layer16B3Geom<TK, TO, OTX>;
+    return (G::NS < NB ? G::NS : NB) * G::SLICE;
 }
 
 // The bf16x3 planes of a net's streamed layers sit BEHIND its transposed f32 image (img_bwd + layoutb16(md).total): forward layers,

@@ -35,6 +35,52 @@ __global__ __launch_bounds__(k16Threads, 2) void bench_kernel(const float* __res
     for (int t = 0; t < T; ++t) yp[t] = out[t];
 }
 
+// The same layer with ONE workgroup per compute unit (the width-256 gradient kernels' situation: a wave alone on its SIMD), for
+// slice shapes (OTX output tiles per slice) and buffer counts NB of layer16r_b3; OTX < 0: the f32 layer.
+template <int T, int OTX, int NB>
+__global__ __launch_bounds__(k16Threads, 1) void bench1_kernel(const float* __restrict__ img, const float* __restrict__ x,
+                                                                float* __restrict__ y, int reps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t tile = (size_t)blockIdx.x * k16Waves + wave;
+    f32x4 in[T], out[T];
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x) + (tile * 64 + lane) * T;
+#pragma unroll
+    for (int t = 0; t < T; ++t) in[t] = xp[t];
+    for (int rep = 0; rep < reps; ++rep) {
+        if constexpr (OTX >= 0) layer16r_b3<T, T, 2, false, OTX, NB>(img, nullptr, lds, lane, tid, in, out);
+        else layer16r<T, T, 2, false>(img, nullptr, lds, lane, tid, in, out);
+        if (rep + 1 < reps)
+#pragma unroll
+            for (int t = 0; t < T; ++t) in[t] = out[t] * 0.05f;
+    }
+    f32x4* yp = reinterpret_cast<f32x4*>(y) + (tile * 64 + lane) * T;
+#pragma unroll
+    for (int t = 0; t < T; ++t) yp[t] = out[t];
+}
+
+template <int T, int OTX, int NB>
+static void run1(const char* name, const float* img, const float* dx, float* dy, int N) {
+    const int grid = 256, reps = 400, MD = T * 16;
+    const size_t lds = 120 * 1024;   // the gradient kernels' region at width 256; > 80 KB: one workgroup per compute unit
+    hipFuncSetAttribute((const void*)bench1_kernel<T, OTX, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int it = 0; it < 4; ++it) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((bench1_kernel<T, OTX, NB>), dim3(grid), dim3(k16Threads), lds, 0, img, dx, dy, reps);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    (void)N;
+    printf("width %3d one workgroup per CU  %-22s %6.2f us per layer (64 samples): %.1f TFLOP/s f32-equivalent\n", MD, name,
+           best * 1e3 / reps, 2.0 * MD * MD * 64.0 * grid * reps / (best * 1e-3) / 1e12);
+}
+
 template <int T>
 static int run() {
     constexpr int MD = T * 16;
@@ -134,6 +180,14 @@ static int run() {
                which ? "bf16x3" : "f32", best, reps, N, tf[which], which ? lds_b3 : lds_f32);
     }
     printf("width %3d bf16x3 / f32 = %.2fx\n", MD, tf[1] / tf[0]);
+    run1<T, -1, 3>("f32", dimg, dx, dy, N);
+    run1<T, 0, 3>("bf16x3 8 tiles x 3", (const float*)dpl, dx, dy, N);
+    run1<T, 0, 4>("bf16x3 8 tiles x 4", (const float*)dpl, dx, dy, N);
+    run1<T, 0, 5>("bf16x3 8 tiles x 5", (const float*)dpl, dx, dy, N);
+    if constexpr (T == 16) {
+        run1<T, 16, 2>("bf16x3 16 tiles x 2", (const float*)dpl, dx, dy, N);
+        run1<T, 4, 5>("bf16x3 4 tiles x 5", (const float*)dpl, dx, dy, N);
+    }
     hipFree(dimg); hipFree(dx); hipFree(dy); hipFree(dpl);
     return bad;
 }
