@@ -986,37 +986,49 @@ __device__ __forceinline__ void dw16_sliced_b3(float* __restrict__ X, int lane, 
             for (int y = 0; y < NB; ++y) acc[x][y] = accum ? *slab_ptr(p, x, y) : f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};   // bias gradient of A tile 4p + wave: column sums, as a product with an all-ones operand
         PIME16_BARRIER();              // the slice (first pass: and the B image) is visible
+        // eight steps (k-step ks, A tile x); the A fragments of step + 1 are requested one block (six MFMAs) into step: hipcc waits for
+        // every LDS read in flight in front of the first MFMA that uses a fresh fragment, so a request right in front of its use
+        // is a fully exposed LDS round trip -- ten per pass before this ordering, four now
+        bf16x8 af[2][3], bf[NB][3];
+        auto load_a = [&](int step, bf16x8 (&dst)[3]) {
+            const int r0 = 32 * (step >> 2) + 8 * g + q, x = step & 3;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int r0 = 32 * ks + 8 * g + q, r1 = r0 + 4;
-            bf16x8 bf[NB][3];
+            for (int pl = 0; pl < 3; ++pl) dst[pl] = frag(Aimg, P::aoff(pl, r0, x, 8 * p4), P::aoff(pl, r0 + 4, x, 8 * p4));
+        };
+        load_a(0, af[0]);
 #pragma unroll
-            for (int y = 0; y < NB; ++y)
+        for (int step = 0; step < 2 * NA; ++step) {
+            const int ks = step >> 2, x = step & 3, cur = step & 1;
+            if (x == 0) {
+                const int r0 = 32 * ks + 8 * g + q;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    bf[y][pl] = frag(Bimg, P::boff(pl, r0, wave * NB + y, 8 * p4), P::boff(pl, r1, wave * NB + y, 8 * p4));
+                for (int y = 0; y < NB; ++y)
 #pragma unroll
-            for (int x = 0; x < NA; ++x) {
-                bf16x8 af[3];
+                    for (int pl = 0; pl < 3; ++pl)
+                        bf[y][pl] = frag(Bimg, P::boff(pl, r0, wave * NB + y, 8 * p4), P::boff(pl, r0 + 4, wave * NB + y, 8 * p4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[pl] = frag(Aimg, P::aoff(pl, r0, x, 8 * p4), P::aoff(pl, r1, x, 8 * p4));
-#pragma unroll
-                for (int y = 0; y < NB; ++y) {
-                    f32x4 c = acc[x][y];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[y][0], c, 0, 0, 0);   // the small terms first
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[y][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[y][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[y][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[y][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[y][0], c, 0, 0, 0);
-                    acc[x][y] = c;
-                }
-                if (gb && x == wave) {
-                    bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], ones, bacc, 0, 0, 0);
-                    bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], ones, bacc, 0, 0, 0);
-                    bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], ones, bacc, 0, 0, 0);
+            for (int y = 0; y < NB; ++y) {
+                f32x4 c = acc[x][y];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][2], bf[y][0], c, 0, 0, 0);   // the small terms first
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][0], bf[y][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][1], bf[y][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][1], bf[y][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][0], bf[y][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][0], bf[y][0], c, 0, 0, 0);
+                acc[x][y] = c;
+                if (y == 0) {
+                    if (step + 1 < 2 * NA) load_a(step + 1, af[cur ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (gb && x == wave) {
+                bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][2], ones, bacc, 0, 0, 0);
+                bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][1], ones, bacc, 0, 0, 0);
+                bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][0], ones, bacc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // one 16-byte store per lane and block (a wave writes 1 KB contiguous)
 #pragma unroll
