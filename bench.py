@@ -232,7 +232,7 @@ def emit(json_fd, out):
         variants.append("PIME_GRAD_BF16X3=1: the streamed layers of the 16-tile gradient kernels (widths 128 / 256) as six "
                         "v_mfma_f32_16x16x32_bf16 per product block, every f32 operand split into three bf16 pieces (f32-level "
                         "error; roofline.achieved stays f32-equivalent flops against the f32 matrix peak)")
-        out["dtype"] = "f32 (bf16x3 matrix products in the streamed gradient layers)"
+        out["dtype"] = "f32 (3xbf16 split operands, f32 accumulate)"
     if variants:
         out.setdefault("config", {})["variant"] = "; ".join(variants)
     os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -254,9 +254,30 @@ def grad_roofline(agent, update, D, md, kernel):
     n_g, ms_g = timer.summary()["ppo_minibatch_grad"]
     flops = 2 * 3 * 2 * (D * md + 2 * md * md + md) * BATCH
     tf = flops / (ms_g * 1e-3) / 1e12
-    return {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launches_per_step": n_g, "avg_launch_ms": ms_g,
-            "algorithmic_flops_per_launch": flops}
+    out = {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launches_per_step": n_g, "avg_launch_ms": ms_g,
+           "algorithmic_flops_per_launch": flops}
+    share = bf16x3_share(md)
+    if share > 0:   # the opt-in variant: its own peak = what six bf16 MFMAs per f32 product allow on the share of the flops that take them
+        peak = 1.0 / (share / (BF16_MFMA_PEAK_TFLOPS / 6.0) + (1.0 - share) / F32_MFMA_PEAK_TFLOPS)
+        out.update({"peak": peak, "frac": tf / peak, "frac_of_f32_peak": tf / F32_MFMA_PEAK_TFLOPS,
+                    "peak_note": f"bf16x3: {share:.2f} of the flops as six v_mfma_f32_16x16x32_bf16 per product block "
+                                 f"({BF16_MFMA_PEAK_TFLOPS:.0f} / 6 = {BF16_MFMA_PEAK_TFLOPS / 6:.1f} TFLOP/s f32-equivalent), the rest f32 MFMA "
+                                 f"({F32_MFMA_PEAK_TFLOPS}); achieved counts f32-equivalent flops"})
+    return out
+
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (MI355X_MICROARCH.md)
+
+
+def bf16x3_share(md):
+    """Share of a minibatch gradient's flops that the opt-in PIME_GRAD_BF16X3=1 variant runs on bf16 matrix instructions: the streamed
+    chain layers (2/3: forward and dX) at widths 128 / 256 of the 16-tile family, plus the weight gradients at width 256."""
+    if os.environ.get("PIME_GRAD_BF16X3", "0") in ("", "0"):
+        return 0.0
+    if md == 256:
+        return 1.0
+    return 2.0 / 3.0 if md == 128 and os.environ.get("PIME_MLP16") else 0.0
 
 
 def bench_water_tank(args, device, json_fd):
@@ -765,6 +786,17 @@ def main():
                                       "FETCH_SIZE x2)" if traffic_src else None,
                     "launches_per_step": n_dom / args.steps, "avg_launch_ms": ms_dom,
                     "algorithmic_flops_per_launch": GRAD_FLOPS_PER_SAMPLE * BATCH}
+        if os.environ.get("PIME_MLP16"):   # the 16-tile family serves this width: other kernels, no PMC file of theirs
+            roofline["kernel"] = ("ppo_minibatch_grad = ppo16m_kernel<8> (modular actor) + ppo16_kernel<8> (critic) + ppo_grad_reduce_kernel "
+                                  "(PIME_MLP16=1: the streamed 16-tile family at width 128)")
+            roofline["traffic"], roofline["traffic_source"] = None, None
+        share = bf16x3_share(NET_DIM)
+        if share > 0:
+            peak = 1.0 / (share / (BF16_MFMA_PEAK_TFLOPS / 6.0) + (1.0 - share) / F32_MFMA_PEAK_TFLOPS)
+            roofline.update({"peak": peak, "frac": achieved / peak, "frac_of_f32_peak": achieved / F32_MFMA_PEAK_TFLOPS,
+                             "peak_note": f"bf16x3: {share:.2f} of the flops as six v_mfma_f32_16x16x32_bf16 per product block "
+                                          f"({BF16_MFMA_PEAK_TFLOPS / 6:.1f} TFLOP/s f32-equivalent), the rest f32 MFMA; achieved counts "
+                                          "f32-equivalent flops"})
     elif "critic" in dominant or "actor" in dominant:
         kind = "critic" if "critic" in dominant else "modular_actor"
         rows = LANES * T_EP if kind == "critic" else LANES

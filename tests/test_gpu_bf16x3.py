@@ -35,7 +35,40 @@ for kind, md, D in (("modular", 128, 3), ("resid", 128, 3), ("resid", 256, 3)):
 import test_gpu_update_golden as u   # the UNMODIFIED reference's weights after a whole update_net, same tolerances as the f32 path
 for tag, mode in (("wts10_256", "one_graph"), ("wtmod256", "two_graph"), ("ph128", "one_graph")):
     u.test_hip_update_net_matches_reference_weights(tag, mode)
+for case in ("mw", "big"):   # the reference's own first-step .grad tensors, multi-workgroup / slab-accumulating batches (width 128)
+    u.test_multi_workgroup_update_against_reference_gradients(case)
 print("BF16X3_OK")
+'''
+
+# One minibatch gradient against FLOAT64 autograd of the same loss on the same minibatch: max and rms error of every net's flat
+# gradient, relative to that gradient's largest entry.  Run once per path (child processes), reported side by side.
+_ERR_CHILD = r'''
+import copy, json, os, sys
+sys.path.insert(0, os.environ["PIME_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PIME_ROOT"], "tests"))
+import torch
+from pime_amd import ops
+from test_gpu_ppo_fused import _data, _make, _torch_grads, DEV
+out = {}
+for kind, md, D, B in (("resid", 128, 3, 16384), ("modular", 128, 4, 16384), ("resid", 256, 30, 16384), ("modular", 256, 4, 16384)):
+    act, cri = _make(kind, md, D, seed=B + md)
+    L = 3 * B
+    state, action, logprob, adv, r_sum = _data(L, D, act, seed=1)
+    idx = torch.randint(L, (B,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    act64, cri64 = copy.deepcopy(act).double(), copy.deepcopy(cri).double()
+    want = _torch_grads(act64, cri64, state.double(), action.double(), logprob.double(), adv.double(), r_sum.double(), idx, 0.2, 0.02)[0]
+    fused = ops.FusedPPOGrad(act, cri, B)
+    fused.zero_grad()
+    fused(state, action.reshape(-1).contiguous(), logprob, adv, r_sum, idx, 0.2, 0.02, torch.zeros(1, device=DEV))
+    torch.cuda.synchronize()
+    got = {n: p.grad for n, p in list(act.named_parameters()) + [("cri." + k, v) for k, v in cri.named_parameters()] if p.requires_grad}
+    for net in ("act", "cri"):
+        names = [n for n in want if n.startswith("cri.") == (net == "cri")]
+        w = torch.cat([want[n].reshape(-1) for n in names])
+        g = torch.cat([got[n].double().reshape(-1) for n in names])
+        d = (g - w).abs() / w.abs().max()
+        out[f"{kind}{md}.{net}"] = {"max": float(d.max()), "rms": float(d.pow(2).mean().sqrt()), "p99": float(torch.quantile(d, 0.99)),
+                                    "far": float((d > 2e-6).double().mean())}
+print("GRAD_ERR " + json.dumps(out))
 '''
 
 
@@ -50,3 +83,35 @@ def test_bf16x3_gradients_match_autograd_and_repeat_bitwise():
           ("modular", 128, 3, 4096), ("modular", 128, 4, 1000), ("modular", 128, 4, 40000),
           ("resid", 256, 30, 4096), ("resid", 256, 3, 777), ("modular", 256, 4, 4096), ("modular", 256, 3, 1000)],
          {"PIME_GRAD_BF16X3": "1"})
+
+
+def test_gradient_error_against_float64_autograd_is_reported_for_both_paths():
+    """max / rms error of one minibatch gradient against float64 autograd, f32 MFMA path and bf16x3 path side by side (both through the
+    16-tile family: PIME_MLP16=1).  The variant's contract is "f32-level error": the 99th percentile of its error may not exceed twice
+    the f32 path's (in practice it is at or below it -- six exact bf16 products summed in f32 round less often than a chain of f32
+    FMAs)."""
+    import json
+    res = {}
+    for name, extra in (("f32", {}), ("bf16x3", {"PIME_GRAD_BF16X3": "1"})):
+        env = dict(os.environ, PIME_ROOT=ROOT, PIME_MLP16="1", **extra)
+        env.pop("PIME_GRAD_BF16X3", None) if not extra else None
+        r = subprocess.run([sys.executable, "-c", _ERR_CHILD], env=env, capture_output=True, text=True, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("GRAD_ERR ")]
+        assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-4000:]
+        res[name] = json.loads(line[-1][len("GRAD_ERR "):])
+    rows = []
+    for key in res["f32"]:
+        a, b = res["f32"][key], res["bf16x3"][key]
+        rows.append(f"{key:16s} f32 p99 {a['p99']:.2e} rms {a['rms']:.2e} max {a['max']:.2e} | bf16x3 p99 {b['p99']:.2e} rms {b['rms']:.2e} "
+                    f"max {b['max']:.2e} (entries beyond 2e-6: {b['far']:.4f})")
+        # p99, not max: the critic is a ReLU net, and a unit whose pre-activation is within rounding of zero for ONE sample flips its
+        # mask between any two float evaluations -- that sample's whole contribution to the unit's weight row (1 / B of the gradient,
+        # ~1e-5 of its largest entry at B = 16 384) then differs.  Either path shows such rows against float64 for some seeds; they
+        # say nothing about the products' precision.  At most one row per hundred may be such a row.
+        assert b["p99"] <= max(2.0 * a["p99"], 5e-7), rows[-1]
+        assert b["far"] <= 0.01, rows[-1]
+    report = "\n".join(rows)
+    print("\ngradient error / max |gradient| against float64 autograd (B = 16 384):\n" + report)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bf16x3_gradient_error.txt"), "w") as f:
+        f.write("gradient error / max |gradient| against float64 autograd of the same minibatch (B = 16 384), tests/test_gpu_bf16x3.py\n" + report + "\n")

@@ -141,15 +141,18 @@ static int run() {
     std::vector<float> Y(Xd.size());
     auto err = [&](const char* name) {
         hipMemcpy(Y.data(), dy, Y.size() * 4, hipMemcpyDeviceToHost);
-        double mx = 0, ss = 0;
+        double mx = 0, ss = 0, sb = 0;   // sb: the SIGNED error along the result's sign (a rounding that truncates shows up here)
         for (int f = 0; f < MD; ++f)
             for (int c = 0; c < NSAMP; ++c) {
                 const int t = f >> 4, g = (f & 15) >> 2, r = f & 3, tile = c >> 4, lane = (c & 15) + 16 * g;
-                const double d = fabs((double)Y[(((size_t)tile * 64 + lane) * T + t) * 4 + r] - ref[(size_t)f * NSAMP + c]);
+                const double rv = ref[(size_t)f * NSAMP + c];
+                const double e = (double)Y[(((size_t)tile * 64 + lane) * T + t) * 4 + r] - rv, d = fabs(e);
                 mx = fmax(mx, d);
                 ss += d * d;
+                sb += rv >= 0 ? e : -e;
             }
-        printf("width %3d %-7s max |err| / max |y| = %.3e   rms err / max |y| = %.3e\n", MD, name, mx / ymax, sqrt(ss / ((double)MD * NSAMP)) / ymax);
+        printf("width %3d %-7s max |err| / max |y| = %.3e   rms err / max |y| = %.3e   mean signed err (towards larger |y|) / max |y| = %+.3e\n", MD,
+               name, mx / ymax, sqrt(ss / ((double)MD * NSAMP)) / ymax, sb / ((double)MD * NSAMP) / ymax);
         return mx / ymax;
     };
     int bad = 0;
