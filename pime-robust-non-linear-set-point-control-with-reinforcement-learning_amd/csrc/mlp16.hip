@@ -898,7 +898,9 @@ __device__ __forceinline__ void dw16_sliced(float* __restrict__ X, int lane, int
 // Images: B [plane][sample 0..63][16 tiles x 32 bytes] = 96 KB, published once; A one 4-tile slice per pass [plane][sample][4 x 32 B]
 // = 24 KB (single buffer: with both images padded or double-buffered the map does not fit beside a 32 KB first-layer image).
 // Rows are unpadded; the 32-byte chunk (= tile) index is XOR-swizzled with row bits so that the eight rows a 32-lane half reads
-// (samples 4 hh + q and 8 + 4 hh + q) fall on distinct banks.  Patch assignment and slab layout as dw16_sliced.
+// (samples 4 hh + q and 8 + 4 hh + q) fall on distinct banks, and the 8-byte piece inside a chunk with row bits 2..3 so that the
+// publishers' ds_write_b64 (16 rows x 2 pieces per 32-lane half) are 2-way instead of 4-way (the transposing read takes whatever
+// address a lane supplies for "row q, columns 4p .. 4p+3").  Patch assignment and slab layout as dw16_sliced.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int T>
 struct Dw16SlicedB3 {
@@ -909,10 +911,10 @@ struct Dw16SlicedB3 {
     static constexpr int FLOATS = (BBYTES + ABYTES) / 4;
     // byte offset of (plane, sample row, tile, byte inside the tile's 32)
     __device__ static __forceinline__ int boff(int plane, int row, int tile, int sub) {
-        return (plane * ROWS + row) * BROW + ((tile ^ ((row & 3) | ((row >> 1) & 4))) << 5) + sub;
+        return (plane * ROWS + row) * BROW + ((tile ^ ((row & 3) | ((row >> 1) & 4))) << 5) + (sub ^ (((row >> 2) & 3) << 3));
     }
     __device__ static __forceinline__ int aoff(int plane, int row, int tile4, int sub) {
-        return (plane * ROWS + row) * AROW + ((tile4 ^ (((row >> 1) & 1) | ((row >> 2) & 2))) << 5) + sub;
+        return (plane * ROWS + row) * AROW + ((tile4 ^ (((row >> 1) & 1) | ((row >> 2) & 2))) << 5) + (sub ^ (((row >> 2) & 3) << 3));
     }
 };
 
