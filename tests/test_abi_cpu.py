@@ -115,3 +115,45 @@ def test_capture_flag_entry_points_work_without_a_gpu():
     with nt.capture_guard():
         assert L.pime_deferred_releases() == 0
     assert L.pime_deferred_releases() == 0
+
+
+def test_bf16x3_switch_only_grows_the_transposed_image_of_the_16_tile_family():
+    """PIME_GRAD_BF16X3 is read once per process by the library: child processes.  Without it pime_ppo_bwd_image_f32_floats ==
+    pime_ppo_bwd_image_floats everywhere; with it the nets the 16-tile family serves at width 128 (PIME_MLP16=1) / 256 carry their
+    chain layers' three bf16 planes behind the f32 image -- 1.5x the f32 floats per layer and direction (csrc/mlp16.hip:
+    layout_b3_16 / layout_b3_16m) -- and nothing else changes size (host-side size functions: no GPU needed)."""
+    import json
+    import subprocess
+    import sys
+    child = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["PIME_ROOT"])
+from pime_amd import native as nt
+L = nt.lib()
+out = {}
+for name, kind, D, Di, md in (("cri128", nt.MLP_CRITIC, 3, 0, 128), ("mod128", nt.MLP_MODULAR_ACTOR, 4, 1, 128), ("cri256", nt.MLP_CRITIC, 30, 0, 256),
+                              ("mod256", nt.MLP_MODULAR_ACTOR, 4, 1, 256), ("cri64", nt.MLP_CRITIC, 3, 0, 64)):
+    out[name] = [L.pime_ppo_bwd_image_f32_floats(kind, D, Di, md), L.pime_ppo_bwd_image_floats(kind, D, Di, md), L.pime_ppo_fwd_image_floats(kind, D, Di, md)]
+print("SIZES " + json.dumps(out))
+'''
+    res = {}
+    for tag, extra in (("off", {}), ("mlp16", {"PIME_MLP16": "1"}), ("on", {"PIME_MLP16": "1", "PIME_GRAD_BF16X3": "1"}),
+                       ("on_default_family", {"PIME_GRAD_BF16X3": "1"})):
+        env = {k: v for k, v in os.environ.items() if k not in ("PIME_MLP16", "PIME_GRAD_BF16X3")}
+        env.update(PIME_ROOT=ROOT, **extra)
+        r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("SIZES ")]
+        assert r.returncode == 0 and line, r.stdout[-1000:] + r.stderr[-2000:]
+        res[tag] = json.loads(line[-1][6:])
+    for tag in ("off", "mlp16"):
+        for name, (f32, total, _) in res[tag].items():
+            assert f32 == total > 0, (tag, name)
+    planes = lambda md, layers_sq, layers_half: (md // 32) * (md // 16) * 768 * layers_sq + (md // 32) * (md // 32) * 768 * layers_half
+    on, base = res["on"], res["mlp16"]
+    assert on["cri128"] == [base["cri128"][0], base["cri128"][1] + planes(128, 4, 0), base["cri128"][2]]
+    assert on["mod128"] == [base["mod128"][0], base["mod128"][1] + planes(128, 2, 4), base["mod128"][2]]
+    assert on["cri256"] == [base["cri256"][0], base["cri256"][1] + planes(256, 4, 0), base["cri256"][2]]
+    assert on["mod256"] == [base["mod256"][0], base["mod256"][1] + planes(256, 2, 4), base["mod256"][2]]
+    assert on["cri64"] == base["cri64"]                                  # width 64: no variant
+    d = res["on_default_family"]                                          # without PIME_MLP16 width 128 stays on the LDS-resident kernels
+    assert d["cri128"] == res["off"]["cri128"] and d["mod128"] == res["off"]["mod128"] and d["cri256"] == on["cri256"]
