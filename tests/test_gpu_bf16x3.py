@@ -6,7 +6,7 @@ check_grads); the optimizer step fused into the slab reduction leaves the bf16 p
 whole update_net calls against the weights the unmodified reference produced (tests/golden/ppo_update*.npz: width 256 plain and
 modular, width 128 modular) at the f32 path's tolerances.
 Child processes: both switches are read once per process.  The layer alone against float64: tools/layer16_b3_bench.hip
-(profiles/r04_l_layer16_b3_bench.txt: 3.5e-7 of max |y|, the f32 chain 4.0e-7)."""
+(profiles/r04_n_layer16_b3_bench.txt: 3.5e-7 of max |y|, the f32 chain 4.0e-7)."""
 import os
 import subprocess
 import sys

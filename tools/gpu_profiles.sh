@@ -28,7 +28,7 @@ PIME_MLP16=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/${TAG}_b
 PIME_MLP16=1 PIME_GRAD_BF16X3=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_bf16x3.json 2>/dev/null || exit 1
 python -c "
 import json
-for f in ("ph_mlp16", "bf16x3"):
+for f in ('ph_mlp16', 'bf16x3'):
     d = json.load(open('$OUT/${TAG}_bench_' + f + '.json')); print(f, round(d['value'] / 1e6, 2), 'M env-steps/s, minibatch gradient', round(d['roofline']['avg_launch_ms'] * 1e3, 1), 'us')"
 PIME_GRAD_BF16X3=1 timeout -k 10 300 bash tools/profile_bench.sh ${TAG}_wt256_bf16x3 --workload wt256 || exit 1
 if [ -x tools/bin/layer16_b3_bench ]; then
