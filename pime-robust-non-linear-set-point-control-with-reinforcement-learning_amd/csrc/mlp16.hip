@@ -362,7 +362,8 @@ __device__ __forceinline__ void layer16r_b3(const float* __restrict__ gimg, cons
             // of a pair's first MFMA whatever is outstanding, so reads issued right in front of that wait sit exposed; half a pair
             // earlier they have landed (+5 %).  Hand-placed reads two pairs ahead with counted waits (asm) were bit-identical and
             // SLOWER, as were more or larger slice buffers (tools/layer16_b3_bench.hip): on random data the layer runs at ~1.7 PFLOP/s
-            // of bf16 products, 70 % of the matrix peak, whichever of those pipelines feeds it.
+            // of bf16 products, 70 % of the matrix peak (matrix pipe busy 0.55 - 0.71 of the cycles at an unchanged clock:
+            // profiles/r04_o_layer16_b3_bench_pmc.txt), whichever of those pipelines feeds it.
             const bf16x8 (&w)[6] = wf[cur];   // [0..2] = hi, mid, lo of tile t0; [3..5] of tile t0 + 1
             f32x4 c0 = out[t0], c1 = out[t0 + 1];
             c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], bh, c0, 0, 0, 0);   // the small terms first
