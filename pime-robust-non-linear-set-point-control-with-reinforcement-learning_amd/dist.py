@@ -182,14 +182,18 @@ class DataParallel:
         if extra is not None:
             grads = grads + [extra.to(device=grads[0].device, dtype=grads[0].dtype)]
         n = sum(g.numel() for g in grads)
-        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
-            self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
-        torch.cat([g.reshape(-1) for g in grads], out=self._flat)
-        td.all_reduce(self._flat, op=td.ReduceOp.SUM)
-        self._flat.div_(self.world)
+        key = (n, grads[0].device, grads[0].dtype)   # one staging buffer per gradient set (TD3 alternates critic / actor)
+        if not isinstance(self._flat, dict):
+            self._flat = {}
+        flat = self._flat.get(key)
+        if flat is None:
+            flat = self._flat[key] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        torch.cat([g.reshape(-1) for g in grads], out=flat)
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        flat.div_(self.world)
         off = 0
         for g in grads:
-            g.copy_(self._flat[off:off + g.numel()].view_as(g))
+            g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
         return grads[-1] if extra is not None else None
 

@@ -892,9 +892,16 @@ class AgentTD3(AgentBase):
         return self.criterion(q1, q_label) + self.criterion(q2, q_label), state
 
     def _one_update(self, buffer, batch_size, soft):
+        """One iteration of the reference's loop (agent.py:314-331).  Data parallel (the reference has no collective): every rank
+        samples its own minibatch from its own lanes and the gradients of BOTH backward passes are averaged before their optimizer
+        step -- the two means over batch_size samples become the means over the union of the ranks' minibatches, so G ranks make the
+        step of one rank on a G x batch_size minibatch (tests/test_dist_gloo.py) and the replicas stay identical.  Two all-reduces per
+        step: the actor's objective needs the critic's step applied."""
         obj_critic, state = self.get_obj_critic(buffer, batch_size)
         self.cri_optimizer.zero_grad(set_to_none=False)
         obj_critic.backward()
+        if self.dp is not None:
+            self.dp.average_gradients([p for p in self.cri.parameters() if p.grad is not None])
         self.cri_optimizer.step()
         tp = self._tpacks or None
         if soft:
@@ -904,6 +911,8 @@ class AgentTD3(AgentBase):
         obj_actor = -self.cri_target(state, self.act(state)).mean()
         self.act_optimizer.zero_grad(set_to_none=False)
         obj_actor.backward()
+        if self.dp is not None:
+            self.dp.average_gradients([p for p in self.act.parameters() if p.grad is not None])
         self.act_optimizer.step()
         if soft:
             self.soft_update(self.act_target, self.act, self.soft_update_tau)
@@ -921,11 +930,12 @@ class AgentTD3(AgentBase):
             return self._update_fused(fused, buffer, n_steps, batch_size, int(target_step if not vec else n_steps))
         sums = torch.zeros(2, device=dev)
         obj_actor = obj_critic = torch.zeros((), device=dev)
-        graphs = self._graphs if (vec and self.use_hip_graphs and dev.type == "cuda") else None
+        use_graphs = vec and self.use_hip_graphs and dev.type == "cuda" and self.dp is None   # (the all-reduces run eagerly)
+        graphs = self._graphs if use_graphs else None
         key = (id(buffer), batch_size)
         for i in range(n_steps):
             soft = i % self.update_freq == 0
-            if vec and self.use_hip_graphs and dev.type == "cuda" and (i >= 2 or (graphs and graphs.get("key") == key)):
+            if use_graphs and (i >= 2 or (graphs and graphs.get("key") == key)):
                 # the step's launch sequence is fixed once Adam's state exists (two eager steps): capture it twice (with /
                 # without the delayed soft update) and replay.  The sampler reads its index bounds from the device
                 # (VecReplayBuffer._bounds), so the two graphs serve every later call as well.

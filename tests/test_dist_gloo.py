@@ -234,3 +234,77 @@ def test_data_parallel_update_equals_one_rank_on_the_union_minibatch(tmp_path, w
     for k in range(1, world):
         assert torch.equal(r[0]["flat"], r[k]["flat"]), "replicas diverged"
     np.testing.assert_allclose(r[0]["flat"].numpy(), r[0]["solo"].numpy(), rtol=0, atol=2e-6)
+
+
+class _ListBuffer:
+    """A replay buffer that hands out prepared minibatches: (reward, mask, action, state, next_state) per optimizer step."""
+
+    def __init__(self, batches):
+        self.batches, self.i = batches, 0
+
+    def update_now_len_before_sample(self):
+        pass
+
+    def sample_batch(self, batch_size):
+        b = self.batches[self.i]
+        self.i += 1
+        assert b[0].shape[0] == batch_size
+        return b
+
+
+def _td3_union_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from oracle.cpu_stack import OracleBackend
+    from pime_amd import dist as pdist
+    from pime_amd.elegantrl.agent import AgentTD3
+    dp = pdist.init_from_env(backend="gloo", device="cpu")
+    B, n_steps, D = 48, 4, 4
+
+    def make_agent():
+        torch.manual_seed(7)
+        ag = AgentTD3(backend=OracleBackend(), device="cpu")
+        ag.init(32, D, 1)
+        ag.policy_noise = 0.0      # no smoothing-noise draws: the union step is then a deterministic function of the minibatches
+        return ag
+
+    def batches(r):
+        g = torch.Generator().manual_seed(300 + r)
+        out = []
+        for _ in range(n_steps):
+            s = torch.randn(B, D, generator=g) * 2
+            out.append((-torch.rand(B, 1, generator=g) * 3, torch.where(torch.rand(B, 1, generator=g) < 0.1, 0.0, 0.99),
+                        torch.rand(B, 1, generator=g) * 2 - 1, s, s + 0.1 * torch.randn(B, D, generator=g)))
+        return out
+
+    agent = make_agent()
+    agent.dp = dp
+    mine = batches(rank)
+    agent.update_net(_ListBuffer(mine), n_steps, B, 1.0)   # a non-vector buffer: int(target_step * repeat_times) optimizer steps
+    nets = lambda a: torch.cat([p.detach().reshape(-1) for m in (a.act, a.cri, a.act_target, a.cri_target) for p in m.parameters()])
+    out = {"flat": nets(agent)}
+    if rank == 0:
+        solo = make_agent()
+        every = [batches(r) for r in range(world)]
+        union = [tuple(torch.cat([every[r][k][j] for r in range(world)]) for j in range(5)) for k in range(n_steps)]
+        solo.update_net(_ListBuffer(union), n_steps, B * world, 1.0)
+        out["solo"] = nets(solo)
+    torch.save(out, os.path.join(out_dir, f"td3_union_rank{rank}.pt"))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_td3_data_parallel_update_equals_one_rank_on_the_union_minibatch(tmp_path):
+    """AgentTD3.update_net under data parallelism (the reference has no collective): both backward passes of every optimizer step
+    (agent.py:314-331) are followed by an all-reduce (mean) of that net's gradients.  Two ranks with different minibatches end four
+    steps -- two of them with the delayed soft update -- bit-identical to each other and equal (2e-6) to ONE rank stepping on the
+    concatenated minibatches: online nets and targets."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_td3_union_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"td3_union_rank{k}.pt"), weights_only=True) for k in range(world)]
+    assert torch.equal(r[0]["flat"], r[1]["flat"]), "replicas diverged"
+    np.testing.assert_allclose(r[0]["flat"].numpy(), r[0]["solo"].numpy(), rtol=0, atol=2e-6)
