@@ -489,7 +489,7 @@ def launcher_selftest(json_fd):
         os.write(json_fd, (json.dumps({"selftest": "launcher", "n_gpus": got_world, "max_t": t, "sum": total}) + "\n").encode())
 
 
-def bench_water_tank_td3(args, device, json_fd):
+def bench_water_tank_td3(args, device, json_fd, rank=0, world=1, dp=None):
     """BASELINE config 2 as BASELINE.json words it: water-tank Integrator env, 4096 vectorised instances, residual TD3
     (AgentResidualTD3: composed from the reference's TD3 pieces).  One step = 200 lock-steps of all lanes
     (one episode each: 819 200 transitions into the device ring) + 200 TD3 optimizer steps (one per lock-step, the reference's
@@ -504,6 +504,11 @@ def bench_water_tank_td3(args, device, json_fd):
     agent = AgentResidualTD3(device=device)
     agent.init(NET_DIM, env.state_dim, 1)
     agent.init_residual({"init_K": env.K.reshape(-1, 1)})
+    agent.dp = dp   # data parallel: every rank its own lanes and ring; both gradients of a step all-reduced (ops.FusedTD3.step_dp)
+    if dp is not None:
+        dp.broadcast_module(agent.act, agent.cri)
+        agent.act_target.load_state_dict(agent.act.state_dict()); agent.cri_target.load_state_dict(agent.cri.state_dict())
+        torch.manual_seed(1000 + rank)
     buf = make_buffer(agent, env, 2 ** 21)
 
     def step():
@@ -513,10 +518,17 @@ def bench_water_tank_td3(args, device, json_fd):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if dp is not None:
+        dp.barrier()
     t0 = time.perf_counter()
     total = sum(step() for _ in range(args.steps))
     torch.cuda.synchronize()
+    if dp is not None:
+        dp.barrier()
     dt = time.perf_counter() - t0
+    if dp is not None:
+        dt = dp.max_over_ranks(dt)
+        total = total * world
     # roofline of the update (92 % of the step): ONE TD3 optimizer step = four hand-written launches (td3_critic_kernel,
     # td3_apply_kernel, td3_actor_kernel, td3_apply_kernel; csrc/td3_fused.hip), the 200 steps of an update replayed as one HIP
     # graph; HIP events around that replay on the stream it runs on.  Algorithmic flops per sample (net_dim 128, D = 4): actor
@@ -558,12 +570,16 @@ def bench_water_tank_td3(args, device, json_fd):
                         "splitting every layer's output features (v_mfma_f32_16x16x4_f32); the exploration is ONE launch per "
                         "explore call (pime_rollout_offpolicy)"}
     out = {"metric": "env-steps/sec (rollout+update), water-tank env, 4096 parallel envs, residual TD3", "value": total / dt,
-           "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "water tank Integrator-v2 (reward 'distance'), 4096 lanes x 200 lock-steps, AgentResidualTD3 "
-                                  "net_dim 128, 200 optimizer steps of batch 4096 per step (one HIP graph per update)"},
+           "config": {"workload": "water tank Integrator-v2 (reward 'distance'), 4096 lanes/GPU x 200 lock-steps, AgentResidualTD3 "
+                                  "net_dim 128, 200 optimizer steps of batch 4096 per step" +
+                                  (" (one HIP graph per update)" if dp is None else
+                                   " per rank (data parallel: five launches + two gradient all-reduces per step, eager)"),
+                      "parallelism": f"dp{world}"},
            "roofline": roofline}
-    emit(json_fd, out)
+    if rank == 0:
+        emit(json_fd, out)
 
 
 def bench_mixed16(args, device, json_fd, rank, world, dp):
@@ -700,7 +716,7 @@ def main():
     if args.workload == "wtmod256":
         return bench_water_tank_256(args, device, json_fd, modular=True)
     if args.workload == "wt_td3":
-        return bench_water_tank_td3(args, device, json_fd)
+        return bench_water_tank_td3(args, device, json_fd, rank, world, dp)
     env, agent, buf = build_stack(device, rank, world, dp)
     timer = KernelTimer()
     # time the hand-written kernels where the agent calls them

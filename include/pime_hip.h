@@ -28,7 +28,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define PIME_ABI_VERSION 18
+#define PIME_ABI_VERSION 19
 
 typedef struct pime_env pime_env; /* opaque: SoA env state + titration LUT replica, resident in HBM */
 typedef void* pime_stream;        /* hipStream_t */
@@ -443,6 +443,10 @@ int64_t pime_td3_workspace_floats(int32_t D, int32_t md, int32_t B);
  *         apply(row) wrote and, behind a soft row, the actor target the actor apply(row) wrote.  So on rows without a soft update
  *         the critic apply may run beside the actor gradients, and the actor apply beside the next row's critic gradients
  *         (AgentTD3._update_fused does that: parallel branches of the update's HIP graph).
+ *         Data-parallel callers split the two apply launches around their all-reduce (mean) of the net's `grad` tensor: 16 = critic slab
+ *         reduction ONLY (grad = this rank's gradient, loss words), 32 = critic Adam (+ soft update) FROM `grad` (no slabs read); 64 / 128
+ *         the same for the actor.  One optimizer step on G ranks: phases 1|16, all-reduce critic grad, phases 32|4|64, all-reduce actor
+ *         grad, phases 128 (order inside a call: 1, 2|16, 32, 4, 8|64, 128; 2 with 16 or 8 with 64 is PIME_ERR_ARG).
  * loss [dev] float32[4] or NULL: [0] += obj_actor, [1] += obj_critic of this step (zero them per update), [2], [3] = this step's values.
  * workspace [dev] float32[pime_td3_workspace_floats]. */
 int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_td3_net* critic, const pime_td3_batch* batch,

@@ -1231,7 +1231,8 @@ int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_t
     PIME_REQUIRE(soft_mode >= 0 && soft_mode <= 2 && (soft_mode != 2 || update_freq >= 1), "pime_td3_step: soft_mode %d / update_freq %d", soft_mode, update_freq);
     PIME_REQUIRE(b->row >= 0, "pime_td3_step: table row %lld", (long long)b->row);
     const int soft = soft_mode == 1 || (soft_mode == 2 && b->row % update_freq == 0);
-    PIME_REQUIRE(phases >= 1 && phases <= 15, "pime_td3_step: phases %d", phases);
+    PIME_REQUIRE(phases >= 1 && phases <= 255 && !((phases & 2) && (phases & 16)) && !((phases & 8) && (phases & 64)),
+                 "pime_td3_step: phases %d", phases);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = td3_grid(b->B), ngroups = (b->B + 15) / 16;
     const Td3SlabLayout LA = td3_actor_slab(D, md), LC = td3_critic_slab(D, md);
@@ -1241,9 +1242,9 @@ int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_t
     // while the critic launch of the NEXT row (other parity) gathers (the caller's two-stream schedule, see include/pime_hip.h)
     float* const xg = slab_a + (size_t)grid * LA.stride + (size_t)(b->row & 1) * b->B * 8;
     Td3Batch tb{b->state, b->other, b->idx, b->nxt, b->noise, (long long)b->row, b->epoch, b->B, b->noise_seed, b->noise_epoch, b->policy_noise, b->noise_clip};
-    auto apply = [&](const pime_td3_net* n, const Td3SlabLayout& L, const float* slab, int slot) {
+    auto apply = [&](const pime_td3_net* n, const Td3SlabLayout& L, const float* slab, int slot, int mode) {
         Td3ApplyArgs a{};
-        a.L = L; a.slab = slab; a.nslabs = grid;
+        a.L = L; a.slab = slab; a.nslabs = grid; a.mode = mode;
         a.param = n->param; a.target = n->target; a.grad = n->grad; a.exp_avg = n->exp_avg; a.exp_avg_sq = n->exp_avg_sq; a.step = n->step;
         a.lr = n->lr; a.b1 = n->beta1; a.b2 = n->beta2; a.eps = n->eps; a.tau = tau;
         a.row = (long long)b->row; a.soft = soft;
@@ -1258,14 +1259,18 @@ int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_t
         Td3GradArgs g{tb, D, actor->target, critic->param, critic->target, slab_c, xg, LC.stride, ngroups, tracing ? trace_dev : nullptr};
         if (int rc = launch_td3_grad(true, md, g, grid, s)) return rc;
     }
-    if (phases & 2)
-        if (int rc = apply(critic, LC, slab_c, 1)) return rc;
+    if (phases & (2 | 16))
+        if (int rc = apply(critic, LC, slab_c, 1, (phases & 16) ? 1 : 0)) return rc;
+    if (phases & 32)
+        if (int rc = apply(critic, LC, slab_c, 1, 2)) return rc;
     if (phases & 4) {
         Td3GradArgs g{tb, D, actor->param, critic->target, nullptr, slab_a, xg, LA.stride, ngroups, tracing ? trace_dev + 32 : nullptr};
         if (int rc = launch_td3_grad(false, md, g, grid, s)) return rc;
     }
-    if (phases & 8)
-        if (int rc = apply(actor, LA, slab_a, 0)) return rc;
+    if (phases & (8 | 64))
+        if (int rc = apply(actor, LA, slab_a, 0, (phases & 64) ? 1 : 0)) return rc;
+    if (phases & 128)
+        if (int rc = apply(actor, LA, slab_a, 0, 2)) return rc;
     if (tracing) {
         long long t[64];
         PIME_HIP_TRY(hipStreamSynchronize(s));

@@ -104,6 +104,8 @@ struct Td3ApplyArgs {
     long long row;             // this launch is Adam step number step[0] + row + 1
     float lr, b1, b2, eps, tau;
     int soft;                  // 1: soft target update in this launch (delayed steps: row % update_freq == 0, agent.py:320-321,330-331)
+    int mode;                  // 0: slab reduction + Adam (+ soft update); data-parallel callers split it around their all-reduce of `grad`:
+                               // 1: slab reduction only (grad = the sum, loss words), 2: Adam (+ soft update) from `grad`, no slabs read
     float* loss;               // [4]: [slot] += value of this step, [2 + slot] = value of this step
     int loss_slot;             // 0: actor objective = -(q sum) / B, 1: critic objective = (loss sum) / B
     float inv_B;

@@ -772,8 +772,14 @@ __global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) 
             pm[k] = a.exp_avg[flat[k]]; pv[k] = a.exp_avg_sq[flat[k]]; pp[k] = a.param[flat[k]];
             if (soft) pt[k] = a.target[flat[k]];
         }
+    float gin[4] = {0.f, 0.f, 0.f, 0.f};   // mode 2: the (all-reduced) gradient stands in for the slab sums
+    if (a.mode == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (flat[k] >= 0) gin[k] = a.grad[flat[k]];
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (unit < nwords) {
+    if (unit < nwords && a.mode != 2) {
         const float* base = a.slab + (size_t)unit * 4;
         const size_t stride = (size_t)a.L.stride;
         int s = g;
@@ -802,9 +808,9 @@ __global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) 
     if (finisher) {
         float4 t = part[0][l];
         for (int w = 1; w < kApplyGroups; ++w) { const float4 v = part[w][l]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-        const float gv[4] = {t.x, t.y, t.z, t.w};
+        const float gv[4] = {a.mode == 2 ? gin[0] : t.x, a.mode == 2 ? gin[1] : t.y, a.mode == 2 ? gin[2] : t.z, a.mode == 2 ? gin[3] : t.w};
         if (scalar_word) {
-            if (a.loss) {
+            if (a.loss && a.mode != 2) {
                 const float val = (a.loss_slot == 0 ? -gv[0] : gv[0]) * a.inv_B;
                 a.loss[a.loss_slot] += val;
                 a.loss[2 + a.loss_slot] = val;
@@ -814,7 +820,8 @@ __global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) 
             for (int k = 0; k < 4; ++k) {
                 if (flat[k] < 0) continue;
                 const long long e = flat[k];
-                a.grad[e] = gv[k];
+                if (a.mode != 2) a.grad[e] = gv[k];
+                if (a.mode == 1) continue;
                 const float mi = pm[k] + (gv[k] - pm[k]) * (1.0f - a.b1);
                 const float vi = pv[k] * a.b2 + gv[k] * gv[k] * (1.0f - a.b2);
                 a.exp_avg[e] = mi;

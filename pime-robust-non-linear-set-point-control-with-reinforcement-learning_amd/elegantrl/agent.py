@@ -750,7 +750,7 @@ class AgentTD3(AgentBase):
 
     def _fused_step(self, batch_size):
         """ops.FusedTD3 serving the current nets, or None -> the PyTorch modules (_one_update)."""
-        if not self.use_fused_update or self.device.type != "cuda" or self.dp is not None or not hasattr(self.backend, "fused_td3"):
+        if not self.use_fused_update or self.device.type != "cuda" or not hasattr(self.backend, "fused_td3"):
             return None
         f = self._fused_td3
         if f is False:
@@ -995,8 +995,9 @@ class AgentTD3(AgentBase):
         f.begin_update()   # table row 0; the noise epoch advances (a captured graph draws fresh noise in every replay)
 
         side = st.get("side")
-        if side is None and self.use_two_streams:
+        if side is None and self.use_two_streams and self.dp is None:
             side = st["side"] = torch.cuda.Stream(device=dev)
+        can_graph = self.use_hip_graphs and self.dp is None   # a data-parallel update launches eagerly: 2 collectives per step
 
         def one(k, phases):   # the row is a launch argument: every node of the captured graph carries its own
             f.step(buffer.buf_state, buffer.buf_other, idx, nxt, noise, self.soft_update_tau, self.update_freq, self.policy_noise,
@@ -1009,6 +1010,17 @@ class AgentTD3(AgentBase):
             (written by the actor's apply on soft rows only).  On the other rows the critic's apply runs beside the actor's
             gradients and the actor's apply beside the next row's critic gradients -- inside the captured graph these are parallel
             branches.  Same arithmetic, same bits as the one-stream order (tests/test_gpu_td3_fused.py)."""
+            if self.dp is not None:
+                # data parallel: a net's slab reduction leaves THIS rank's gradient, the ranks average it, Adam (+ the delayed soft
+                # update) is applied from the averaged tensor -- five launches and two all-reduces per step (ops.FusedTD3.step_dp); G
+                # ranks with their own minibatches make the step of one rank on the union minibatch
+                for k in range(n_steps):
+                    one(k, 1 | 16)
+                    self.dp.all_reduce_mean(f.cri_grad)
+                    one(k, 32 | 4 | 64)
+                    self.dp.all_reduce_mean(f.act_grad)
+                    one(k, 128)
+                return
             if side is None:
                 for k in range(n_steps):
                     one(k, 15)
@@ -1031,8 +1043,8 @@ class AgentTD3(AgentBase):
                     main.wait_stream(side)      # the next critic gradients read the actor target this row's actor apply wrote
 
         key = (buffer.buf_state.data_ptr(), buffer.buf_other.data_ptr(), noise is None, self.soft_update_tau, self.update_freq,
-               self.policy_noise, side is not None)
-        if self.use_hip_graphs and st["warm"] and (st["graph"] is None or st["key"] != key):
+               self.policy_noise, side is not None, self.dp is not None)
+        if can_graph and st["warm"] and (st["graph"] is None or st["key"] != key):
             try:
                 torch.cuda.synchronize(dev)
                 g = torch.cuda.CUDAGraph()
@@ -1044,7 +1056,7 @@ class AgentTD3(AgentBase):
                 self.use_hip_graphs = False
                 torch.cuda.synchronize(dev)
                 st["graph"] = None
-        go = st["graph"].replay if (self.use_hip_graphs and st["graph"] is not None and st["key"] == key) else run
+        go = st["graph"].replay if (can_graph and st["graph"] is not None and st["key"] == key) else run
         if self.launch_timer is not None:
             self.launch_timer("td3_update", go)
         else:

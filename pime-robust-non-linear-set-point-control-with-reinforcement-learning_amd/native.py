@@ -16,7 +16,7 @@ LIB_PATH = _override or os.path.join(PACKAGE_DIR, "libpime_hip.so")
 CSRC = os.path.join(PACKAGE_DIR, "csrc")
 
 OK = 0
-ABI_VERSION = 18
+ABI_VERSION = 19
 ENV_PH, ENV_WT = 0, 1
 STATE_F64, STATE_MIXED, STATE_MIXED16 = 0, 1, 2
 REWARD = {"distance": 0, "square_distance": 1, "sparse": 2}

@@ -446,6 +446,19 @@ class FusedTD3:
         self.row = 0                                                   # table row of the next step (host side: a launch argument)
         self._structs()
 
+    def step_dp(self, all_reduce_mean, *args, row=None, **kw):
+        """One optimizer step of a data-parallel rank: critic gradients + slab reduction, all-reduce (mean) of the critic's gradient,
+        critic Adam + actor gradients + slab reduction, all-reduce of the actor's gradient, actor Adam -- five launches and two
+        collectives.  G ranks with their own minibatches make the step of one rank on the union minibatch."""
+        r = self.row if row is None else int(row)
+        self.step(*args, phases=1 | 16, row=r, **kw)
+        all_reduce_mean(self.cri_grad)
+        self.step(*args, phases=32 | 4 | 64, row=r, **kw)
+        all_reduce_mean(self.act_grad)
+        self.step(*args, phases=128, row=r, **kw)
+        if row is None:
+            self.row += 1
+
     def begin_update(self):
         """Table row 0 again: the steps of the previous update move into the optimizers' step base, the noise epoch advances."""
         if self.row:
@@ -493,7 +506,8 @@ class FusedTD3:
         """One optimizer step on table row `row` (default: self.row, which then advances) of idx / nxt (int64 [rows, B]) and noise
         (float32 [rows, B] or None: Philox in the kernel).  The row is a launch argument: a captured graph of an update's steps
         bakes each step's row into its nodes.  phases: bit 0 critic gradients, 1 critic apply, 2 actor gradients, 3 actor apply
-        (include/pime_hip.h: what may run beside what)."""
+        (include/pime_hip.h: what may run beside what); data-parallel callers split an apply around their all-reduce of cri_grad /
+        act_grad: 16 / 64 = slab reduction only, 32 / 128 = Adam (+ soft update) from the gradient tensor (step_dp)."""
         _need_cuda(buf_state, buf_other, idx, nxt)
         B = idx.shape[-1]
         advance = row is None
@@ -512,5 +526,5 @@ class FusedTD3:
                                                     C.c_float(tau), int(update_freq), int(soft_mode), int(phases),
                                                     native.ptr(self.workspace), native.ptr(self.loss), _stream(buf_state)),
                          "pime_td3_step")
-        if advance and phases & 8:
+        if advance and phases & (8 | 128):
             self.row += 1
