@@ -575,7 +575,8 @@ def bench_water_tank_td3(args, device, json_fd, rank=0, world=1, dp=None):
            "config": {"workload": "water tank Integrator-v2 (reward 'distance'), 4096 lanes/GPU x 200 lock-steps, AgentResidualTD3 "
                                   "net_dim 128, 200 optimizer steps of batch 4096 per step" +
                                   (" (one HIP graph per update)" if dp is None else
-                                   " per rank (data parallel: five launches + two gradient all-reduces per step, eager)"),
+                                   " per rank (data parallel: five launches + two gradient all-reduces per step, one HIP graph per update where "
+                                   "the collective can be captured)"),
                       "parallelism": f"dp{world}"},
            "roofline": roofline}
     if rank == 0:

@@ -997,7 +997,11 @@ class AgentTD3(AgentBase):
         side = st.get("side")
         if side is None and self.use_two_streams and self.dp is None:
             side = st["side"] = torch.cuda.Stream(device=dev)
-        can_graph = self.use_hip_graphs and self.dp is None   # a data-parallel update launches eagerly: 2 collectives per step
+        # data parallel: the two all-reduces of every step are captured inside the update's graph where the communicator allows it
+        # (RCCL: yes; gloo and a refused capture: eager launches, decided for all ranks together)
+        in_graph_dp = (self.dp is not None and getattr(self, "use_graph_collective", True)
+                       and getattr(self.dp, "graph_capturable", False))
+        can_graph = self.use_hip_graphs and (self.dp is None or in_graph_dp)
 
         def one(k, phases):   # the row is a launch argument: every node of the captured graph carries its own
             f.step(buffer.buf_state, buffer.buf_other, idx, nxt, noise, self.soft_update_tau, self.update_freq, self.policy_noise,
@@ -1045,6 +1049,7 @@ class AgentTD3(AgentBase):
         key = (buffer.buf_state.data_ptr(), buffer.buf_other.data_ptr(), noise is None, self.soft_update_tau, self.update_freq,
                self.policy_noise, side is not None, self.dp is not None)
         if can_graph and st["warm"] and (st["graph"] is None or st["key"] != key):
+            refused = None
             try:
                 torch.cuda.synchronize(dev)
                 g = torch.cuda.CUDAGraph()
@@ -1052,7 +1057,16 @@ class AgentTD3(AgentBase):
                     run()
                 st["graph"], st["key"] = g, key
             except RuntimeError as exc:
-                print(f"| HIP graph capture of the TD3 update failed ({exc}); continuing with eager launches")
+                refused = exc
+            if self.dp is not None:
+                # the ranks must agree on the launch form: one MAX over the ranks decides for all of them
+                if self.dp.max_over_ranks(1.0 if refused is not None else 0.0) > 0.5:
+                    print(f"| all-reduce inside the TD3 update's HIP graph refused on a rank ({refused}); every rank launches eagerly")
+                    self.use_graph_collective, can_graph = False, False
+                    torch.cuda.synchronize(dev)
+                    st["graph"] = None
+            elif refused is not None:
+                print(f"| HIP graph capture of the TD3 update failed ({refused}); continuing with eager launches")
                 self.use_hip_graphs = False
                 torch.cuda.synchronize(dev)
                 st["graph"] = None
@@ -1065,6 +1079,8 @@ class AgentTD3(AgentBase):
         f.row = n_steps        # (begin_update of the next call moves them into the optimizers' step base)
         self._n_updates += n_updates
         tot = f.loss.tolist()   # the update's only host synchronisation
+        if self.dp is not None:
+            self.dp.check()     # a timed-out one-shot all-reduce left gradients un-averaged: fatal, here where the stream is drained
         logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
         logger.record("train/actor_loss", tot[0] / n_steps)
         logger.record("train/critic_loss", tot[1] / n_steps)
