@@ -115,3 +115,42 @@ def test_gradient_error_against_float64_autograd_is_reported_for_both_paths():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bf16x3_gradient_error.txt"), "w") as f:
         f.write("gradient error / max |gradient| against float64 autograd of the same minibatch (B = 16 384), tests/test_gpu_bf16x3.py\n" + report + "\n")
+
+
+_PLANES_CHILD = r'''
+import os, sys
+sys.path.insert(0, os.environ["PIME_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PIME_ROOT"], "tests"))
+import numpy as np, torch
+from pime_amd import ops
+from test_gpu_ppo_fused import _make, DEV
+for md in (128, 256):
+    act, cri = _make("resid", md, 3, seed=5)
+    f = ops.FusedPPOGrad(act, cri, 4096)
+    torch.cuda.synchronize()
+    T = md // 16
+    per_layer = (T // 2) * T * 768 * 2          # bf16 elements of one layer's three planes
+    for net, mod in zip(f.nets, (act, cri)):
+        planes = net["img_bwd"][net["n_bwd_f32"]:].cpu().numpy().view(np.uint16)
+        assert planes.size == 4 * per_layer
+        sd = dict(mod.named_parameters())
+        W1, W2 = sd["net.2.weight"].detach().cpu().numpy(), sd["net.4.weight"].detach().cpu().numpy()
+        for name, base, W in (("w1", 0, W1), ("w2", per_layer, W2), ("w2t", 2 * per_layer, W2.T), ("w1t", 3 * per_layer, W1.T)):
+            # image [k-step ks][output tile to][plane][lane (i, g)][e]: W[16 to + i][16 (2 ks + (e >> 2)) + 4 g + (e & 3)]
+            img = (planes[base:base + per_layer].astype(np.uint32) << 16).view(np.float32).reshape(T // 2, T, 3, 4, 16, 2, 4)
+            #                                                                 ks      to plane g   i  e>>2 e&3
+            rec = img.astype(np.float64).sum(axis=2)                       # hi + mid + lo: [ks][to][g][i][eh][el]
+            rec = rec.transpose(1, 3, 0, 4, 2, 5).reshape(md, md)          # [to][i] x [ks][eh][g][el]  (k = 32 ks + 16 eh + 4 g + el)
+            assert np.array_equal(rec.astype(np.float32), W), (md, name, float(np.abs(rec - W).max()))
+            hi = img[:, :, 0].astype(np.float64).transpose(1, 3, 0, 4, 2, 5).reshape(md, md)
+            assert np.abs(hi - W).max() <= 2.0 ** -8 * np.abs(W).max()     # the leading piece alone is W at bf16 precision
+print("PLANES_OK")
+'''
+
+
+def test_bf16_planes_hold_the_weights_exactly_in_the_documented_layout():
+    """The three bf16 planes behind the transposed f32 image, unpacked on the host with the layout DESIGN.md section 4b states, sum to
+    the layer's weights EXACTLY (hi + mid + lo is an exact decomposition of an f32 value), for the forward layers and their
+    transposes, widths 128 and 256; the hi plane alone is the weight at bf16 precision."""
+    env = dict(os.environ, PIME_ROOT=ROOT, PIME_MLP16="1", PIME_GRAD_BF16X3="1")
+    r = subprocess.run([sys.executable, "-c", _PLANES_CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PLANES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
