@@ -566,8 +566,8 @@ def bench_water_tank_td3(args, device, json_fd, rank=0, world=1, dp=None):
                 "algorithmic_flops_per_launch": flops,
                 "algorithmic_flops_split": {"td3_critic_kernel": flops_c, "td3_actor_kernel": flops_a},
                 "note": "avg_launch_ms is one optimizer step (four launches), timed with HIP events around the one-graph replay of an "
-                        "update's 200 steps; batch 4096 = 256 workgroups of one 16-sample tile, the four waves of a workgroup "
-                        "splitting every layer's output features (v_mfma_f32_16x16x4_f32); the exploration is ONE launch per "
+                        "update's 200 steps; batch 4096 = 256 workgroups of one 16-sample tile, the eight waves of a workgroup "
+                        "(two per SIMD) owning one of a layer's eight output-feature tiles each (v_mfma_f32_16x16x4_f32); the exploration is ONE launch per "
                         "explore call (pime_rollout_offpolicy)"}
     out = {"metric": "env-steps/sec (rollout+update), water-tank env, 4096 parallel envs, residual TD3", "value": total / dt,
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

@@ -33,7 +33,8 @@ namespace pime {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kTd3Threads = 256, kTd3Tile = 16;
+constexpr int kTd3Threads = 256, kTd3Tile = 16;   // kTd3Threads: the apply kernel; the gradient kernels run NW * 64
+constexpr int kTd3DefaultWaves = 8;   // measured: 63.1 -> 60.4 us per optimizer step (profiles/r04_u_td3_waves_ab.txt)
 constexpr int kQP = 72, kTP = 4 * kQP;   // chain layout: floats between lane groups / tiles (72 = 16 samples x 4 + 8: the operand reads of the weight gradients hit 32 banks)
 constexpr uint32_t STREAM_TD3_SMOOTH = 3;
 
@@ -164,13 +165,18 @@ __device__ __forceinline__ float head_partial(const float* __restrict__ w, int t
     p += __shfl_xor(p, 32);
     return p;
 }
-// cross-wave sums through LDS: slot = 64 floats [wave][sample]
+// cross-wave sums through LDS: slot = kRedSlot floats [wave][sample] (up to eight waves), summed in wave order
+constexpr int kRedSlot = 128;
 __device__ __forceinline__ void red_put(float* __restrict__ red, int slot, int wave, int lane, float p) {
-    if (lane < 16) red[slot * 64 + wave * 16 + lane] = p;
+    if (lane < 16) red[slot * kRedSlot + wave * 16 + lane] = p;
 }
+template <int NW>
 __device__ __forceinline__ float red_get(const float* __restrict__ red, int slot, int lane) {
-    const float* p = red + slot * 64 + (lane & 15);
-    return ((p[0] + p[16]) + p[32]) + p[48];
+    const float* p = red + slot * kRedSlot + (lane & 15);
+    float s = p[0] + p[16];
+#pragma unroll
+    for (int w = 2; w < NW; ++w) s += p[16 * w];
+    return s;
 }
 
 // ---- weight gradients ----------------------------------------------------------------------------------------------------------------
@@ -265,7 +271,7 @@ __host__ __device__ inline Td3Lds td3_lds(int NT, int D) {
     int o = 0;
     for (int k = 0; k < 4; ++k) { L.buf[k] = o; o += td3_buf_floats(NT); }
     L.xin = o; o += 16 * 16;
-    L.red = o; o += 8 * 64;
+    L.red = o; o += 8 * kRedSlot;
     const int md = NT * 16, sa = td3_small_actor(D, md).total, sc = td3_small_critic(D, md).total;
     L.small[0] = o; o += sa;                 // the launch's actor (critic launch: the target actor)
     L.small[1] = o; o += sc;                 // the launch's critic (critic launch: the online critic; actor launch: the target critic)
@@ -299,9 +305,10 @@ __device__ __forceinline__ float td3_noise(const Td3Batch& b, long long trow, in
 // DD: the state width as a compile-time constant (3: pH, 4: water tank Integrator), 0: read from the arguments.  With DD fixed every
 // offset of the parameter / slab / LDS layouts folds into an immediate; as run-time values they are ~100 live scalars that hipcc
 // spills through VGPR lanes (v_readlane / v_writelane) and re-derives with scalar arithmetic in every phase.
-template <int MD, int DD>
-__global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs a) {
-    constexpr int NT = MD / 16, PER = NT / 4;
+template <int MD, int DD, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void td3_critic_kernel(Td3GradArgs a) {
+    constexpr int NT = MD / 16, PER = NT / NW;
+    static_assert(PER >= 1 && PER * NW == NT, "the waves split a layer's output tiles evenly");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = DD ? DD : a.D, Dc = D + 1;
     const Td3Lds F = td3_lds(NT, D);
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
             for (int n = 0; n < PER; ++n) h[n] = relu4(h[n]);
             red_put(red, 0, wave, lane, head_partial<PER>(at + SA.w4, t0, lane, h));
             TD3_BARRIER();
-            const float pre = red_get(red, 0, lane) + at[SA.b4];
+            const float pre = red_get<NW>(red, 0, lane) + at[SA.b4];
             const float nz = fminf(fmaxf(eps * a.b.policy_noise, -a.b.noise_clip), a.b.noise_clip);   // net.py:109
             next_a = fminf(fmaxf(tanhf(pre) + nz, -1.0f), 1.0f);
         }
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
             red_put(red, 1, wave, lane, head_partial<PER>(ct + SC.q1w, t0, lane, h));
             red_put(red, 2, wave, lane, head_partial<PER>(ct + SC.q2w, t0, lane, h));
             TD3_BARRIER();
-            const float tq1 = red_get(red, 1, lane) + ct[SC.q1b], tq2 = red_get(red, 2, lane) + ct[SC.q2b];
+            const float tq1 = red_get<NW>(red, 1, lane) + ct[SC.q1b], tq2 = red_get<NW>(red, 2, lane) + ct[SC.q2b];
             label = reward + mask * fminf(tq1, tq2);
         }
         TD3_MARK(5);   // target critic: label
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
         // ------------------------------------------------------------------ SmoothL1 x 2 (beta = 1, mean) and its gradient
         float g1 = 0.f, g2 = 0.f;
         {
-            const float d1 = red_get(red, 3, lane) + cr[SC.q1b] - label, d2 = red_get(red, 4, lane) + cr[SC.q2b] - label;
+            const float d1 = red_get<NW>(red, 3, lane) + cr[SC.q1b] - label, d2 = red_get<NW>(red, 4, lane) + cr[SC.q2b] - label;
             const float a1 = fabsf(d1), a2 = fabsf(d2);
             if (valid) {
                 g1 = (a1 < 1.f ? d1 : (d1 > 0.f ? 1.f : -1.f)) * invB;
@@ -518,9 +525,10 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_critic_kernel(Td3GradArgs 
 
 // ======================================================================================================== actor gradients
 // obj_actor = -mean(cri_target.q1(s, tanh(act(s))))  (agent.py:323-324), differentiated down to the actor's parameters
-template <int MD, int DD>
-__global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a) {
-    constexpr int NT = MD / 16, PER = NT / 4;
+template <int MD, int DD, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void td3_actor_kernel(Td3GradArgs a) {
+    constexpr int NT = MD / 16, PER = NT / NW;
+    static_assert(PER >= 1 && PER * NW == NT, "the waves split a layer's output tiles evenly");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = DD ? DD : a.D, Dc = D + 1;
     const Td3Lds F = td3_lds(NT, D);
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
         for (int n = 0; n < PER; ++n) a3[n] = relu4(a3[n]);
         red_put(red, 0, wave, lane, head_partial<PER>(ac + SA.w4, t0, lane, a3));
         TD3_BARRIER();
-        const float act = tanhf(red_get(red, 0, lane) + ac[SA.b4]);
+        const float act = tanhf(red_get<NW>(red, 0, lane) + ac[SA.b4]);
         TD3_MARK(2);   // actor forward
         // ------------------------------------------------------------------ q1 = cri_target.q1(s, action)
         {
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
         load_wt<NT, PER>(a.act + PA.W3, t0, lane, wA);   // dA2 = W3^T dZ3
         TD3_BARRIER();
         TD3_MARK(3);   // target critic forward, dZc2
-        if (valid && wave == 0 && q == 0) q_acc += red_get(red, 1, lane) + ct[SC.q1b];
+        if (valid && wave == 0 && q == 0) q_acc += red_get<NW>(red, 1, lane) + ct[SC.q1b];
         chain_get<NT>(B3, lane, in);
         float dpre;
         {
@@ -641,7 +649,7 @@ __global__ __launch_bounds__(kTd3Threads, 1) void td3_actor_kernel(Td3GradArgs a
             pa += __shfl_xor(pa, 32);
             red_put(red, 2, wave, lane, pa);
             TD3_BARRIER();
-            dpre = red_get(red, 2, lane) * (1.0f - act * act);   // tanh'
+            dpre = red_get<NW>(red, 2, lane) * (1.0f - act * act);   // tanh'
         }
         TD3_MARK(4);   // critic backward to the action
         // ------------------------------------------------------------------ actor backward + weight gradients
@@ -845,13 +853,31 @@ int64_t td3_workspace_floats(int D, int md, int B) {
 }
 bool td3_supported(int D, int A, int md) { return A == 1 && D >= 1 && D <= kTd3MaxD && (md == 64 || md == 128); }
 
-template <int MD, int DD>
-static int launch_grad_d(bool critic, const Td3GradArgs& a, int grid, hipStream_t s) {
+// Waves per workgroup of the gradient kernels at width 128: 4 = one wave per SIMD owning two of a layer's eight output tiles,
+// 8 = two waves per SIMD owning one tile each (the non-MFMA instructions of one wave issue behind the other's MFMAs).
+// Width 64 has four output tiles: four waves.  PIME_TD3_WAVES=4|8 is the A/B knob.
+static int td3_waves(int md) {
+    static const int w = [] {
+        const char* e = std::getenv("PIME_TD3_WAVES");
+        const int v = e ? std::atoi(e) : kTd3DefaultWaves;
+        return v == 8 ? 8 : 4;
+    }();
+    return md == 128 ? w : 4;
+}
+template <int MD, int DD, int NW>
+static int launch_grad_w(bool critic, const Td3GradArgs& a, int grid, hipStream_t s) {
     const size_t lds_bytes = sizeof(float) * (size_t)td3_lds(MD / 16, a.D).total;
-    if (critic) hipLaunchKernelGGL((td3_critic_kernel<MD, DD>), dim3(grid), dim3(kTd3Threads), lds_bytes, s, a);
-    else hipLaunchKernelGGL((td3_actor_kernel<MD, DD>), dim3(grid), dim3(kTd3Threads), lds_bytes, s, a);
+    if (critic) hipLaunchKernelGGL((td3_critic_kernel<MD, DD, NW>), dim3(grid), dim3(NW * 64), lds_bytes, s, a);
+    else hipLaunchKernelGGL((td3_actor_kernel<MD, DD, NW>), dim3(grid), dim3(NW * 64), lds_bytes, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
+}
+template <int MD, int DD>
+static int launch_grad_d(bool critic, const Td3GradArgs& a, int grid, hipStream_t s) {
+    if constexpr (MD == 128) {
+        if (td3_waves(MD) == 8) return launch_grad_w<MD, DD, 8>(critic, a, grid, s);
+    }
+    return launch_grad_w<MD, DD, 4>(critic, a, grid, s);
 }
 template <int MD>
 static int launch_grad(bool critic, const Td3GradArgs& a, int grid, hipStream_t s) {
