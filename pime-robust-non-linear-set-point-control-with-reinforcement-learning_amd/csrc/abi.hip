@@ -1277,8 +1277,9 @@ int pime_td3_step(int32_t D, int32_t md, const pime_td3_net* actor, const pime_t
         PIME_HIP_TRY(hipMemcpy(t, trace_dev, sizeof(t), hipMemcpyDeviceToHost));
         for (int k = 0; k < 2; ++k) {
             std::fprintf(stderr, "[pime td3 trace] %s:", k ? "actor " : "critic");
-            for (int i = 1; i < 32; ++i)
+            for (int i = 1; i < 30; ++i)
                 if (t[32 * k + i]) std::fprintf(stderr, " m%d=%.2f", i, (double)(t[32 * k + i] - t[32 * k]) * 0.01);
+            if (t[32 * k + 30]) std::fprintf(stderr, " shader_cycles=%lld", t[32 * k + 30]);   // s_memtime ticks first mark -> last mark
             std::fprintf(stderr, "\n");
         }
     }

@@ -86,6 +86,10 @@ __device__ __forceinline__ void chain_get(const float* __restrict__ buf, int lan
     const float* p = buf + (lane >> 4) * kQP + (lane & 15) * 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) v[t] = ld4(p + t * kTP);
+    // all NT reads are issued before the first MFMA that consumes one (left alone, hipcc re-uses the consumed weight registers as
+    // destinations and issues the reads two at a time between the MFMAs: four exposed LDS round trips per layer); the counted
+    // lgkmcnt waits are inserted after scheduling, so the MFMAs of k-tile t still wait for read t only
+    __builtin_amdgcn_sched_barrier(0);
 }
 // element (feature 16 t + i, sample 4 s + q) of an image, for the lane (q, i): the A / B operand of a weight-gradient k-step
 __device__ __forceinline__ float chain_elem(const float* __restrict__ buf, int lane, int t, int s) {
@@ -117,15 +121,21 @@ __device__ __forceinline__ void load_wt(const float* __restrict__ W, int t0, int
             for (int r = 0; r < 4; ++r) w[n][kt][r] = W[o + (16 * kt + r) * (NT * 16) + 16 * n];
 }
 
-// out[n] = bias + W in (output tiles t0 .. t0 + PER - 1); bias == nullptr: no bias (the backward chain)
-template <int NT, int PER>
-__device__ __forceinline__ void layer(const f32x4_t (&w)[PER][NT], const float* __restrict__ bias, int t0, int lane,
-                                      const f32x4_t (&in)[NT], f32x4_t (&out)[PER]) {
+// out[n] += W in (output tiles t0 .. t0 + PER - 1).  The caller initialises out: bias_get IN FRONT of the barrier that publishes `in`
+// (the bias lives in the small-tensor image; read behind the barrier it was the youngest LDS read in front of the first MFMA, which
+// then waited for all of the activation's reads -- lgkmcnt(0) -- instead of the first), or zero4 for the backward chain.
+template <int PER>
+__device__ __forceinline__ void bias_get(const float* __restrict__ bias, int t0, int lane, f32x4_t (&out)[PER]) {
 #pragma unroll
-    for (int n = 0; n < PER; ++n) {
-        if (bias) out[n] = ld4(bias + 16 * (t0 + n) + 4 * (lane >> 4));
-        else out[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int n = 0; n < PER; ++n) out[n] = ld4(bias + 16 * (t0 + n) + 4 * (lane >> 4));
+}
+template <int PER>
+__device__ __forceinline__ void zero4(f32x4_t (&out)[PER]) {
+#pragma unroll
+    for (int n = 0; n < PER; ++n) out[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+}
+template <int NT, int PER>
+__device__ __forceinline__ void layer(const f32x4_t (&w)[PER][NT], const f32x4_t (&in)[NT], f32x4_t (&out)[PER]) {
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
@@ -332,6 +342,7 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_critic_kernel(Td3GradArgs a) {
     float* const sl = a.slab + (size_t)blockIdx.x * a.stride;
     float loss_acc = 0.f;   // wave 0, lanes 0..15: this workgroup's loss terms
     TD3_MARK(0);
+    const long long cyc0 = a.trace ? (long long)__builtin_readcyclecounter() : 0;   // shader clock (s_memtime) beside the 100 MHz marks
 
 #pragma unroll 1
     for (int group = blockIdx.x; group < a.ngroups; group += gridDim.x) {
@@ -389,23 +400,25 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_critic_kernel(Td3GradArgs a) {
             for (int n = 0; n < PER; ++n) chain_put(B0, lane, t0 + n, relu4(h[n]));
         }
         load_w<NT, PER>(a.act + PA.W3, t0, lane, wB);
+        f32x4_t hb[PER];   // the next layer's accumulators, initialised with its bias in front of the barrier
+        bias_get<PER>(at + SA.b2, t0, lane, hb);
         TD3_BARRIER();
         TD3_MARK(2);   // target actor layer 1
         chain_get<NT>(B0, lane, in);
         {
-            f32x4_t h[PER];
-            layer<NT, PER>(wA, at + SA.b2, t0, lane, in, h);
+            layer<NT, PER>(wA, in, hb);
 #pragma unroll
-            for (int n = 0; n < PER; ++n) chain_put(B1, lane, t0 + n, relu4(h[n]));
+            for (int n = 0; n < PER; ++n) chain_put(B1, lane, t0 + n, relu4(hb[n]));
         }
         load_w<NT, PER>(a.cri_target + PC.W2, t0, lane, wA);
+        bias_get<PER>(at + SA.b3, t0, lane, hb);
         TD3_BARRIER();
         TD3_MARK(3);   // layer 2
         chain_get<NT>(B1, lane, in);
         float next_a;
         {
-            f32x4_t h[PER];
-            layer<NT, PER>(wB, at + SA.b3, t0, lane, in, h);
+            f32x4_t (&h)[PER] = hb;
+            layer<NT, PER>(wB, in, h);
 #pragma unroll
             for (int n = 0; n < PER; ++n) h[n] = relu4(h[n]);
             red_put(red, 0, wave, lane, head_partial<PER>(at + SA.w4, t0, lane, h));
@@ -425,9 +438,10 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_critic_kernel(Td3GradArgs a) {
             layer_first<PER>(ct + SC.W1, ct + SC.b1, Dc, t0, lane, x0, x1, h);
 #pragma unroll
             for (int n = 0; n < PER; ++n) chain_put(B0, lane, t0 + n, relu4(h[n]));
+            bias_get<PER>(ct + SC.b2, t0, lane, h);
             TD3_BARRIER();
             chain_get<NT>(B0, lane, in);
-            layer<NT, PER>(wA, ct + SC.b2, t0, lane, in, h);
+            layer<NT, PER>(wA, in, h);
 #pragma unroll
             for (int n = 0; n < PER; ++n) h[n] = relu4(h[n]);
             red_put(red, 1, wave, lane, head_partial<PER>(ct + SC.q1w, t0, lane, h));
@@ -445,9 +459,10 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_critic_kernel(Td3GradArgs a) {
             for (int n = 0; n < PER; ++n) { h1[n] = relu4(h1[n]); chain_put(B1, lane, t0 + n, h1[n]); }
         }
         load_wt<NT, PER>(a.cri + PC.W2, t0, lane, wA);   // for dH1 = W2^T dZ2
+        bias_get<PER>(cr + SC.b2, t0, lane, h2);
         TD3_BARRIER();
         chain_get<NT>(B1, lane, in);
-        layer<NT, PER>(wB, cr + SC.b2, t0, lane, in, h2);
+        layer<NT, PER>(wB, in, h2);
 #pragma unroll
         for (int n = 0; n < PER; ++n) h2[n] = relu4(h2[n]);
         red_put(red, 3, wave, lane, head_partial<PER>(cr + SC.q1w, t0, lane, h2));
@@ -501,7 +516,8 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_critic_kernel(Td3GradArgs a) {
         chain_get<NT>(B2, lane, in);
         {
             f32x4_t d1[PER];
-            layer<NT, PER>(wA, nullptr, t0, lane, in, d1);
+            zero4<PER>(d1);
+            layer<NT, PER>(wA, in, d1);
 #pragma unroll
             for (int n = 0; n < PER; ++n) { d1[n] = gate4(d1[n], h1[n]); chain_put(B0, lane, t0 + n, d1[n]); }
             vec_grad<PER>(sl + SL.seg[1].slab_off, t0, lane, d1, accum);   // net_sa.0 bias
@@ -517,6 +533,7 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_critic_kernel(Td3GradArgs a) {
         }
     }
     TD3_MARK(10);   // dW1
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[30] = (long long)__builtin_readcyclecounter() - cyc0;
     if (wave == 0) {
         const float t = row_sum16(loss_acc);
         if (tid == 0) st4(sl + SL.scalar_off, f32x4_t{t, 0.f, 0.f, 0.f});
@@ -551,6 +568,7 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_actor_kernel(Td3GradArgs a) {
     float* const sl = a.slab + (size_t)blockIdx.x * a.stride;
     float q_acc = 0.f;
     TD3_MARK(0);
+    const long long cyc0 = a.trace ? (long long)__builtin_readcyclecounter() : 0;
 
 #pragma unroll 1
     for (int group = blockIdx.x; group < a.ngroups; group += gridDim.x) {
@@ -592,15 +610,17 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_actor_kernel(Td3GradArgs a) {
 #pragma unroll
         for (int n = 0; n < PER; ++n) { a1[n] = relu4(a1[n]); chain_put(B0, lane, t0 + n, a1[n]); }
         load_w<NT, PER>(a.act + PA.W3, t0, lane, wB);
+        bias_get<PER>(ac + SA.b2, t0, lane, a2);   // a layer's accumulators start as its bias, read in front of the barrier
         TD3_BARRIER();
         chain_get<NT>(B0, lane, in);
-        layer<NT, PER>(wA, ac + SA.b2, t0, lane, in, a2);
+        layer<NT, PER>(wA, in, a2);
 #pragma unroll
         for (int n = 0; n < PER; ++n) { a2[n] = relu4(a2[n]); chain_put(B1, lane, t0 + n, a2[n]); }
         load_w<NT, PER>(a.cri + PC.W2, t0, lane, wA);
+        bias_get<PER>(ac + SA.b3, t0, lane, a3);
         TD3_BARRIER();
         chain_get<NT>(B1, lane, in);
-        layer<NT, PER>(wB, ac + SA.b3, t0, lane, in, a3);
+        layer<NT, PER>(wB, in, a3);
 #pragma unroll
         for (int n = 0; n < PER; ++n) a3[n] = relu4(a3[n]);
         red_put(red, 0, wave, lane, head_partial<PER>(ac + SA.w4, t0, lane, a3));
@@ -616,9 +636,10 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_actor_kernel(Td3GradArgs a) {
             for (int n = 0; n < PER; ++n) { c1[n] = relu4(c1[n]); chain_put(B2, lane, t0 + n, c1[n]); }
         }
         load_wt<NT, PER>(a.cri + PC.W2, t0, lane, wB);   // dC1 = W2^T dZc2
+        bias_get<PER>(ct + SC.b2, t0, lane, c2);
         TD3_BARRIER();
         chain_get<NT>(B2, lane, in);
-        layer<NT, PER>(wA, ct + SC.b2, t0, lane, in, c2);
+        layer<NT, PER>(wA, in, c2);
 #pragma unroll
         for (int n = 0; n < PER; ++n) c2[n] = relu4(c2[n]);
         red_put(red, 1, wave, lane, head_partial<PER>(ct + SC.q1w, t0, lane, c2));   // (the value itself only feeds the logged objective)
@@ -637,7 +658,8 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_actor_kernel(Td3GradArgs a) {
         float dpre;
         {
             f32x4_t d[PER];
-            layer<NT, PER>(wB, nullptr, t0, lane, in, d);
+            zero4<PER>(d);
+            layer<NT, PER>(wB, in, d);
             float pa = 0.f;   // d obj / d action = sum_f W1[f][D] dZc1[f]
 #pragma unroll
             for (int n = 0; n < PER; ++n) {
@@ -684,7 +706,8 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_actor_kernel(Td3GradArgs a) {
         chain_get<NT>(B2, lane, in);
         {
             f32x4_t d[PER];
-            layer<NT, PER>(wA, nullptr, t0, lane, in, d);
+            zero4<PER>(d);
+            layer<NT, PER>(wA, in, d);
 #pragma unroll
             for (int n = 0; n < PER; ++n) { d[n] = gate4(d[n], a2[n]); chain_put(B3, lane, t0 + n, d[n]); }
             vec_grad<PER>(sl + SL.seg[3].slab_off, t0, lane, d, accum);    // net.2 bias
@@ -700,7 +723,8 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_actor_kernel(Td3GradArgs a) {
         chain_get<NT>(B3, lane, in);
         {
             f32x4_t d[PER];
-            layer<NT, PER>(wB, nullptr, t0, lane, in, d);
+            zero4<PER>(d);
+            layer<NT, PER>(wB, in, d);
 #pragma unroll
             for (int n = 0; n < PER; ++n) { d[n] = gate4(d[n], a1[n]); chain_put(B1, lane, t0 + n, d[n]); }
             vec_grad<PER>(sl + SL.seg[1].slab_off, t0, lane, d, accum);    // net.0 bias
@@ -716,6 +740,7 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_actor_kernel(Td3GradArgs a) {
         }
     }
     TD3_MARK(8);   // dW1
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[30] = (long long)__builtin_readcyclecounter() - cyc0;
     if (wave == 0) {
         const float t = row_sum16(q_acc);
         if (tid == 0) st4(sl + SL.scalar_off, f32x4_t{t, 0.f, 0.f, 0.f});
