@@ -97,6 +97,13 @@ __device__ __forceinline__ float chain_elem(const float* __restrict__ buf, int l
     return buf[t * kTP + (i >> 2) * kQP + (4 * s + q) * 4 + (i & 3)];
 }
 
+// Timing ablation only (-DPIME_TD3_ABLATE_W: every weight load of the md x md matrices folded into the tensor's first 4 KB -- wrong
+// results, the same instructions; what is left is the step without the L2 -> compute-unit weight stream)
+#ifdef PIME_TD3_ABLATE_W
+#define PIME_TD3_WOFF(x) ((x) & 1023)
+#else
+#define PIME_TD3_WOFF(x) (x)
+#endif
 // ---- weights: global -> registers --------------------------------------------------------------------------------------------------
 // forward: A operand of output tile t0 + n, k-step (kt, r) = W[16 (t0 + n) + i][16 kt + 4 q + r]: component r of one 16-byte load
 // (a wave-uniform base pointer + ONE 32-bit lane offset + compile-time offsets: with a 64-bit per-lane pointer hipcc spends two
@@ -107,7 +114,7 @@ __device__ __forceinline__ void load_w(const float* __restrict__ W, int t0, int 
 #pragma unroll
     for (int n = 0; n < PER; ++n)
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) w[n][kt] = ld4(W + (o + n * 16 * (NT * 16) + 16 * kt));
+        for (int kt = 0; kt < NT; ++kt) w[n][kt] = ld4(W + PIME_TD3_WOFF(o + n * 16 * (NT * 16) + 16 * kt));
 }
 // transposed (dX = W^T dZ): A operand of output (= input-feature) tile t0 + n, k-step (kt, r) = W[16 kt + 4 q + r][16 (t0 + n) + i]
 template <int NT, int PER>
@@ -118,7 +125,7 @@ __device__ __forceinline__ void load_wt(const float* __restrict__ W, int t0, int
 #pragma unroll
         for (int n = 0; n < PER; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[n][kt][r] = W[o + (16 * kt + r) * (NT * 16) + 16 * n];
+            for (int r = 0; r < 4; ++r) w[n][kt][r] = W[PIME_TD3_WOFF(o + (16 * kt + r) * (NT * 16) + 16 * n)];
 }
 
 // out[n] += W in (output tiles t0 .. t0 + PER - 1).  The caller initialises out: bias_get IN FRONT of the barrier that publishes `in`
