@@ -33,6 +33,7 @@
 #include "ppo_device.hpp"
 #include "ppo_train.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace pime {
@@ -1287,9 +1288,16 @@ int launch_repack(const PackArgs& critic, const PackArgs& actor, float* c_fwd, f
 }
 
 int fused_grid(int B) {
+    // PIME_FUSED_GRID=<n>: tuning aid -- fewer workgroups than 256-sample groups, so that a workgroup runs several groups back to
+    // back (the second one from a warm instruction cache); production: one workgroup per group up to 256
+    static const int cap = [] {
+        const char* e = std::getenv("PIME_FUSED_GRID");
+        const int v = e ? std::atoi(e) : 0;
+        return v > 0 && v < 256 ? v : 256;
+    }();
     const int ntiles = (B + 31) / 32;
     int grid = (ntiles + kFusedWaves - 1) / kFusedWaves;
-    return grid > 256 ? 256 : grid;
+    return grid > cap ? cap : grid;
 }
 
 int launch_grad_reduce(const PpoArgs& critic, const PpoArgs& actor, int kind_c, int md_c, int kind_a, int md_a,

@@ -876,8 +876,15 @@ __global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) 
 
 // ======================================================================================================== host side
 int td3_grid(int B) {
+    // PIME_TD3_GRID=<n>: tuning aid -- fewer workgroups than sample tiles, so that a workgroup runs several groups back to back
+    // (the second one from a warm instruction cache); production: one group per workgroup up to kTd3MaxSlabs
+    static const int cap = [] {
+        const char* e = std::getenv("PIME_TD3_GRID");
+        const int v = e ? std::atoi(e) : 0;
+        return v > 0 && v < kTd3MaxSlabs ? v : kTd3MaxSlabs;
+    }();
     const int ngroups = (B + kTd3Tile - 1) / kTd3Tile;
-    return ngroups < kTd3MaxSlabs ? ngroups : kTd3MaxSlabs;
+    return ngroups < cap ? ngroups : cap;
 }
 int64_t td3_workspace_floats(int D, int md, int B) {
     const int64_t g = td3_grid(B);
