@@ -655,8 +655,13 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
         const int64_t* const idx = a.indices + (a.index_row ? (size_t)a.index_row[0] * a.B : 0);
         const long long row = idx[valid ? pos : a.B - 1];
         const float* xrow = a.state + (size_t)row * a.D;
+#ifdef PIME_PPO_ABLATE_STASH   // timing ablation only: every workgroup stashes into the first group's tiles (L2-resident, wrong results)
+        float* st = a.stash + (size_t)wave * T * 1024;
+        const float* st0 = a.stash;
+#else
         float* st = a.stash + (size_t)tile * T * 1024;
         const float* st0 = a.stash + (size_t)group * kFusedWaves * T * 1024;  // the group's first tile
+#endif
         // Stash regions 1 (and 2): the FIRST-layer activations (round 3).  Rounds 1-2 recomputed them from the states wherever the
         // backward needed them -- as B operand of the second layer's weight-gradient rounds and for act'(H1) -- which is ~1 000
         // vector instructions per wave for the critic and ~2 300 (640 of them transcendental pairs) for the modular actor; with
@@ -1054,7 +1059,12 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
 template <int T, int KIND>
 __global__ __launch_bounds__(kFusedThreads) void ppo_fused_kernel(PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // tuning aid: shader-clock ticks (s_memtime) and 100 MHz ticks (s_memrealtime) of the traced workgroup -> the clock the SIMDs ran at
+    const bool timing = a.trace && (int)blockIdx.x == a.trace_wg && threadIdx.x == 0;
+    long long c0 = 0, w0 = 0;
+    if (timing) { c0 = (long long)__builtin_readcyclecounter(); w0 = wall_clock64(); }
     ppo_fused_body<T, KIND, true>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+    if (timing) { a.trace[38] = wall_clock64() - w0; a.trace[39] = (long long)__builtin_readcyclecounter() - c0; }
 }
 
 // Both nets of an optimizer step in ONE launch: workgroups [0, na) run the actor's body, [na, na + nc) the critic's.  The two

@@ -21,7 +21,7 @@ DEV = "cuda:0"
 torch.manual_seed(0)
 cri = CriticAdv(D, md).to(DEV)
 act = (ActorResidualIntegratorModularPPO(md, D, 1, 1) if kind == "modular" else ActorResidualPPO(md, D, 1)).to(DEV)
-L, B = 819200, 65536
+L, B = 819200, int(os.environ.get("GRAD_AB_B", "65536"))
 state = torch.randn(L, D, device=DEV) * 3 + 5
 action = torch.randn(L, device=DEV)
 lp = torch.randn(L, device=DEV) * 0.1 - 1
