@@ -802,7 +802,10 @@ def main():
                     "traffic_source": f"{traffic_src} (rocprofv3 --pmc of this bench, separate FETCH_SIZE / WRITE_SIZE passes, "
                                       "FETCH_SIZE x2)" if traffic_src else None,
                     "launches_per_step": n_dom / args.steps, "avg_launch_ms": ms_dom,
-                    "algorithmic_flops_per_launch": GRAD_FLOPS_PER_SAMPLE * BATCH}
+                    "algorithmic_flops_per_launch": GRAD_FLOPS_PER_SAMPLE * BATCH,
+                    "clock_note": "peak is the guide's figure at 2.4 GHz; s_memtime / s_memrealtime inside these kernels read 2.17 GHz with "
+                                  "all 256 compute units busy (profiles/r04_v_clock_and_group_timing.txt: a recorded measurement, not "
+                                  "taken in this run), at which the f32 matrix peak is 142 TFLOP/s"}
         if os.environ.get("PIME_MLP16"):   # the 16-tile family serves this width: other kernels, no PMC file of theirs
             roofline["kernel"] = ("ppo_minibatch_grad = ppo16m_kernel<8> (modular actor) + ppo16_kernel<8> (critic) + ppo_grad_reduce_kernel "
                                   "(PIME_MLP16=1: the streamed 16-tile family at width 128)")
