@@ -2,10 +2,12 @@
 # tools/training_consoles.sh <tag>: end-to-end training runs through `python -m pime_amd.train` (the reference's CLI), consoles into
 # gpurun_out/<tag>_*_training_console.txt: the headline pH config to 4e8 env-steps, the reference's two water-tank script blocks
 # (ResidualPPO / ResidualIntegratorModularPPO, net_dim 256) to 1e8, and residual TD3 on 4096 tank lanes.
-TAG=$1; OUT=gpurun_out; mkdir -p $OUT; cd ${GRAFT_REPO_ROOT:-/root/repo}
+# tools/training_consoles.sh <tag> td3: the TD3 run only
+TAG=$1; ONLY=$2; OUT=gpurun_out; mkdir -p $OUT; cd ${GRAFT_REPO_ROOT:-/root/repo}
 LOG=/tmp/pime_logs
 run() {
   name=$1; shift
+  if [ "$ONLY" = td3 ] && [ "$name" != wt_residual_td3 ]; then return; fi
   t0=$(date +%s)
   timeout -k 10 400 python -m pime_amd.train "$@" --log_root $LOG > $OUT/${TAG}_${name}_training_console.txt 2>&1
   echo "wall clock of the whole command (imports, table, graph capture, evaluations included): $(( $(date +%s) - t0 )) s" >> $OUT/${TAG}_${name}_training_console.txt
