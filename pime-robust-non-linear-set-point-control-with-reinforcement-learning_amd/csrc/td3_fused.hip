@@ -33,7 +33,7 @@ namespace pime {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kTd3Threads = 256, kTd3Tile = 16;   // kTd3Threads: the apply kernel; the gradient kernels run NW * 64
+constexpr int kTd3Tile = 16;
 constexpr int kTd3DefaultWaves = 8;   // measured: 63.1 -> 60.4 us per optimizer step (profiles/r04_u_td3_waves_ab.txt)
 constexpr int kQP = 72, kTP = 4 * kQP;   // chain layout: floats between lane groups / tiles (72 = 16 samples x 4 + 8: the operand reads of the weight gradients hit 32 banks)
 constexpr uint32_t STREAM_TD3_SMOOTH = 3;
@@ -755,15 +755,26 @@ __global__ __launch_bounds__(NW * 64, 1) void td3_actor_kernel(Td3GradArgs a) {
 }
 
 // ======================================================================================================== slab reduction + Adam + soft update
-// Workgroup = 16 consecutive 16-byte words of the slab layout x 16 slab groups: thread (g, l) sums word l of slabs g, g + 16, ... with
+// Workgroup = kApplyWords (64) consecutive 16-byte words of the slab layout x kApplyGroups (8) slab groups (the first version: 16 x 16;
+// 1 KB contiguous per slab and 32 loads per thread in flight read the freshly written slabs 23 % faster, see the sweep below):
+// thread (g, l) sums word l of slabs g, g + 8, ... with
 // ALL of them in flight at once (the slabs were written by other compute units a kernel ago: every load is an Infinity-Cache / HBM
 // round trip, and the launch is a few hundred workgroups of one such round trip each -- the first version, 64 words x 4 groups with
 // four loads in flight, took 11.5 us of a 78 us optimizer step); the 16 partial sums meet in LDS and are combined in group order
 // (bit-reproducible); the threads of group 0 then own four gradient elements each: they write them, apply torch.optim.Adam (defaults:
 // no weight decay, no amsgrad) to their parameters and, on a delayed step, target = tau * param + (1 - tau) * target (agent.py:116-124,
 // the reference's operand order).
-constexpr int kApplyWords = 16, kApplyGroups = kTd3Threads / kApplyWords;
-__global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) {
+#ifndef PIME_APPLY_WORDS
+#define PIME_APPLY_WORDS 64   // swept at the end of round 4 (words x threads, us per launch): 16x256 9.6, 8x256 11.6, 32x256 8.7, 64x256 8.2, 128x256 10.6,
+                              // 32x512 8.6, 64x512 7.4, 128x512 9.1, 256x512 14.8, 64x1024 7.5, 32x1024 12.8 (profiles/r04_w_td3_apply_shape_sweep.txt)
+#endif
+#ifndef PIME_APPLY_THREADS
+#define PIME_APPLY_THREADS 512
+#endif
+constexpr int kApplyThreads = PIME_APPLY_THREADS;
+constexpr int kApplyWords = PIME_APPLY_WORDS, kApplyGroups = kApplyThreads / kApplyWords;
+constexpr int kApplyBatch = 256 / kApplyGroups > 32 ? 32 : 256 / kApplyGroups;   // slab loads a thread keeps in flight: one batch covers 256 slabs
+__global__ __launch_bounds__(kApplyThreads) void td3_apply_kernel(Td3ApplyArgs a) {
     __shared__ float4 part[kApplyGroups][kApplyWords];
     __shared__ float adam_sh[3];   // [1] step size, [2] sqrt of the second bias correction
     const int tid = threadIdx.x, l = tid & (kApplyWords - 1), g = tid / kApplyWords;
@@ -823,12 +834,12 @@ __global__ __launch_bounds__(kTd3Threads) void td3_apply_kernel(Td3ApplyArgs a) 
         const float* base = a.slab + (size_t)unit * 4;
         const size_t stride = (size_t)a.L.stride;
         int s = g;
-        for (; s + 15 * kApplyGroups < a.nslabs; s += 16 * kApplyGroups) {   // sixteen loads in flight (256 slabs: one batch)
-            float4 v[16];
+        for (; s + (kApplyBatch - 1) * kApplyGroups < a.nslabs; s += kApplyBatch * kApplyGroups) {   // kApplyBatch loads in flight (256 slabs: one batch)
+            float4 v[kApplyBatch];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const float4*>(base + (size_t)(s + kApplyGroups * k) * stride);
+            for (int k = 0; k < kApplyBatch; ++k) v[k] = *reinterpret_cast<const float4*>(base + (size_t)(s + kApplyGroups * k) * stride);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+            for (int k = 0; k < kApplyBatch; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
         }
         for (; s + 3 * kApplyGroups < a.nslabs; s += 4 * kApplyGroups) {
             float4 v[4];
@@ -932,7 +943,7 @@ int launch_td3_grad(bool critic, int md, const Td3GradArgs& a, int grid, hipStre
 }
 int launch_td3_apply(const Td3ApplyArgs& a, hipStream_t s) {
     const int nwords = a.L.stride / 4;
-    hipLaunchKernelGGL(td3_apply_kernel, dim3((nwords + kApplyWords - 1) / kApplyWords), dim3(kTd3Threads), 0, s, a);
+    hipLaunchKernelGGL(td3_apply_kernel, dim3((nwords + kApplyWords - 1) / kApplyWords), dim3(kApplyThreads), 0, s, a);
     PIME_HIP_TRY(hipGetLastError());
     return PIME_OK;
 }
