@@ -1108,6 +1108,10 @@ struct ReduceArgs {
     float* dp_moments;   // not NULL (data parallel): the critic's gradient stays unscaled; [0..2] = sum r, sum r^2, B of this rank's minibatch
 };
 
+#ifndef PIME_REDUCE_BATCH
+#define PIME_REDUCE_BATCH 4
+#endif
+constexpr int kReduceBatch = PIME_REDUCE_BATCH;
 __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
     __shared__ float4 part[8][64];
     __shared__ float scale_sh;
@@ -1210,15 +1214,13 @@ __global__ __launch_bounds__(512) void ppo_grad_reduce_kernel(ReduceArgs a) {
         const size_t stride = (size_t)a.stride[sg.net];
         const int nslabs = a.nslabs[sg.net];
         int s = wave;
-        for (; s + 24 < nslabs; s += 32) {   // four loads in flight
-            const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
-            const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(s + 8) * stride);
-            const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(s + 16) * stride);
-            const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(s + 24) * stride);
-            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        // kReduceBatch loads in flight per thread (summed in slab order whatever the batch: the result does not depend on it)
+        for (; s + 8 * (kReduceBatch - 1) < nslabs; s += 8 * kReduceBatch) {
+            float4 v[kReduceBatch];
+#pragma unroll
+            for (int k = 0; k < kReduceBatch; ++k) v[k] = *reinterpret_cast<const float4*>(base + (size_t)(s + 8 * k) * stride);
+#pragma unroll
+            for (int k = 0; k < kReduceBatch; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
         }
         for (; s < nslabs; s += 8) {
             const float4 v = *reinterpret_cast<const float4*>(base + (size_t)s * stride);
