@@ -35,7 +35,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kTd3Tile = 16;
 constexpr int kTd3DefaultWaves = 8;   // measured: 63.1 -> 60.4 us per optimizer step (profiles/r04_u_td3_waves_ab.txt)
-constexpr int kQP = 72, kTP = 4 * kQP;   // chain layout: floats between lane groups / tiles (72 = 16 samples x 4 + 8: the operand reads of the weight gradients hit 32 banks)
+constexpr int kQP = 72, kTP = 4 * kQP;   // chain layout: floats between lane groups / tiles (72 = 16 samples x 4 + 8: the operand reads of the weight gradients hit 32 banks; pitches 68 .. 88 swept at the end of round 4: the launches take the same 20.0 / 21.7 us)
 constexpr uint32_t STREAM_TD3_SMOOTH = 3;
 
 #define TD3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
