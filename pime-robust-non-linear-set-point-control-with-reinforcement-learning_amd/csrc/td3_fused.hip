@@ -9,8 +9,8 @@
 //
 // Shape of the problem: batch 4 096, nets of width 128 -- 0.48 MFLOP per sample, 2 GFLOP per step.  A sample tile per wave for the
 // whole net (the PPO kernels' decomposition) would occupy 128 of 1 024 SIMDs.  Here a WORKGROUP owns one 16-sample tile and its
-// four waves split every layer's OUTPUT features (v_mfma_f32_16x16x4_f32; wave w computes output tiles [PER w, PER w + PER) of
-// md / 16): batch 4 096 = 256 workgroups = every SIMD of the chip has a wave.  Consequences:
+// NW waves (8 at width 128: two per SIMD; 4 at width 64) split every layer's OUTPUT features (v_mfma_f32_16x16x4_f32; wave w computes
+// output tiles [PER w, PER w + PER) of md / 16, PER = md / 16 / NW): batch 4 096 = 256 workgroups = every SIMD of the chip busy.  Consequences:
 //   * a weight element is used by exactly ONE wave of a workgroup, once: weights go global -> registers (16-byte row pieces of the
 //     nn.Linear tensors themselves: a lane's four consecutive k values of an output row are one global_load_dwordx4), a layer ahead
 //     of their use.  No packed images, no LDS staging, nothing to re-pack after an optimizer step.
