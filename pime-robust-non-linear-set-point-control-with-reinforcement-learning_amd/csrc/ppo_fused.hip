@@ -653,7 +653,11 @@ __device__ __forceinline__ void ppo_fused_body(const PpoArgs& a, float* __restri
         const int pos = tile * 32 + li;
         const bool valid = pos < a.B;
         const int64_t* const idx = a.indices + (a.index_row ? (size_t)a.index_row[0] * a.B : 0);
+#ifdef PIME_PPO_ABLATE_GATHER   // timing ablation only: the minibatch is rows 0 .. B-1 (no index load in front of the row loads; wrong results)
+        const long long row = valid ? pos : a.B - 1;
+#else
         const long long row = idx[valid ? pos : a.B - 1];
+#endif
         const float* xrow = a.state + (size_t)row * a.D;
 #ifdef PIME_PPO_ABLATE_STASH   // timing ablation only: every workgroup stashes into the first group's tiles (L2-resident, wrong results)
         float* st = a.stash + (size_t)wave * T * 1024;
